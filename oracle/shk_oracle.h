@@ -1,0 +1,153 @@
+/*
+ * shk_oracle.h — CPU ORACLE for the sharkmer k-mer counting hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may link, load or
+ * call anything declared here.  The product path (sharkmer_amd/csrc, the
+ * libshk C-ABI) never includes this header and never falls back to it.
+ *
+ * It is a plain-C, single-threaded restatement of the reference algorithm
+ * (caseywdunn/sharkmer v3.1.0, pure Rust).  Every function cites the
+ * reference file:line whose behaviour it restates.  The reference cannot be
+ * built in this image (no cargo/rustc, crates not vendored — SURVEY.md §8c),
+ * so parity is pinned by transcribing every known-answer vector of the
+ * reference's own unit tests (src/kmer/mod.rs:61-305,
+ * src/kmer/counting.rs:365-509) into tests/test_oracle_kat.py, plus a second,
+ * code-independent sort-based oracle (oracle/oracle.py: sort_count_histogram).
+ *
+ * Structure deliberately follows the REFERENCE (per-chunk hash tables,
+ * 1000-read round-robin batches, sequential merge with Histogram::move_count)
+ * and not the GPU design, so that it is an independent check.
+ */
+#ifndef SHK_ORACLE_H
+#define SHK_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_OK 0
+#define ORC_ERR_INVALID_CHAR (-1) /* encoding.rs:353-356 */
+#define ORC_ERR_BAD_K (-2)        /* encoding.rs:333 */
+#define ORC_ERR_K_MISMATCH (-3)   /* counting.rs:158-160,176-178 */
+#define ORC_ERR_NOMEM (-4)
+#define ORC_ERR_NO_READS (-5)     /* io.rs:578-580 */
+#define ORC_ERR_INVARIANT (-6)    /* io.rs:1042-1047,1120-1132 */
+#define ORC_ERR_FASTQ (-7)        /* io.rs:161-198,287-318 */
+#define ORC_ERR_IO (-8)
+
+/* ---- encoding.rs ------------------------------------------------------ */
+
+/* kmers_from_ascii, src/kmer/encoding.rs:332-371.  out must hold at least
+ * len entries (len-k+1 are written at most).  On ORC_ERR_INVALID_CHAR,
+ * *bad_char receives the offending byte. */
+int orc_kmers_from_ascii(const uint8_t *seq, size_t len, int k, uint64_t *out,
+                         size_t *n_out, uint8_t *bad_char);
+/* count_valid_bases, src/kmer/encoding.rs:374-376 */
+uint64_t orc_count_valid_bases(const uint8_t *seq, size_t len);
+/* revcomp_kmer, src/kmer/encoding.rs:219-262 (byte LUT form) */
+uint64_t orc_revcomp_kmer(uint64_t kmer, int k);
+/* Read::from_str, src/kmer/encoding.rs:60-95.  out needs len/4+1 bytes.
+ * Returns number of bytes written or a negative error. */
+long orc_read_from_str(const uint8_t *seq, size_t len, uint8_t *out);
+/* Read::get_kmers, src/kmer/encoding.rs:130-190 (test-only second path). */
+int orc_read_get_kmers(const uint8_t *packed, size_t n_bytes, size_t length,
+                       int k, uint64_t *out, size_t *n_out);
+/* seq_to_kmer / kmer_to_seq, src/kmer/encoding.rs:310-325,378-392 */
+int orc_seq_to_kmer(const uint8_t *seq, size_t len, uint64_t *out);
+void orc_kmer_to_seq(uint64_t kmer, int k, char *out /* k+1 bytes */);
+
+/* ---- counting.rs: KmerCounts ----------------------------------------- */
+
+typedef struct orc_counts orc_counts;
+orc_counts *orc_counts_new(int k);                          /* counting.rs:119-124 */
+orc_counts *orc_counts_new_with_capacity(int k, size_t cap);/* counting.rs:126-131 */
+void orc_counts_free(orc_counts *c);
+int orc_counts_k(const orc_counts *c);
+int orc_counts_ingest_seq(orc_counts *c, const uint8_t *seq, size_t len,
+                          uint8_t *bad_char);               /* counting.rs:144-149 */
+int orc_counts_insert(orc_counts *c, uint64_t kmer, uint32_t count); /* :152-154 */
+int orc_counts_extend(orc_counts *dst, const orc_counts *src);      /* :157-166 */
+uint32_t orc_counts_get_count(const orc_counts *c, uint64_t kmer);  /* :224-226 */
+int orc_counts_contains(const orc_counts *c, uint64_t kmer);        /* :228-231 */
+uint32_t orc_counts_get_canonical_count(const orc_counts *c, uint64_t kmer); /* :205-209 */
+/* get_canonical, :218-222: returns 1 and sets *count if found in either orientation */
+int orc_counts_get_canonical(const orc_counts *c, uint64_t kmer, uint32_t *count);
+uint64_t orc_counts_n_kmers(const orc_counts *c);        /* :254-256 */
+uint64_t orc_counts_n_unique(const orc_counts *c);       /* :258-260 */
+uint32_t orc_counts_max_count(const orc_counts *c);      /* :271-273 */
+uint32_t orc_counts_median_count(const orc_counts *c);   /* :275-298 */
+void orc_counts_remove_low(orc_counts *c, uint32_t min_count); /* :234-237 */
+/* iter(), :239-241: export all (kmer,count) pairs; arrays sized n_unique */
+size_t orc_counts_export(const orc_counts *c, uint64_t *keys, uint32_t *counts);
+
+/* ---- histogram.rs: Histogram ----------------------------------------- */
+
+typedef struct orc_histo orc_histo;
+orc_histo *orc_histo_new(uint64_t histo_max);              /* histogram.rs:19-28 */
+void orc_histo_free(orc_histo *h);
+void orc_histo_move_count(orc_histo *h, uint64_t old_count, uint64_t new_count); /* :51-85 */
+void orc_histo_ingest_counts(orc_histo *h, const orc_counts *c);  /* :31-42 */
+uint64_t orc_histo_get(const orc_histo *h, uint64_t count);       /* :94-101 */
+uint64_t orc_histo_n_kmers(const orc_histo *h);                   /* :103-117 */
+uint64_t orc_histo_n_unique(const orc_histo *h);                  /* :119-123 */
+/* get_vector, :125-134; out has histo_max+2 entries */
+void orc_histo_get_vector(const orc_histo *h, uint64_t *out);
+/* extend_with_histogram, counting.rs:171-202; *any_saturated mirrors :190-200 */
+int orc_counts_extend_with_histogram(orc_counts *dst, const orc_counts *src,
+                                     orc_histo *h, int *any_saturated);
+
+/* ---- chunk.rs + io.rs: the ingest/consolidate driver -------------------- */
+
+typedef struct orc_run orc_run;
+
+typedef struct orc_run_stats {
+  uint64_t n_reads_read;      /* io.rs:337 */
+  uint64_t n_bases_read;      /* io.rs:335 (N included) */
+  uint64_t n_reads_ingested;  /* io.rs:548 Σ chunk.n_reads (= n_subreads_ingested in stats.yaml) */
+  uint64_t n_bases_ingested;  /* io.rs:549 Σ chunk.n_bases (non-N) */
+  uint64_t n_kmers_ingested;  /* io.rs:550 Σ chunk table counts */
+  uint64_t n_unique_kmers;    /* counting.rs:258 of merged table */
+  uint64_t n_hashed_kmers;    /* io.rs:1035 Σ merged counts */
+  uint64_t n_singleton_kmers; /* io.rs:1096-1099 (only chunks>0) */
+  int has_histogram;          /* args.chunks>0 */
+  int any_saturated;          /* counting.rs:190-200 */
+} orc_run_stats;
+
+/* chunks: the CLI value (0 ⇒ one internal chunk, no histogram; io.rs:378). */
+orc_run *orc_run_new(int k, uint32_t chunks, uint64_t histo_max);
+void orc_run_free(orc_run *r);
+/* One FASTQ sequence line, as read_fastq would push it (io.rs:335-343):
+ * counts n_bases_read/n_reads_read, batches 1000, drains round-robin. */
+int orc_run_push_seq(orc_run *r, const uint8_t *seq, size_t len);
+/* Bulk form of the same: concatenated sequences + offsets[n+1]. */
+int orc_run_push_batch(orc_run *r, const uint8_t *bases, const uint64_t *offsets,
+                       size_t n_seqs);
+/* tail drain (io.rs:542-543), totals (:545-552), consolidate_and_histogram
+ * (io.rs:977-1161).  After this, histograms/stats/merged table are readable. */
+int orc_run_finish(orc_run *r);
+const orc_run_stats *orc_run_get_stats(const orc_run *r);
+/* n_chunks × (histo_max+2), row-major by chunk: histo_vecs of io.rs:1020-1028 */
+const uint64_t *orc_run_histograms(const orc_run *r, size_t *n_cols, size_t *len);
+const orc_counts *orc_run_merged(const orc_run *r);
+const char *orc_run_error(const orc_run *r);
+uint8_t orc_run_bad_char(const orc_run *r);
+
+/* Read one (optionally gzip-compressed) FASTQ file into the run, restating
+ * open_fastq_reader (io.rs:598-625) + read_fastq (io.rs:271-352).
+ * max_reads: 0 = unlimited.  validate_every: io.rs:321-322.
+ * *reached_max is set like read_fastq's Ok(true). */
+int orc_run_read_fastq(orc_run *r, const char *path, uint64_t max_reads,
+                       uint64_t validate_every, int *reached_max);
+
+/* Writers (io.rs:1051-1094; stats.rs:27-45,186-193). version e.g. "3.1.0". */
+int orc_run_write_histo(const orc_run *r, const char *path, const char *version);
+int orc_run_write_final_histo(const orc_run *r, const char *path, const char *version);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
