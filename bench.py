@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — Gbases/s of k-mer counting (k=21, 150 bp reads), histograms bit-exact vs CPU.
+
+One "step" = the whole BASELINE.json config-2 job on one GPU: an empty table, one batch of
+synthetic reads already resident in HBM → validate/scan → count → histogram emit.
+With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank counts its own
+shard of reads (weak scaling: per-GPU work fixed); the per-rank tables are exchanged by owner
+page range over RCCL (all_to_all), merged, scanned, and the histograms all-reduced, so the
+emitted histogram is that of the union of all reads.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events
+on the engine's own stream inside libshk (SHK_FLAG_TIMING); `cpu_baseline` times the CPU
+oracle (a single-threaded C restatement of the reference algorithm — "port") on the same
+reads and checks the GPU histogram against it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--k", type=int, default=21)
+    ap.add_argument("--genome", type=int, default=3_000_000)
+    ap.add_argument("--chunks", type=int, default=1)
+    ap.add_argument("--histo-max", type=int, default=10000)
+    ap.add_argument("--path", choices=["auto", "direct", "paged"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0,
+                    help="reads for the CPU baseline (0 = the whole step batch of rank 0)")
+    args = ap.parse_args()
+
+    import torch
+    import sharkmer_amd as sa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+    L = 150
+    n_reads = args.reads
+    # weak scaling: the genome grows with the number of GPUs so the distinct load per GPU and
+    # the coverage (≈50×) stay those of config 2
+    genome = args.genome * n_gpus
+    spec = sa.SynthSpec(genome_len=genome, read_len=L)
+    flags = sa.FLAG_TIMING
+    if args.path == "direct":
+        flags |= sa.FLAG_FORCE_DIRECT
+    elif args.path == "paged":
+        flags |= sa.FLAG_FORCE_PAGED
+    eng = sa.KmerEngine(args.k, args.chunks, args.histo_max, device=dev,
+                        capacity_hint=genome, flags=flags)
+
+    d_bases = torch.empty(n_reads * L, dtype=torch.uint8, device=f"cuda:{dev}")
+    d_offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=f"cuda:{dev}")
+    eng.synth_reads_device(spec, rank * n_reads, n_reads, d_bases.data_ptr(), d_offsets.data_ptr())
+    n_bases = n_reads * L
+
+    if world > 1:
+        from sharkmer_amd.dist import DistCounter
+        dc = DistCounter(eng, dist, device=dev)
+
+    def step():
+        eng.reset()
+        eng.ingest_reads_device(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases)
+        if world > 1:
+            return dc.finalize_histograms()
+        eng.finalize()
+        return eng.histograms()
+
+    for _ in range(args.warmup):
+        step()
+    eng.reset_timings()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hist = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    tim = eng.timings()
+    cnt = eng.counters()
+    total_bases = n_bases * n_gpus * args.steps
+    value = total_bases / dt / 1e9
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (SURVEY.md §8d algorithmic bytes) ----------------
+        kpr = L - args.k + 1
+        n_kmers = n_reads * kpr
+        n_distinct = cnt["n_unique_kmers"] if world == 1 else None
+        count_kernels = {k_: v for k_, v in tim.items() if k_ in ("direct", "scatter", "pages")}
+        dom = max(tim.items(), key=lambda kv: kv[1][0])[0] if tim else None
+        roof = None
+        if count_kernels:
+            # the counting kernels together carry B_alg's per-base and per-k-mer terms
+            ms_count = sum(v[0] for v in count_kernels.values()) / args.steps
+            nd = n_distinct if n_distinct is not None else min(genome, n_kmers)
+            b_alg = n_bases * 1 + n_kmers * 16 + nd * 8
+            achieved = b_alg / (ms_count * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "+".join(sorted(count_kernels)),
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "alg_bytes_per_launch": int(b_alg),
+                    "avg_launch_ms": round(ms_count, 4)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            ns = args.cpu_sample_reads or n_reads
+            hb, ho = sa.synth_reads(spec, 0, ns)
+            t1 = time.perf_counter()
+            ref = orc.run_batch(hb, ho, args.k, args.chunks, args.histo_max)
+            cdt = time.perf_counter() - t1
+            cpu = {"value": round(ns * L / cdt / 1e9, 5), "unit": "Gbases/s", "cores": 1,
+                   "kind": "port",
+                   "sample": f"{ns} reads x {L} bp of the step batch (rank 0 shard), "
+                             f"single-threaded C restatement of sharkmer's counting path"}
+            if world == 1 and ns == n_reads:
+                exact = bool(np.array_equal(hist, ref.histograms()))
+                cpu["histogram_bit_exact"] = exact
+                if not exact:
+                    print("ERROR: GPU histogram differs from the CPU oracle", file=sys.stderr)
+                    sys.exit(2)
+        out = {
+            "metric": "Gbases/sec k-mer counted (k=21, 150bp reads); histogram bit-exact vs CPU",
+            "value": round(value, 4), "unit": "Gbases/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: {n_reads} synthetic {L}bp reads per GPU, "
+                                   f"k={args.k}, {n_gpus}xMI355X, single hash-table shard per GPU; "
+                                   f"step = reset + count + histogram emit, input resident in HBM",
+                       "reads_per_gpu": n_reads, "k": args.k, "chunks": args.chunks,
+                       "genome": genome, "path": args.path},
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in tim.items()},
+            "dominant_kernel": dom,
+            "table": {"capacity": cnt["table_capacity"], "n_unique": cnt["n_unique_kmers"],
+                      "n_grows": cnt["n_grows"], "n_spilled": cnt["n_spilled"]},
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+/*
+ * shk.h — C ABI of libshk, the MI355X-native k-mer counting engine.
+ *
+ * Drop-in boundary for the hot path of caseywdunn/sharkmer v3.1.0 (pure Rust,
+ * no FFI seam of its own): the seam sits where the reference's src/io.rs calls
+ * into src/kmer/ — drain_batch → Chunk::ingest_seq (io.rs:355-361,
+ * kmer/chunk.rs:25-30) and consolidate_and_histogram →
+ * KmerCounts::extend_with_histogram / Histogram::get_vector (io.rs:1021-1028).
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions (mirroring the reference's anyhow::Result-to-main behaviour,
+ * SURVEY.md §8b): every function returns SHK_OK (0) or a negative SHK_ERR_*;
+ * the message a reference run would have printed is available from
+ * shk_last_error().  No exceptions, no unwinding, no torch types: plain
+ * pointers and sizes only.  One caller thread per context (the reference's
+ * counting is single-threaded); the library uses HIP streams internally.
+ *
+ * There is NO CPU fallback: shk_create fails with SHK_ERR_NO_DEVICE when no
+ * gfx950 device is usable.
+ */
+#ifndef SHK_H
+#define SHK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHK_ABI_VERSION 1
+
+#define SHK_OK 0
+#define SHK_ERR_INVALID_CHAR (-1) /* kmer/encoding.rs:353-356 */
+#define SHK_ERR_BAD_ARG (-2)      /* cli.rs:659-677; encoding.rs:333 */
+#define SHK_ERR_K_MISMATCH (-3)   /* counting.rs:158-160 */
+#define SHK_ERR_NOMEM (-4)
+#define SHK_ERR_NO_READS (-5)     /* io.rs:578-580 */
+#define SHK_ERR_INVARIANT (-6)    /* io.rs:1042-1047, 1120-1132 */
+#define SHK_ERR_FASTQ (-7)        /* io.rs:161-198, 287-318 */
+#define SHK_ERR_IO (-8)
+#define SHK_ERR_NO_DEVICE (-9)
+#define SHK_ERR_HIP (-10)
+#define SHK_ERR_STATE (-11)       /* call out of order / poisoned context */
+
+#define SHK_READS_PER_BATCH 1000u /* N_READS_PER_BATCH, io.rs:15 */
+
+/* flags */
+#define SHK_FLAG_TIMING 1u        /* bracket every kernel with HIP events */
+#define SHK_FLAG_FORCE_DIRECT 2u  /* count with the global-atomic kernel only */
+#define SHK_FLAG_FORCE_PAGED 4u   /* count with the LDS-page kernels only */
+
+typedef struct shk_ctx shk_ctx;
+
+typedef struct shk_config {
+  uint32_t k;          /* 0 < k < 32 (encoding.rs:333; CLI adds "odd", cli.rs:667) */
+  uint32_t chunks;     /* CLI --chunks: 0 ⇒ one internal chunk and no histogram (io.rs:378) */
+  uint64_t histo_max;  /* 0 < histo_max ≤ 1_000_000 (cli.rs:668-673) */
+  int32_t device;      /* HIP device ordinal */
+  uint32_t flags;      /* SHK_FLAG_* */
+  uint64_t table_capacity_hint; /* expected distinct k-mers; 0 = start small and grow */
+  uint64_t reserved[4];
+} shk_config;
+
+/* io.rs:545-552 and counting.rs:254-260 totals, plus device-side facts */
+typedef struct shk_counters {
+  uint64_t n_reads_ingested;  /* Σ Chunk::n_reads (chunk.rs:27) */
+  uint64_t n_bases_read;      /* Σ sequence lengths, N included (io.rs:335) */
+  uint64_t n_bases_ingested;  /* Σ Chunk::n_bases = non-N bytes (chunk.rs:28) */
+  uint64_t n_kmers_ingested;  /* Σ over chunks of Σ table counts (io.rs:550) */
+  uint64_t n_unique_kmers;    /* merged table len (counting.rs:258) — valid after finalize */
+  uint64_t n_hashed_kmers;    /* Σ merged counts (io.rs:1035) — valid after finalize */
+  uint64_t n_singleton_kmers; /* last column [1] (io.rs:1096-1099) — chunks>0 only */
+  uint32_t any_saturated;     /* counting.rs:190-200 */
+  uint32_t n_chunks;          /* internal chunk count (≥1) */
+  uint64_t table_capacity;    /* slots */
+  uint64_t n_grows;           /* table doublings so far */
+  uint64_t n_spilled;         /* k-mers that took the spill path */
+} shk_counters;
+
+/* Accumulated per-kernel device time (HIP events on the engine's stream);
+ * filled only when SHK_FLAG_TIMING is set. */
+#define SHK_N_KERNELS 16
+typedef struct shk_timings {
+  double ms[SHK_N_KERNELS];
+  uint64_t launches[SHK_N_KERNELS];
+} shk_timings;
+/* kernel ids for shk_timings */
+enum {
+  SHK_K_MARK = 0,      /* read-start bitmap + tile list */
+  SHK_K_SCAN = 1,      /* validate / count bases / partition histogram */
+  SHK_K_DIRECT = 2,    /* extract + global-atomic insert */
+  SHK_K_SCATTER = 3,   /* extract + partition scatter */
+  SHK_K_PAGES = 4,     /* LDS page count */
+  SHK_K_HISTO = 5,     /* table scan → histograms + totals */
+  SHK_K_GROW = 6,      /* rehash into a bigger table */
+  SHK_K_INSERT = 7,    /* (kmer,count) insert / spill re-insert */
+  SHK_K_LOOKUP = 8,
+  SHK_K_EXPORT = 9,
+  SHK_K_SYNTH = 10,
+  SHK_K_MERGE = 11
+};
+
+/* ---- lifecycle ------------------------------------------------------------ */
+
+/* Replaces Chunk::new ×n_chunks (io.rs:378-379) + Histogram::new (io.rs:1021).
+ * Validates the cli.rs:659-677 ranges except "k odd" (a CLI rule; the kmer
+ * module itself accepts any 0<k<32, encoding.rs:333). */
+int shk_create(const shk_config *cfg, shk_ctx **out);
+/* Drop of FastqReadState / KmerCounts. */
+void shk_destroy(shk_ctx *ctx);
+/* Back to the state right after shk_create (empty chunks, zero counters), keeping the
+ * allocated table and scratch: a fresh FastqReadState (io.rs:381-387) without re-allocating. */
+int shk_reset(shk_ctx *ctx);
+/* The anyhow message of the last failure on this context ("" if none).
+ * ctx == NULL returns the message of the last failed shk_create on this thread. */
+const char *shk_last_error(const shk_ctx *ctx);
+int shk_abi_version(void);
+
+/* ---- ingest ----------------------------------------------------------------- */
+
+/* Replaces the body of drain_batch (io.rs:356-358): every sequence of the
+ * batch goes to chunk `chunk_id` (Chunk::ingest_seq, chunk.rs:25-30).
+ * bases: concatenated ASCII sequences; offsets[n_seqs+1] byte offsets into
+ * bases.  Host buffers, caller-owned, may be freed after return.
+ * Any byte outside ACGTN ⇒ SHK_ERR_INVALID_CHAR, message identical to
+ * encoding.rs:353-356, context poisoned (the reference aborts the run). */
+int shk_ingest_batch(shk_ctx *ctx, uint32_t chunk_id, const uint8_t *bases,
+                     const uint64_t *offsets, uint64_t n_seqs);
+
+/* Replaces read_fastq's push + drain_batch cadence (io.rs:335-343, 355-361)
+ * for a run of sequences in input order: the engine keeps the running read
+ * index i and sends read i to chunk (i / 1000) % n_chunks. */
+int shk_ingest_reads(shk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets,
+                     uint64_t n_seqs);
+
+/* Same as shk_ingest_reads with input already resident in device memory
+ * (d_bases: n_bases bytes, d_offsets: n_seqs+1 u64).  Asynchronous on the
+ * engine stream; errors surface at the next synchronising call. */
+int shk_ingest_reads_device(shk_ctx *ctx, const void *d_bases, const void *d_offsets,
+                            uint64_t n_seqs, uint64_t n_bases);
+
+/* Replaces KmerCounts::insert (counting.rs:152-154) on chunk `chunk_id`:
+ * saturating add of counts[i] to kmers[i]. Host buffers. */
+int shk_insert_counts(shk_ctx *ctx, uint32_t chunk_id, const uint64_t *kmers,
+                      const uint32_t *counts, uint64_t n);
+
+/* Wait for all queued device work; report deferred errors. */
+int shk_sync(shk_ctx *ctx);
+
+/* ---- consolidate ----------------------------------------------------------- */
+
+/* Replaces the merge loop of consolidate_and_histogram (io.rs:1023-1028 for
+ * chunks>0, io.rs:1135-1138 for chunks==0) and its invariants
+ * (io.rs:1042-1047, 1120-1132).  SHK_ERR_NO_READS mirrors io.rs:578-580.
+ * Idempotent; ingest after finalize re-opens the context. */
+int shk_finalize(shk_ctx *ctx);
+
+/* histo_vecs of io.rs:1020-1028: chunks × (histo_max+2) u64, row-major by
+ * chunk; column j = Histogram::get_vector() after merging chunks 0..j
+ * (histogram.rs:125-134).  chunks==0 ⇒ nothing is written, returns SHK_OK. */
+int shk_histograms(shk_ctx *ctx, uint64_t *out);
+
+int shk_get_counters(shk_ctx *ctx, shk_counters *out);
+int shk_get_timings(shk_ctx *ctx, shk_timings *out);
+int shk_reset_timings(shk_ctx *ctx);
+
+/* ---- merged-table read API (counting.rs:205-260) --------------------------------- */
+
+/* KmerCounts::iter (counting.rs:239-241) over the merged table: writes up to
+ * cap (kmer,count) pairs in unspecified order; *n_out = number of entries. */
+int shk_export_table(shk_ctx *ctx, uint64_t *kmers, uint32_t *counts, uint64_t cap,
+                     uint64_t *n_out);
+/* KmerCounts::get_count (canonical=0, counting.rs:224-226) or
+ * get_canonical_count (canonical=1: min(kmer, revcomp), counting.rs:205-209). */
+int shk_lookup(shk_ctx *ctx, const uint64_t *kmers, uint32_t *counts, uint64_t n,
+               int canonical);
+
+/* ---- multi-GPU hooks (device pointers; exchanged by the caller over RCCL) ---- */
+
+/* Table geometry needed to shard by owner: n_pages (power of two),
+ * page_slots, n_lanes.  Pages [p0,p1) are contiguous in every array. */
+int shk_table_geometry(shk_ctx *ctx, uint64_t *n_pages, uint32_t *page_slots,
+                       uint32_t *n_lanes);
+/* Grow the table until it has at least n_pages pages (all ranks must agree
+ * before exchanging page ranges). */
+int shk_table_reserve_pages(shk_ctx *ctx, uint64_t n_pages);
+/* Device pointers to the live table arrays: keys u64[n_pages*page_slots],
+ * vals u32[n_lanes][n_pages*page_slots]. Valid until the next growing call. */
+int shk_table_device_ptrs(shk_ctx *ctx, void **d_keys, void **d_vals);
+/* KmerCounts::extend across devices (counting.rs:157-166): merge a peer's
+ * page range [p0,p1) (same geometry; device pointers to its keys and
+ * lane-major vals for that range) into this table, saturating per lane. */
+int shk_merge_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1, const void *d_keys,
+                    const void *d_vals);
+/* Restrict finalize's histogram scan to pages [p0,p1) (owner shard). */
+int shk_set_owned_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1);
+
+/* ---- pinned staging buffers for streaming hosts -------------------------------- */
+void *shk_alloc_pinned(size_t bytes);
+void shk_free_pinned(void *p);
+void *shk_alloc_device(shk_ctx *ctx, size_t bytes);
+void shk_free_device(shk_ctx *ctx, void *p);
+
+/* ---- synthetic reads, generated on device ------------------------ */
+
+typedef struct shk_synth {
+  uint64_t seed_genome;   /* 0x5EED0001 */
+  uint64_t seed_reads;    /* 0x5EED0002 */
+  uint64_t genome_len;    /* G */
+  uint32_t read_len;      /* 150 */
+  uint32_t sub_per_64k;   /* substitution errors per 65536 bases (0 = error-free) */
+  uint32_t n_per_64k;     /* N per 65536 bases */
+  uint32_t reserved;
+} shk_synth;
+/* Writes reads [first_read, first_read+n_reads) as ASCII to d_bases
+ * (n_reads*read_len bytes) and offsets to d_offsets (n_reads+1 u64). */
+int shk_synth_reads_device(shk_ctx *ctx, const shk_synth *spec, uint64_t first_read,
+                           uint64_t n_reads, void *d_bases, void *d_offsets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,694 @@
+// shk_device.hip.h — gfx950 device code of libshk (hand-written HIP, wave64).
+//
+// Data layout in HBM:
+//   bases      u8 [n_bases]             concatenated ASCII reads (as handed over)
+//   startbits  u32[n_bases/32+2]        bit p set ⇔ position p is the first base of a read
+//   tiles      TileDesc[n_tiles]        ≤TILE_T-base spans, never crossing a 1000-read block
+//   keys       u64[n_pages*PAGE_SLOTS]  canonical k-mer or EMPTY; page = top hash bits,
+//                                       linear probing confined to the page
+//   vals       u32[n_lanes][capacity]   per-chunk-lane counts, lane-major
+//
+// Reference semantics reproduced (file:line under /root/reference):
+//   extraction   src/kmer/encoding.rs:332-371 (kmers_from_ascii), :374-376
+//   counting     src/kmer/counting.rs:82-85 (entry().or_insert(0); saturating_add)
+//   histogram    src/kmer/counting.rs:171-202 + src/kmer/histogram.rs:51-85,125-134
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace shk {
+
+constexpr uint64_t EMPTY = 0xFFFFFFFFFFFFFFFFull;  // never a k-mer: k<32 ⇒ key < 2^62
+constexpr int PAGE_LOG = 12;
+constexpr uint32_t PAGE_SLOTS = 1u << PAGE_LOG;     // 4096 slots: 32 KiB keys + 16 KiB vals in LDS
+constexpr int WG = 256;                             // 4 waves
+constexpr int TILE_T = 16384;                       // k-mer end positions per tile
+constexpr int SPAN = TILE_T / WG;                   // 64 end positions per thread
+constexpr int HALO = 32;                            // ≥ k-1 bases before the tile (k ≤ 31)
+constexpr int TILE_LDS = TILE_T + HALO;
+
+struct TileDesc {
+  uint64_t begin;  // first k-mer END position owned by the tile
+  uint64_t end;    // one past the last
+  uint32_t lane;   // chunk lane of the enclosing 1000-read block
+  uint32_t pad;
+};
+
+struct DevStats {
+  unsigned long long n_distinct;   // keys inserted so far (all launches)
+  unsigned long long spill_count;  // entries in the spill list (this launch)
+  unsigned long long bad;          // min over (position<<8 | byte) of invalid bytes; ~0 = none
+  unsigned long long n_tiles;      // written by k_build_tiles
+  unsigned long long scratch[4];
+};
+
+struct TableRef {
+  uint64_t *keys;
+  uint32_t *vals;
+  uint64_t cap;      // n_pages * PAGE_SLOTS
+  uint32_t log_pages;
+  uint32_t n_lanes;
+};
+
+struct BatchRef {
+  const uint8_t *bases;
+  const uint32_t *startbits;
+  uint64_t n_bases;
+  const TileDesc *tiles;  // nullptr ⇒ one block: tile t = [t*TILE_T, …) ∩ [0,n_bases), lane = lane0
+  const DevStats *stats;  // n_tiles lives here when tiles != nullptr
+  uint64_t n_tiles_single;
+  uint64_t tile_first;  // this launch covers tiles [tile_first, tile_first + tile_count)
+  uint64_t tile_count;
+  uint32_t lane0;
+  int k;
+};
+
+struct SpillRef {
+  uint64_t *keys;
+  uint32_t *lanes;
+  uint32_t *counts;
+  uint64_t cap;
+};
+
+// ---- hashing: 2-round multiply/xorshift; page from the top bits, in-page slot from
+// the next 12.  Results never depend on it — only speed does.
+__device__ __forceinline__ uint64_t hash64(uint64_t key) {
+  uint64_t h = key * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 32;
+  h *= 0xD6E8FEB86659FD93ull;
+  return h;
+}
+__device__ __forceinline__ uint64_t page_of(uint64_t h, uint32_t log_pages) {
+  return log_pages ? (h >> (64 - log_pages)) : 0ull;
+}
+__device__ __forceinline__ uint32_t slot_of(uint64_t h, uint32_t log_pages) {
+  return (uint32_t)(h >> (64 - PAGE_LOG - log_pages)) & (PAGE_SLOTS - 1);
+}
+
+__device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
+  uint32_t s = a + b;
+  return s < a ? 0xFFFFFFFFu : s;
+}
+
+// ---- tile geometry -------------------------------------------------------------------
+__device__ __forceinline__ bool tile_get(const BatchRef &b, uint64_t t, uint64_t &t0, uint64_t &t1,
+                                         uint32_t &lane) {
+  if (t >= b.tile_count) return false;
+  t += b.tile_first;
+  if (b.tiles) {
+    if (t >= b.stats->n_tiles) return false;
+    TileDesc d = b.tiles[t];
+    t0 = d.begin;
+    t1 = d.end;
+    lane = d.lane;
+  } else {
+    if (t >= b.n_tiles_single) return false;
+    t0 = t * (uint64_t)TILE_T;
+    t1 = t0 + TILE_T < b.n_bases ? t0 + TILE_T : b.n_bases;
+    lane = b.lane0;
+  }
+  return true;
+}
+
+// ASCII → code for 4 bytes at once: A,C,G,T → 0..3 via ((c>>1)^(c>>2))&3; 'N' → 4.
+// (Validity is established by k_scan before any counting kernel runs.)
+__device__ __forceinline__ uint32_t codes4(uint32_t w) {
+  uint32_t c = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
+  uint32_t t = w ^ 0x4E4E4E4Eu;  // zero byte ⇔ 'N'
+  uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 per zero byte
+  return c | (z >> 5);  // 'N' (0x4E) already maps to base bits 00
+}
+
+// Stage positions [t0-HALO, t0+TILE_T) of the batch into LDS as one code byte per base:
+// bits 0-1 base, bit 2 = N / outside the batch (resets the window), bit 3 = first base
+// of a read (resets the window before the base is taken).  encoding.rs:341-352.
+__device__ __forceinline__ void stage_tile(const BatchRef &b, uint64_t t0, uint8_t *lds) {
+  const int64_t p0 = (int64_t)t0 - HALO;
+  for (int m = threadIdx.x; m < TILE_LDS / 16; m += WG) {
+    int64_t p = p0 + (int64_t)m * 16;
+    uint32_t w[4];
+    if (p >= 0 && (uint64_t)p + 16 <= b.n_bases) {
+      __builtin_memcpy(w, b.bases + p, 16);  // unaligned 16-B global load (one dwordx4)
+      w[0] = codes4(w[0]);
+      w[1] = codes4(w[1]);
+      w[2] = codes4(w[2]);
+      w[3] = codes4(w[3]);
+    } else {
+      for (int q = 0; q < 4; ++q) {
+        uint32_t ww = 0;
+        for (int r = 0; r < 4; ++r) {
+          int64_t pp = p + q * 4 + r;
+          uint32_t c = 4;
+          if (pp >= 0 && (uint64_t)pp < b.n_bases) {
+            uint32_t a = b.bases[pp];
+            c = a == 'N' ? 4u : (((a >> 1) ^ (a >> 2)) & 3u);
+          }
+          ww |= c << (8 * r);
+        }
+        w[q] = ww;
+      }
+    }
+    // read-start flags for these 16 positions: bits [p, p+16) of startbits
+    uint32_t f = 0;
+    if (p >= 0 && (uint64_t)p < b.n_bases) {
+      uint64_t wi = (uint64_t)p >> 5;
+      uint32_t sh = (uint32_t)p & 31;
+      uint64_t two = (uint64_t)b.startbits[wi] | ((uint64_t)b.startbits[wi + 1] << 32);
+      f = (uint32_t)(two >> sh) & 0xFFFFu;
+    } else if (p < 0 && p + 16 > 0) {  // straddles position 0
+      uint32_t lo = b.startbits[0];
+      f = (lo << (uint32_t)(-p)) & 0xFFFFu;
+    }
+    if (f) {
+      for (int q = 0; q < 4; ++q) {
+        uint32_t fq = (f >> (4 * q)) & 0xF;
+        // spread 4 flag bits into bit 3 of 4 bytes
+        uint32_t s = ((fq & 1) << 3) | ((fq & 2) << 10) | ((fq & 4) << 17) | ((fq & 8) << 24);
+        w[q] |= s;
+      }
+    }
+    uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4 *>(lds + m * 16) = v;
+  }
+}
+
+// Walk this thread's SPAN end positions of the staged tile and hand every canonical
+// k-mer to emit(kmer).  Rolling forward/reverse frames exactly as encoding.rs:359-367.
+template <class Emit>
+__device__ __forceinline__ void walk_tile(const uint8_t *lds, uint64_t t0, uint64_t t1, int k,
+                                          Emit &&emit) {
+  const uint64_t mask = (1ull << (2 * k)) - 1;
+  const int rsh = 2 * (k - 1);
+  const int e0 = threadIdx.x * SPAN;  // first end position (tile-relative)
+  const int n_end = (int)(t1 - t0);   // valid end positions in this tile
+  if (e0 >= n_end) return;
+  // start k-1 bases early, rounded down to a multiple of 8 for ds_read_b64
+  int j0 = (HALO + e0 - (k - 1)) & ~7;
+  const int jend = HALO + (e0 + SPAN < n_end ? e0 + SPAN : n_end);
+  const int jemit = HALO + e0;
+  uint64_t fwd = 0, rev = 0;
+  int n_valid = 0;
+  for (int j = j0; j < jend; j += 8) {
+    uint64_t w = *reinterpret_cast<const uint64_t *>(lds + j);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint32_t c = (uint32_t)(w >> (8 * r)) & 0xFF;
+      int jj = j + r;
+      if (c & 8) n_valid = 0;
+      uint64_t bb = c & 3;
+      fwd = ((fwd << 2) | bb) & mask;
+      rev = (rev >> 2) | ((3 - bb) << rsh);
+      n_valid = (c & 4) ? 0 : n_valid + 1;
+      if (n_valid >= k && jj >= jemit && jj < jend) emit(fwd < rev ? fwd : rev);
+    }
+  }
+}
+
+// ---- open-addressing probe inside one page ----------------------------------------------
+// Keys only ever go EMPTY → key, so a stale read can only show EMPTY where a key already
+// sits; the device-scope CAS is the arbiter.  Returns the slot index or -1 (page full).
+__device__ __forceinline__ int64_t find_or_insert(uint64_t *keys, uint64_t base, uint32_t s0,
+                                                  uint64_t key, bool &inserted) {
+  uint32_t s = s0;
+  for (uint32_t i = 0; i < PAGE_SLOTS; ++i) {
+    uint64_t cur = __hip_atomic_load(&keys[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == key) return (int64_t)(base + s);
+    if (cur == EMPTY) {
+      uint64_t prev = atomicCAS((unsigned long long *)&keys[base + s], (unsigned long long)EMPTY,
+                                (unsigned long long)key);
+      if (prev == EMPTY) {
+        inserted = true;
+        return (int64_t)(base + s);
+      }
+      if (prev == key) return (int64_t)(base + s);
+    }
+    s = (s + 1) & (PAGE_SLOTS - 1);
+  }
+  return -1;
+}
+
+__device__ __forceinline__ int64_t find_slot(const uint64_t *keys, uint64_t base, uint32_t s0,
+                                             uint64_t key) {
+  uint32_t s = s0;
+  for (uint32_t i = 0; i < PAGE_SLOTS; ++i) {
+    uint64_t cur = keys[base + s];
+    if (cur == key) return (int64_t)(base + s);
+    if (cur == EMPTY) return -1;
+    s = (s + 1) & (PAGE_SLOTS - 1);
+  }
+  return -1;
+}
+
+// saturating add of an arbitrary delta (counting.rs:82-92 semantics) by CAS
+__device__ __forceinline__ void sat_add_cas(uint32_t *p, uint32_t delta) {
+  uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    uint32_t nv = sat_add_u32(old, delta);
+    if (nv == old) return;
+    uint32_t prev = atomicCAS(p, old, nv);
+    if (prev == old) return;
+    old = prev;
+  }
+}
+
+// ==========================================================================================
+// K_MARK: read-start bitmap.  One thread per read.
+// ==========================================================================================
+__global__ void __launch_bounds__(WG) k_mark_starts(const uint64_t *__restrict__ offsets,
+                                                    uint64_t n_seqs, uint64_t n_bases,
+                                                    uint32_t *__restrict__ startbits) {
+  uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  if (i >= n_seqs) return;
+  uint64_t o = offsets[i], e = offsets[i + 1];
+  if (e > o && o < n_bases) atomicOr(&startbits[o >> 5], 1u << (o & 31));
+}
+
+// ==========================================================================================
+// K_MARK (part 2): tile list for multi-chunk batches.  Blocks are the runs of reads between
+// global read indices that are multiples of 1000 (io.rs:340-343, 355-361); every tile lies
+// inside one block so it has one chunk lane.  Single workgroup; exclusive scan over blocks.
+// ==========================================================================================
+constexpr int TB_WG = 1024;
+__global__ void __launch_bounds__(TB_WG) k_build_tiles(const uint64_t *__restrict__ offsets,
+                                                       uint64_t n_seqs, uint64_t g0,
+                                                       uint32_t n_chunks, uint64_t n_blocks,
+                                                       TileDesc *__restrict__ tiles,
+                                                       DevStats *__restrict__ stats) {
+  __shared__ uint64_t sc[TB_WG];
+  __shared__ uint64_t running;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  const uint64_t first = (g0 % 1000 == 0) ? 1000 : 1000 - g0 % 1000;
+  for (uint64_t jb = 0; jb < n_blocks; jb += TB_WG) {
+    uint64_t j = jb + threadIdx.x;
+    uint64_t nt = 0, b0 = 0, b1 = 0;
+    uint32_t lane = 0;
+    if (j < n_blocks) {
+      uint64_t r0 = j == 0 ? 0 : first + (j - 1) * 1000;
+      uint64_t r1 = first + j * 1000;
+      if (r1 > n_seqs) r1 = n_seqs;
+      b0 = offsets[r0];
+      b1 = offsets[r1];
+      nt = (b1 - b0 + TILE_T - 1) / TILE_T;
+      lane = (uint32_t)(((g0 + r0) / 1000) % n_chunks);
+    }
+    sc[threadIdx.x] = nt;
+    __syncthreads();
+    for (int d = 1; d < TB_WG; d <<= 1) {  // inclusive Hillis–Steele scan
+      uint64_t v = threadIdx.x >= (unsigned)d ? sc[threadIdx.x - d] : 0;
+      __syncthreads();
+      sc[threadIdx.x] += v;
+      __syncthreads();
+    }
+    uint64_t excl = running + sc[threadIdx.x] - nt;
+    for (uint64_t t = 0; t < nt; ++t) {
+      TileDesc d;
+      d.begin = b0 + t * TILE_T;
+      d.end = d.begin + TILE_T < b1 ? d.begin + TILE_T : b1;
+      d.lane = lane;
+      d.pad = 0;
+      tiles[excl + t] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x == TB_WG - 1) running += sc[TB_WG - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) stats->n_tiles = running;
+}
+
+// ==========================================================================================
+// K_SCAN: validate bytes (encoding.rs:353-356) and count non-N bases per chunk lane
+// (encoding.rs:374-376 via chunk.rs:28).  Runs before any counting kernel, so an invalid
+// byte aborts the batch with the table untouched.
+// ==========================================================================================
+__device__ __forceinline__ bool byte_is_acgtn(uint32_t c) {
+  // A=0x41 C=0x43 G=0x47 N=0x4E T=0x54 → bits 1,3,7,14,20 of the 0x40..0x5F word
+  return (c >> 5) == 2 && ((0x0010408Au >> (c & 31)) & 1u);
+}
+
+__global__ void __launch_bounds__(WG) k_scan(BatchRef b, DevStats *__restrict__ stats,
+                                             unsigned long long *__restrict__ lane_bases) {
+  __shared__ uint32_t red[WG / 64];
+  for (uint64_t t = blockIdx.x;; t += gridDim.x) {
+    uint64_t t0, t1;
+    uint32_t lane;
+    if (!tile_get(b, t, t0, t1, lane)) break;
+    uint32_t n_valid = 0;
+    for (uint64_t p = t0 + (uint64_t)threadIdx.x * 16; p < t1; p += (uint64_t)WG * 16) {
+      uint8_t buf[16];
+      int n = (int)(t1 - p < 16 ? t1 - p : 16);
+      if (n == 16) {
+        __builtin_memcpy(buf, b.bases + p, 16);
+      } else {
+        for (int r = 0; r < n; ++r) buf[r] = b.bases[p + r];
+      }
+      for (int r = 0; r < n; ++r) {
+        uint32_t c = buf[r];
+        if (!byte_is_acgtn(c)) {
+          atomicMin(&stats->bad, ((unsigned long long)(p + r) << 8) | c);
+        }
+        n_valid += (c != 'N');
+      }
+    }
+    // wave reduce, then one atomic per workgroup
+    for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n_valid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t s = 0;
+      for (int w = 0; w < WG / 64; ++w) s += red[w];
+      if (s) atomicAdd(&lane_bases[lane], (unsigned long long)s);
+    }
+    __syncthreads();
+  }
+}
+
+// ==========================================================================================
+// K_DIRECT: extract + insert with global device-scope atomics.  General path: any table
+// size, any batch size; also the re-insert path for spilled k-mers.
+// counting.rs:82-85: entry(kmer).or_insert(0); *c = c.saturating_add(1).
+// Saturation stays exact with a returning add: an add that observes old == u32::MAX has
+// wrapped the slot and repairs it with atomicMax(MAX); every wrap is followed by its own
+// repair, so the last operation on a saturated slot always leaves MAX.
+// ==========================================================================================
+__device__ __forceinline__ void count_one(const TableRef &tb, uint64_t key, uint32_t lane,
+                                          DevStats *stats, const SpillRef &sp,
+                                          uint32_t &n_new) {
+  uint64_t h = hash64(key);
+  uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
+  bool inserted = false;
+  int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
+  if (s < 0) {
+    unsigned long long i = atomicAdd(&stats->spill_count, 1ull);
+    if (i < sp.cap) {
+      sp.keys[i] = key;
+      sp.lanes[i] = lane;
+      sp.counts[i] = 1u;
+    }
+    return;
+  }
+  n_new += inserted;
+  uint32_t *v = tb.vals + (uint64_t)lane * tb.cap + (uint64_t)s;
+  uint32_t old = atomicAdd(v, 1u);
+  if (old == 0xFFFFFFFFu) atomicMax(v, 0xFFFFFFFFu);
+}
+
+__global__ void __launch_bounds__(WG) k_direct(BatchRef b, TableRef tb, DevStats *__restrict__ stats,
+                                               SpillRef sp) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[TILE_LDS];
+  uint32_t n_new = 0;
+  if (stats->bad != ~0ull) return;  // k_scan found an invalid byte: leave the table untouched
+  for (uint64_t t = blockIdx.x;; t += gridDim.x) {
+    uint64_t t0, t1;
+    uint32_t lane;
+    if (!tile_get(b, t, t0, t1, lane)) break;
+    __syncthreads();
+    stage_tile(b, t0, lds);
+    __syncthreads();
+    walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) { count_one(tb, kmer, lane, stats, sp, n_new); });
+  }
+  for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
+  if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&stats->n_distinct, (unsigned long long)n_new);
+}
+
+// ==========================================================================================
+// K_INSERT: (kmer, lane, count) records — KmerCounts::insert (counting.rs:152-154) and the
+// re-insert of spilled k-mers after a grow.  lanes == nullptr ⇒ all records use lane0;
+// counts == nullptr ⇒ count 1.
+// ==========================================================================================
+__global__ void __launch_bounds__(WG) k_insert(const uint64_t *__restrict__ kmers,
+                                               const uint32_t *__restrict__ lanes,
+                                               const uint32_t *__restrict__ counts, uint64_t n,
+                                               uint32_t lane0, TableRef tb,
+                                               DevStats *__restrict__ stats, SpillRef sp) {
+  uint32_t n_new = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
+    uint64_t key = kmers[i];
+    uint32_t lane = lanes ? lanes[i] : lane0;
+    uint32_t cnt = counts ? counts[i] : 1u;
+    uint64_t h = hash64(key);
+    uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
+    bool inserted = false;
+    int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
+    if (s < 0) {
+      unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
+      if (j < sp.cap) {
+        sp.keys[j] = key;
+        sp.lanes[j] = lane;
+        sp.counts[j] = cnt;
+      }
+      continue;
+    }
+    n_new += inserted;
+    sat_add_cas(tb.vals + (uint64_t)lane * tb.cap + (uint64_t)s, cnt);
+  }
+  for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
+  if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&stats->n_distinct, (unsigned long long)n_new);
+}
+
+// ==========================================================================================
+// K_GROW: rehash every occupied slot of the old table into a table with more pages.  A
+// page's entries land in its 2^d child pages, each of which has room for all of them.
+// ==========================================================================================
+__global__ void __launch_bounds__(WG) k_grow(TableRef oldt, TableRef newt) {
+  for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < oldt.cap;
+       i += (uint64_t)gridDim.x * WG) {
+    uint64_t key = oldt.keys[i];
+    if (key == EMPTY) continue;
+    uint64_t h = hash64(key);
+    uint64_t base = page_of(h, newt.log_pages) << PAGE_LOG;
+    bool inserted = false;
+    int64_t s = find_or_insert(newt.keys, base, slot_of(h, newt.log_pages), key, inserted);
+    // s >= 0 by construction (child pages cannot overflow)
+    for (uint32_t l = 0; l < oldt.n_lanes; ++l)
+      newt.vals[(uint64_t)l * newt.cap + (uint64_t)s] = oldt.vals[(uint64_t)l * oldt.cap + i];
+  }
+}
+
+// ==========================================================================================
+// K_HISTO: one pass over pages [page0,page1) → every histogram column + totals.
+// Column j of the reference is the histogram of the table after merging chunks 0..j with
+// saturating adds (counting.rs:171-202; histogram.rs:51-85) — sequential saturating adds of
+// non-negative lane counts equal the clamped prefix sum, so column j is the histogram of
+// min(Σ_{c≤j} lane_c, u32::MAX); counts > histo_max fold into bin histo_max+1
+// (histogram.rs:125-134); zero prefix sums (k-mer not seen yet) are not counted.
+// Low bins are privatised in LDS (u32), the rest go straight to global u64 atomics.
+// ==========================================================================================
+struct HistoTotals {
+  unsigned long long n_unique;       // occupied slots
+  unsigned long long n_hashed;       // Σ merged (clamped) counts
+  unsigned long long n_lane_sum;     // Σ over lanes of Σ counts  (= n_kmers_ingested)
+  unsigned long long any_saturated;
+};
+
+__global__ void __launch_bounds__(WG) k_histo(TableRef tb, uint64_t slot0, uint64_t slot1,
+                                              uint64_t histo_max, uint32_t n_cols,
+                                              uint32_t lds_bins,
+                                              unsigned long long *__restrict__ hist,
+                                              HistoTotals *__restrict__ tot) {
+  extern __shared__ uint32_t lh[];  // n_cols * lds_bins
+  const uint32_t n_l = n_cols * lds_bins;
+  for (uint32_t i = threadIdx.x; i < n_l; i += WG) lh[i] = 0;
+  __syncthreads();
+  const uint64_t hlen = histo_max + 2;
+  unsigned long long n_unique = 0, n_hashed = 0, n_lane = 0, sat = 0;
+  for (uint64_t s = slot0 + (uint64_t)blockIdx.x * WG + threadIdx.x; s < slot1;
+       s += (uint64_t)gridDim.x * WG) {
+    if (tb.keys[s] == EMPTY) continue;
+    n_unique++;
+    uint32_t cum = 0;
+    for (uint32_t l = 0; l < tb.n_lanes; ++l) {
+      uint32_t v = tb.vals[(uint64_t)l * tb.cap + s];
+      n_lane += v;
+      cum = sat_add_u32(cum, v);
+      if (l < n_cols && cum > 0) {
+        uint64_t bin = cum <= histo_max ? cum : histo_max + 1;
+        if (bin < lds_bins)
+          atomicAdd(&lh[l * lds_bins + (uint32_t)bin], 1u);
+        else
+          atomicAdd(&hist[(uint64_t)l * hlen + bin], 1ull);
+      }
+    }
+    n_hashed += cum;
+    sat |= (cum == 0xFFFFFFFFu);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n_l; i += WG) {
+    uint32_t v = lh[i];
+    if (v) {
+      uint32_t l = i / lds_bins, bin = i % lds_bins;
+      if ((uint64_t)bin < hlen) atomicAdd(&hist[(uint64_t)l * hlen + bin], (unsigned long long)v);
+    }
+  }
+  // totals: wave reduce then atomics
+  for (int off = 32; off > 0; off >>= 1) {
+    n_unique += __shfl_down(n_unique, off, 64);
+    n_hashed += __shfl_down(n_hashed, off, 64);
+    n_lane += __shfl_down(n_lane, off, 64);
+    sat |= __shfl_down(sat, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (n_unique) atomicAdd(&tot->n_unique, n_unique);
+    if (n_hashed) atomicAdd(&tot->n_hashed, n_hashed);
+    if (n_lane) atomicAdd(&tot->n_lane_sum, n_lane);
+    if (sat) atomicOr(&tot->any_saturated, 1ull);
+  }
+}
+
+// ==========================================================================================
+// K_LOOKUP / K_EXPORT: merged-table read API (counting.rs:205-241).
+// ==========================================================================================
+__device__ __forceinline__ uint64_t revcomp(uint64_t kmer, int k) {
+  // complement = bitwise NOT of each 2-bit code; reverse 2-bit groups of the 64-bit word
+  uint64_t x = ~kmer;
+  x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+  x = __builtin_bswap64(x);
+  return x >> (64 - 2 * k);
+}
+
+__device__ __forceinline__ uint32_t merged_count(const TableRef &tb, uint64_t key) {
+  uint64_t h = hash64(key);
+  uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
+  int64_t s = find_slot(tb.keys, base, slot_of(h, tb.log_pages), key);
+  if (s < 0) return 0;
+  uint32_t cum = 0;
+  for (uint32_t l = 0; l < tb.n_lanes; ++l) cum = sat_add_u32(cum, tb.vals[(uint64_t)l * tb.cap + s]);
+  return cum;
+}
+
+__global__ void __launch_bounds__(WG) k_lookup(TableRef tb, const uint64_t *__restrict__ kmers,
+                                               uint32_t *__restrict__ out, uint64_t n, int canonical,
+                                               int k) {
+  uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key = kmers[i];
+  if (canonical) {
+    uint64_t rc = revcomp(key, k);
+    key = key < rc ? key : rc;
+  }
+  out[i] = merged_count(tb, key);
+}
+
+__global__ void __launch_bounds__(WG) k_export(TableRef tb, uint64_t slot0, uint64_t slot1,
+                                               uint64_t *__restrict__ kmers,
+                                               uint32_t *__restrict__ counts, uint64_t cap,
+                                               unsigned long long *__restrict__ n_out) {
+  for (uint64_t s = slot0 + (uint64_t)blockIdx.x * WG + threadIdx.x; s < slot1;
+       s += (uint64_t)gridDim.x * WG) {
+    uint64_t key = tb.keys[s];
+    if (key == EMPTY) continue;
+    uint32_t cum = 0;
+    for (uint32_t l = 0; l < tb.n_lanes; ++l) cum = sat_add_u32(cum, tb.vals[(uint64_t)l * tb.cap + s]);
+    unsigned long long i = atomicAdd(n_out, 1ull);
+    if (i < cap) {
+      kmers[i] = key;
+      counts[i] = cum;
+    }
+  }
+}
+
+// ==========================================================================================
+// K_MERGE: KmerCounts::extend across devices (counting.rs:157-166): fold a peer's page range
+// (same geometry) into this table, lane by lane, saturating.
+// ==========================================================================================
+__global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t slot0, uint64_t n_slots,
+                                              const uint64_t *__restrict__ pkeys,
+                                              const uint32_t *__restrict__ pvals,
+                                              DevStats *__restrict__ stats, SpillRef sp) {
+  uint32_t n_new = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n_slots;
+       i += (uint64_t)gridDim.x * WG) {
+    uint64_t key = pkeys[i];
+    if (key == EMPTY) continue;
+    uint64_t h = hash64(key);
+    uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
+    bool inserted = false;
+    int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
+    if (s < 0) {
+      // page full: one spill record per non-zero lane
+      for (uint32_t l = 0; l < tb.n_lanes; ++l) {
+        uint32_t v = pvals[(uint64_t)l * n_slots + i];
+        if (!v) continue;
+        unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
+        if (j < sp.cap) {
+          sp.keys[j] = key;
+          sp.lanes[j] = l;
+          sp.counts[j] = v;
+        }
+      }
+      continue;
+    }
+    n_new += inserted;
+    for (uint32_t l = 0; l < tb.n_lanes; ++l) {
+      uint32_t v = pvals[(uint64_t)l * n_slots + i];
+      if (v) sat_add_cas(tb.vals + (uint64_t)l * tb.cap + (uint64_t)s, v);
+    }
+  }
+  (void)slot0;
+  for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
+  if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&stats->n_distinct, (unsigned long long)n_new);
+}
+
+// ==========================================================================================
+// K_SYNTH: synthetic reads: implicit uniform genome, fixed-length reads,
+// random strand, optional substitutions and N.  Must match sharkmer_amd/synth.py bit for bit.
+// ==========================================================================================
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct SynthSpec {
+  uint64_t seed_genome, seed_reads, genome_len;
+  uint32_t read_len, sub_per_64k, n_per_64k, pad;
+};
+
+__global__ void __launch_bounds__(WG) k_synth(SynthSpec sp, uint64_t first_read, uint64_t n_reads,
+                                              uint8_t *__restrict__ bases,
+                                              uint64_t *__restrict__ offsets) {
+  // one thread per 8 bases: 8-byte stores, coalesced
+  const uint64_t L = sp.read_len;
+  const uint64_t total = n_reads * L;
+  uint64_t g = ((uint64_t)blockIdx.x * WG + threadIdx.x) * 8;
+  if (g <= n_reads && g + 8 > 0) {
+    for (int r = 0; r < 8; ++r)
+      if (g + r <= n_reads) offsets[g + r] = (g + r) * L;
+  }
+  if (g >= total) return;
+  uint8_t out[8];
+  const char LUT[4] = {'A', 'C', 'G', 'T'};
+  for (int r = 0; r < 8; ++r) {
+    uint64_t p = g + r;
+    if (p >= total) { out[r] = 0; continue; }
+    uint64_t i = first_read + p / L, j = p % L;
+    uint64_t h1 = splitmix64(sp.seed_reads + 2 * i);
+    uint64_t h2 = splitmix64(sp.seed_reads + 2 * i + 1);
+    uint64_t start = h1 % (sp.genome_len - L + 1);
+    bool rc = (h2 >> 63) != 0;
+    uint64_t gp = rc ? start + (L - 1 - j) : start + j;
+    uint32_t b = (uint32_t)(splitmix64(sp.seed_genome + gp) & 3);
+    if (rc) b = 3 - b;
+    uint8_t ch = (uint8_t)LUT[b];
+    if (sp.sub_per_64k | sp.n_per_64k) {
+      uint64_t e = splitmix64((sp.seed_reads ^ 0xE44044ull) + i * L + j);
+      uint32_t u = (uint32_t)(e & 0xFFFF);
+      if (u < sp.n_per_64k) {
+        ch = 'N';
+      } else if (u < sp.n_per_64k + sp.sub_per_64k) {
+        uint32_t d = 1 + (uint32_t)((e >> 16) % 3);
+        ch = (uint8_t)LUT[(b + d) & 3];
+      }
+    }
+    out[r] = ch;
+  }
+  if (g + 8 <= total) {
+    __builtin_memcpy(bases + g, out, 8);
+  } else {
+    for (int r = 0; r < 8 && g + r < total; ++r) bases[g + r] = out[r];
+  }
+}
+
+}  // namespace shk

@@ -1,0 +1,828 @@
+// shk_engine.hip — host side of libshk: the C ABI of include/shk.h over the gfx950
+// kernels in shk_device.hip.h.  One context = one GPU = one HIP stream.
+//
+// Reference call sites this replaces (paths under /root/reference):
+//   src/io.rs:355-361   drain_batch → Chunk::ingest_seq        → shk_ingest_batch/_reads
+//   src/io.rs:1021-1028 extend_with_histogram + get_vector      → shk_finalize/_histograms
+//   src/io.rs:545-552   per-chunk totals                        → shk_get_counters
+// There is no CPU fallback anywhere in this file.
+#include "../../include/shk.h"
+#include "shk_device.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace shk;
+
+struct shk_ctx;
+static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub);
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {  // grow-only device scratch
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct TimedEvent {
+  int kid;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct shk_ctx {
+  shk_config cfg{};
+  uint32_t n_lanes = 1;
+  hipStream_t stream = nullptr;
+  // table
+  TableRef tb{};
+  // device state
+  DevStats *d_stats = nullptr;
+  DevStats *h_stats = nullptr;  // pinned mirror
+  unsigned long long *d_lane_bases = nullptr;
+  unsigned long long *d_hist = nullptr;
+  HistoTotals *d_tot = nullptr;
+  HistoTotals h_tot{};
+  std::vector<uint64_t> h_hist;
+  // scratch
+  DevBuf in_bases, in_offsets, startbits, tiles, spillA, spillB, misc, part;
+  // host counters
+  std::vector<uint64_t> lane_reads;
+  uint64_t n_reads_read = 0, n_bases_read = 0;
+  uint64_t n_grows = 0, n_spilled = 0;
+  uint64_t own_p0 = 0, own_p1 = 0;  // owned page range for finalize (0,0 = all)
+  bool own_set = false;
+  bool finalized = false, poisoned = false;
+  int poison_code = 0;
+  std::string err;
+  // timing
+  std::vector<TimedEvent> events;
+  std::vector<hipEvent_t> event_pool;
+  shk_timings timings{};
+};
+
+namespace {
+
+int fail(shk_ctx *c, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define HIPC(c, expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return fail(c, e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP,              \
+                  "HIP error %s at %s:%d (%s)", hipGetErrorString(e__), __FILE__, __LINE__, \
+                  #expr);                                                                   \
+  } while (0)
+
+struct ScopedTimer {
+  shk_ctx *c;
+  int kid;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(shk_ctx *c_, int kid_) : c(c_), kid(kid_) {
+    if (!(c->cfg.flags & SHK_FLAG_TIMING)) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!c->event_pool.empty()) {
+        e = c->event_pool.back();
+        c->event_pool.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, c->stream);
+  }
+  ~ScopedTimer() {
+    if (!a) return;
+    (void)hipEventRecord(b, c->stream);
+    c->events.push_back({kid, a, b});
+  }
+};
+
+void resolve_timings(shk_ctx *c) {
+  for (auto &ev : c->events) {
+    (void)hipEventSynchronize(ev.b);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+      c->timings.ms[ev.kid] += ms;
+      c->timings.launches[ev.kid] += 1;
+    }
+    c->event_pool.push_back(ev.a);
+    c->event_pool.push_back(ev.b);
+  }
+  c->events.clear();
+}
+
+inline uint32_t grid_for(uint64_t n_items, uint32_t per_block, uint32_t cap_blocks) {
+  uint64_t g = (n_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap_blocks) g = cap_blocks;
+  return (uint32_t)g;
+}
+
+int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out) {
+  TableRef t{};
+  t.log_pages = log_pages;
+  t.n_lanes = c->n_lanes;
+  t.cap = (uint64_t)PAGE_SLOTS << log_pages;
+  HIPC(c, hipMalloc((void **)&t.keys, t.cap * sizeof(uint64_t)));
+  hipError_t e = hipMalloc((void **)&t.vals, t.cap * sizeof(uint32_t) * t.n_lanes);
+  if (e != hipSuccess) {
+    (void)hipFree(t.keys);
+    return fail(c, SHK_ERR_NOMEM, "out of device memory allocating %llu-slot table (%u lanes)",
+                (unsigned long long)t.cap, t.n_lanes);
+  }
+  HIPC(c, hipMemsetAsync(t.keys, 0xFF, t.cap * sizeof(uint64_t), c->stream));
+  HIPC(c, hipMemsetAsync(t.vals, 0, t.cap * sizeof(uint32_t) * t.n_lanes, c->stream));
+  *out = t;
+  return SHK_OK;
+}
+
+int read_stats(shk_ctx *c) {
+  HIPC(c, hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats), hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return SHK_OK;
+}
+
+int grow_to(shk_ctx *c, uint32_t new_log_pages) {
+  if (new_log_pages <= c->tb.log_pages) return SHK_OK;
+  TableRef nt{};
+  int rc = alloc_table(c, new_log_pages, &nt);
+  if (rc != SHK_OK) return rc;
+  {
+    ScopedTimer t(c, SHK_K_GROW);
+    hipLaunchKernelGGL(k_grow, dim3(grid_for(c->tb.cap, WG, 8192)), dim3(WG), 0, c->stream, c->tb, nt);
+  }
+  HIPC(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(c->tb.keys);
+  (void)hipFree(c->tb.vals);
+  c->tb = nt;
+  c->n_grows++;
+  return SHK_OK;
+}
+
+uint32_t log_pages_for(uint64_t want_slots) {
+  uint32_t lp = 0;
+  while (((uint64_t)PAGE_SLOTS << lp) < want_slots && lp < 40) lp++;
+  return lp;
+}
+
+// Make room so that `expect_new` further distinct k-mers keep the load ≤ 1/2.
+int ensure_capacity(shk_ctx *c, uint64_t expect_new) {
+  uint64_t need = (c->h_stats->n_distinct + expect_new) * 2;
+  if (need <= c->tb.cap) return SHK_OK;
+  return grow_to(c, log_pages_for(need));
+}
+
+SpillRef spill_ref(DevBuf &b, uint64_t cap) {
+  SpillRef s{};
+  uint8_t *p = (uint8_t *)b.p;
+  s.keys = (uint64_t *)p;
+  s.lanes = (uint32_t *)(p + cap * 8);
+  s.counts = (uint32_t *)(p + cap * 12);
+  s.cap = cap;
+  return s;
+}
+
+// After a counting launch: re-insert spilled records into a grown table until none remain.
+int drain_spill(shk_ctx *c, uint64_t spill_cap) {
+  DevBuf *cur = &c->spillA, *nxt = &c->spillB;
+  while (c->h_stats->spill_count > 0) {
+    uint64_t n = c->h_stats->spill_count;
+    if (n > spill_cap)
+      return fail(c, SHK_ERR_INVARIANT, "spill list overflow (%llu > %llu)", (unsigned long long)n,
+                  (unsigned long long)spill_cap);
+    c->n_spilled += n;
+    // grow at least ×2, and enough for every spilled record to be a new key at load ≤ 1/2
+    uint32_t lp = std::max(c->tb.log_pages + 1, log_pages_for((c->h_stats->n_distinct + n) * 2));
+    int rc = grow_to(c, lp);
+    if (rc != SHK_OK) return rc;
+    HIPC(c, nxt->ensure(n * 16));
+    SpillRef in = spill_ref(*cur, spill_cap), out = spill_ref(*nxt, n);
+    HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+    {
+      ScopedTimer t(c, SHK_K_INSERT);
+      hipLaunchKernelGGL(k_insert, dim3(grid_for(n, WG, 4096)), dim3(WG), 0, c->stream, in.keys,
+                         in.lanes, in.counts, n, 0u, c->tb, c->d_stats, out);
+    }
+    rc = read_stats(c);
+    if (rc != SHK_OK) return rc;
+    std::swap(cur, nxt);
+    spill_cap = n;
+  }
+  if (cur != &c->spillA) std::swap(c->spillA, c->spillB);
+  return SHK_OK;
+}
+
+constexpr uint64_t MAX_SUB_BASES = 1ull << 28;  // bases per counting launch (bounds scratch)
+
+// Core ingest over device-resident input.  lane_fixed >= 0: every read to that chunk lane
+// (drain_batch, io.rs:356-358); lane_fixed < 0: stripe by running read index
+// (read i → chunk (i/1000) % n_chunks, io.rs:340-343,355-361).
+int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_seqs,
+                uint64_t n_bases, int64_t lane_fixed) {
+  if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  c->finalized = false;
+  const uint64_t g0 = c->n_reads_read;
+  const uint32_t NL = c->n_lanes;
+  // host-side bookkeeping that depends only on read indices
+  uint64_t n_blocks = 1;
+  const uint64_t first = (g0 % 1000 == 0) ? 1000 : 1000 - g0 % 1000;
+  const bool striped = lane_fixed < 0 && NL > 1;
+  if (striped) {
+    n_blocks = n_seqs <= first ? 1 : 1 + (n_seqs - first + 999) / 1000;
+    for (uint64_t j = 0; j < n_blocks; ++j) {
+      uint64_t r0 = j == 0 ? 0 : first + (j - 1) * 1000;
+      uint64_t r1 = std::min(first + j * 1000, n_seqs);
+      c->lane_reads[((g0 + r0) / 1000) % NL] += r1 - r0;
+    }
+  } else {
+    c->lane_reads[lane_fixed < 0 ? 0 : (uint32_t)lane_fixed] += n_seqs;
+  }
+  if (lane_fixed < 0) c->n_reads_read += n_seqs;  // explicit-lane batches do not advance striping
+  c->n_bases_read += n_bases;
+  if (n_seqs == 0 || n_bases == 0) return SHK_OK;
+
+  // 1. read-start bitmap (+ tile list when the batch spans several chunk lanes)
+  const size_t sb_words = (size_t)(n_bases / 32 + 3);
+  HIPC(c, c->startbits.ensure(sb_words * 4));
+  HIPC(c, hipMemsetAsync(c->startbits.p, 0, sb_words * 4, c->stream));
+  uint64_t n_tiles_ub = (n_bases + TILE_T - 1) / TILE_T;
+  const bool multi = striped && n_blocks > 1;
+  if (multi) {
+    n_tiles_ub += n_blocks;
+    HIPC(c, c->tiles.ensure(n_tiles_ub * sizeof(TileDesc)));
+  }
+  {
+    ScopedTimer t(c, SHK_K_MARK);
+    hipLaunchKernelGGL(k_mark_starts, dim3((uint32_t)((n_seqs + WG - 1) / WG)), dim3(WG), 0,
+                       c->stream, d_offsets, n_seqs, n_bases, (uint32_t *)c->startbits.p);
+    if (multi)
+      hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(TB_WG), 0, c->stream, d_offsets, n_seqs, g0,
+                         NL, n_blocks, (TileDesc *)c->tiles.p, c->d_stats);
+  }
+  BatchRef b{};
+  b.bases = d_bases;
+  b.startbits = (const uint32_t *)c->startbits.p;
+  b.n_bases = n_bases;
+  b.tiles = multi ? (const TileDesc *)c->tiles.p : nullptr;
+  b.stats = c->d_stats;
+  b.n_tiles_single = (n_bases + TILE_T - 1) / TILE_T;
+  b.tile_first = 0;
+  b.tile_count = n_tiles_ub;
+  b.lane0 = lane_fixed >= 0 ? (uint32_t)lane_fixed : (striped ? (uint32_t)((g0 / 1000) % NL) : 0u);
+  b.k = (int)c->cfg.k;
+
+  // 2. validate + count bases (encoding.rs:353-356, 374-376)
+  {
+    ScopedTimer t(c, SHK_K_SCAN);
+    hipLaunchKernelGGL(k_scan, dim3(grid_for(n_tiles_ub, 1, 4096)), dim3(WG), 0, c->stream, b,
+                       c->d_stats, c->d_lane_bases);
+  }
+
+  // 3. count, in sub-ranges of tiles
+  const uint64_t tiles_per_sub = MAX_SUB_BASES / TILE_T;
+  for (uint64_t ta = 0; ta < n_tiles_ub; ta += tiles_per_sub) {
+    uint64_t tn = std::min(tiles_per_sub, n_tiles_ub - ta);
+    uint64_t sub_kmers_ub = tn * TILE_T;
+    b.tile_first = ta;
+    b.tile_count = tn;
+    // capacity heuristic when no hint was given: assume ≥ 4× coverage; the spill path keeps
+    // the result exact whatever the truth is
+    int rc = ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : sub_kmers_ub / 4);
+    if (rc != SHK_OK) return rc;
+    rc = count_tiles(c, b, sub_kmers_ub);
+    if (rc != SHK_OK) return rc;
+  }
+  return SHK_OK;
+}
+
+}  // namespace
+
+// count_tiles: one counting pass over b's tile range; picks the paged (LDS) or the direct
+// (global atomics) path, then repairs spills and keeps the load ≤ 1/2.
+static bool paged_available() { return false; }
+static int paged_count(shk_ctx *, const BatchRef &, uint64_t, SpillRef) { return SHK_ERR_STATE; }
+
+static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub) {
+  HIPC(c, c->spillA.ensure(sub_kmers_ub * 16));
+  SpillRef sp = spill_ref(c->spillA, sub_kmers_ub);
+  HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  bool use_paged = paged_available() && !(c->cfg.flags & SHK_FLAG_FORCE_DIRECT);
+  if (use_paged) {
+    int rc = paged_count(c, b, sub_kmers_ub, sp);
+    if (rc != SHK_OK) return rc;
+  } else {
+    ScopedTimer t(c, SHK_K_DIRECT);
+    hipLaunchKernelGGL(k_direct, dim3(grid_for(b.tile_count, 1, 256 * 8)), dim3(WG), 0, c->stream, b,
+                       c->tb, c->d_stats, sp);
+  }
+  int rc = read_stats(c);
+  if (rc != SHK_OK) return rc;
+  if (c->h_stats->bad != ~0ull) {
+    // identical text to encoding.rs:353-356
+    c->poisoned = true;
+    c->poison_code = SHK_ERR_INVALID_CHAR;
+    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%c' in sequence. Only ACGTN allowed.",
+                (char)(c->h_stats->bad & 0xFF));
+  }
+  rc = drain_spill(c, sub_kmers_ub);
+  if (rc != SHK_OK) return rc;
+  // keep the load factor ≤ 1/2 for the next launch
+  if (c->h_stats->n_distinct * 2 > c->tb.cap) {
+    rc = grow_to(c, log_pages_for(c->h_stats->n_distinct * 4));
+    if (rc != SHK_OK) return rc;
+  }
+  return SHK_OK;
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int shk_abi_version(void) { return SHK_ABI_VERSION; }
+
+const char *shk_last_error(const shk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int shk_create(const shk_config *cfg, shk_ctx **out) {
+  if (!cfg || !out) return fail(nullptr, SHK_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  // cli.rs:662-673 (the "k odd" rule is the CLI's, cli.rs:667)
+  if (!(cfg->k < 32))
+    return fail(nullptr, SHK_ERR_BAD_ARG,
+                "k must be less than 32 due to use of 64 bit integers to encode kmers");
+  if (!(cfg->k > 0)) return fail(nullptr, SHK_ERR_BAD_ARG, "k must be greater than 0");
+  if (!(cfg->histo_max > 0)) return fail(nullptr, SHK_ERR_BAD_ARG, "histo_max must be greater than 0");
+  if (!(cfg->histo_max <= 1000000))
+    return fail(nullptr, SHK_ERR_BAD_ARG, "histo_max must not exceed 1000000, got %llu",
+                (unsigned long long)cfg->histo_max);
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(nullptr, SHK_ERR_NO_DEVICE, "no HIP device available (libshk has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= n_dev)
+    return fail(nullptr, SHK_ERR_NO_DEVICE, "device %d out of range (have %d)", cfg->device, n_dev);
+  if (hipSetDevice(cfg->device) != hipSuccess)
+    return fail(nullptr, SHK_ERR_NO_DEVICE, "hipSetDevice(%d) failed", cfg->device);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+    return fail(nullptr, SHK_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, SHK_ERR_NO_DEVICE, "device %d is %s; libshk is built for gfx950 only",
+                cfg->device, prop.gcnArchName);
+
+  shk_ctx *c = new shk_ctx();
+  c->cfg = *cfg;
+  c->n_lanes = cfg->chunks == 0 ? 1 : cfg->chunks;  // io.rs:378
+  c->lane_reads.assign(c->n_lanes, 0);
+  auto bail = [&](int code) {
+    g_create_error = c->err;
+    shk_destroy(c);
+    return code;
+  };
+#define HIPB(expr)                                                                           \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      fail(c, SHK_ERR_HIP, "HIP error %s in %s", hipGetErrorString(e__), #expr);             \
+      return bail(e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP);                 \
+    }                                                                                        \
+  } while (0)
+  HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPB(hipMalloc((void **)&c->d_stats, sizeof(DevStats)));
+  HIPB(hipHostMalloc((void **)&c->h_stats, sizeof(DevStats), hipHostMallocDefault));
+  memset(c->h_stats, 0, sizeof(DevStats));
+  c->h_stats->bad = ~0ull;
+  HIPB(hipMemcpyAsync(c->d_stats, c->h_stats, sizeof(DevStats), hipMemcpyHostToDevice, c->stream));
+  HIPB(hipMalloc((void **)&c->d_lane_bases, sizeof(unsigned long long) * c->n_lanes));
+  HIPB(hipMemsetAsync(c->d_lane_bases, 0, sizeof(unsigned long long) * c->n_lanes, c->stream));
+  const size_t hist_n = (size_t)std::max<uint32_t>(cfg->chunks, 1) * (cfg->histo_max + 2);
+  HIPB(hipMalloc((void **)&c->d_hist, hist_n * sizeof(unsigned long long)));
+  HIPB(hipMalloc((void **)&c->d_tot, sizeof(HistoTotals)));
+  c->h_hist.assign(hist_n, 0);
+  uint64_t want = cfg->table_capacity_hint ? cfg->table_capacity_hint * 2 : (1ull << 20);
+  int rc = alloc_table(c, log_pages_for(want), &c->tb);
+  if (rc != SHK_OK) return bail(rc);
+  HIPB(hipStreamSynchronize(c->stream));
+#undef HIPB
+  *out = c;
+  return SHK_OK;
+}
+
+void shk_destroy(shk_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  resolve_timings(c);
+  for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->tb.keys) (void)hipFree(c->tb.keys);
+  if (c->tb.vals) (void)hipFree(c->tb.vals);
+  if (c->d_stats) (void)hipFree(c->d_stats);
+  if (c->h_stats) (void)hipHostFree(c->h_stats);
+  if (c->d_lane_bases) (void)hipFree(c->d_lane_bases);
+  if (c->d_hist) (void)hipFree(c->d_hist);
+  if (c->d_tot) (void)hipFree(c->d_tot);
+  c->in_bases.release();
+  c->in_offsets.release();
+  c->startbits.release();
+  c->tiles.release();
+  c->spillA.release();
+  c->spillB.release();
+  c->misc.release();
+  c->part.release();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int shk_reset(shk_ctx *c) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  HIPC(c, hipMemsetAsync(c->tb.keys, 0xFF, c->tb.cap * sizeof(uint64_t), c->stream));
+  HIPC(c, hipMemsetAsync(c->tb.vals, 0, c->tb.cap * sizeof(uint32_t) * c->n_lanes, c->stream));
+  memset(c->h_stats, 0, sizeof(DevStats));
+  c->h_stats->bad = ~0ull;
+  HIPC(c, hipMemcpyAsync(c->d_stats, c->h_stats, sizeof(DevStats), hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemsetAsync(c->d_lane_bases, 0, sizeof(unsigned long long) * c->n_lanes, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  std::fill(c->lane_reads.begin(), c->lane_reads.end(), 0);
+  c->n_reads_read = c->n_bases_read = 0;
+  c->own_set = false;
+  c->finalized = c->poisoned = false;
+  c->poison_code = 0;
+  c->err.clear();
+  return SHK_OK;
+}
+
+static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
+                       int64_t lane_fixed) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (n_seqs && (!offsets)) return fail(c, SHK_ERR_BAD_ARG, "null offsets");
+  HIPC(c, hipSetDevice(c->cfg.device));
+  if (n_seqs == 0) return ingest_core(c, nullptr, nullptr, 0, 0, lane_fixed);
+  const uint64_t o0 = offsets[0];
+  const uint64_t n_bases = offsets[n_seqs] - o0;
+  if (n_bases && !bases) return fail(c, SHK_ERR_BAD_ARG, "null bases");
+  HIPC(c, c->in_bases.ensure(n_bases + 64));
+  HIPC(c, c->in_offsets.ensure((n_seqs + 1) * 8));
+  const uint64_t *offs = offsets;
+  std::vector<uint64_t> rebased;
+  if (o0 != 0) {  // device code indexes the staged copy from 0
+    rebased.resize(n_seqs + 1);
+    for (uint64_t i = 0; i <= n_seqs; ++i) rebased[i] = offsets[i] - o0;
+    offs = rebased.data();
+  }
+  if (n_bases)
+    HIPC(c, hipMemcpyAsync(c->in_bases.p, bases + o0, n_bases, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(c->in_offsets.p, offs, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));  // `rebased` and caller buffers may go away
+  return ingest_core(c, (const uint8_t *)c->in_bases.p, (const uint64_t *)c->in_offsets.p, n_seqs,
+                     n_bases, lane_fixed);
+}
+
+int shk_ingest_batch(shk_ctx *c, uint32_t chunk_id, const uint8_t *bases, const uint64_t *offsets,
+                     uint64_t n_seqs) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (chunk_id >= c->n_lanes)
+    return fail(c, SHK_ERR_BAD_ARG, "chunk_id %u out of range (n_chunks %u)", chunk_id, c->n_lanes);
+  return ingest_host(c, bases, offsets, n_seqs, (int64_t)chunk_id);
+}
+
+int shk_ingest_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs) {
+  return ingest_host(c, bases, offsets, n_seqs, -1);
+}
+
+int shk_ingest_reads_device(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs,
+                            uint64_t n_bases) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  return ingest_core(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_seqs, n_bases, -1);
+}
+
+int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, const uint32_t *counts,
+                      uint64_t n) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  if (chunk_id >= c->n_lanes) return fail(c, SHK_ERR_BAD_ARG, "chunk_id out of range");
+  if (n == 0) return SHK_OK;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  c->finalized = false;
+  const uint64_t kmax = c->cfg.k >= 32 ? ~0ull : ((1ull << (2 * c->cfg.k)) - 1);
+  for (uint64_t i = 0; i < n; ++i)
+    if (kmers[i] > kmax) return fail(c, SHK_ERR_BAD_ARG, "kmer %llu does not fit k=%u",
+                                     (unsigned long long)kmers[i], c->cfg.k);
+  int rc = ensure_capacity(c, n);
+  if (rc != SHK_OK) return rc;
+  HIPC(c, c->misc.ensure(n * 12));
+  uint64_t *dk = (uint64_t *)c->misc.p;
+  uint32_t *dc = (uint32_t *)((uint8_t *)c->misc.p + n * 8);
+  HIPC(c, hipMemcpyAsync(dk, kmers, n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(dc, counts, n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, c->spillA.ensure(n * 16));
+  SpillRef sp = spill_ref(c->spillA, n);
+  HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  {
+    ScopedTimer t(c, SHK_K_INSERT);
+    hipLaunchKernelGGL(k_insert, dim3(grid_for(n, WG, 4096)), dim3(WG), 0, c->stream, dk,
+                       (const uint32_t *)nullptr, dc, n, chunk_id, c->tb, c->d_stats, sp);
+  }
+  rc = read_stats(c);
+  if (rc != SHK_OK) return rc;
+  return drain_spill(c, n);
+}
+
+int shk_sync(shk_ctx *c) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  return SHK_OK;
+}
+
+int shk_finalize(shk_ctx *c) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  if (c->finalized) return SHK_OK;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  uint64_t n_reads = 0;
+  for (auto v : c->lane_reads) n_reads += v;
+  if (n_reads == 0 && !c->own_set)  // io.rs:578-580
+    return fail(c, SHK_ERR_NO_READS,
+                "No reads were ingested. Check that input files contain valid FASTQ records.");
+  const uint32_t n_cols = c->cfg.chunks;
+  const uint64_t hlen = c->cfg.histo_max + 2;
+  const size_t hist_n = (size_t)std::max<uint32_t>(n_cols, 1) * hlen;
+  HIPC(c, hipMemsetAsync(c->d_hist, 0, hist_n * sizeof(unsigned long long), c->stream));
+  HIPC(c, hipMemsetAsync(c->d_tot, 0, sizeof(HistoTotals), c->stream));
+  uint64_t s0 = 0, s1 = c->tb.cap;
+  if (c->own_set) {
+    s0 = c->own_p0 << PAGE_LOG;
+    s1 = c->own_p1 << PAGE_LOG;
+  }
+  uint32_t lds_bins = n_cols ? std::max<uint32_t>(32, 16384 / n_cols) : 0;
+  if (lds_bins > hlen) lds_bins = (uint32_t)hlen;
+  if (n_cols && (uint64_t)lds_bins * n_cols * 4 > 65536) lds_bins = 65536 / 4 / n_cols;
+  {
+    ScopedTimer t(c, SHK_K_HISTO);
+    hipLaunchKernelGGL(k_histo, dim3(grid_for(s1 - s0, WG * 8, 2048)), dim3(WG),
+                       (size_t)lds_bins * n_cols * 4, c->stream, c->tb, s0, s1, c->cfg.histo_max,
+                       n_cols, lds_bins, c->d_hist, c->d_tot);
+  }
+  HIPC(c, hipMemcpyAsync(c->h_hist.data(), c->d_hist, hist_n * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                         c->stream));
+  HIPC(c, hipMemcpyAsync(&c->h_tot, c->d_tot, sizeof(HistoTotals), hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  if (!c->own_set) {
+    // io.rs:1042-1047 (and :1150-1155 for chunks==0)
+    if (c->h_tot.n_hashed != c->h_tot.n_lane_sum)
+      return fail(c, SHK_ERR_INVARIANT,
+                  "The total count of hashed kmers (%llu) does not equal the number of ingested kmers (%llu)",
+                  (unsigned long long)c->h_tot.n_hashed, (unsigned long long)c->h_tot.n_lane_sum);
+    if (n_cols > 0) {
+      // io.rs:1114-1132: histogram totals of the last column vs the table
+      const uint64_t *last = c->h_hist.data() + (size_t)(n_cols - 1) * hlen;
+      uint64_t nu = 0;
+      for (uint64_t i = 1; i < hlen; ++i) nu += last[i];
+      if (nu != c->h_tot.n_unique)
+        return fail(c, SHK_ERR_INVARIANT,
+                    "The total count of unique kmers in the histogram (%llu) does not equal the total count of hashed kmers (%llu)",
+                    (unsigned long long)nu, (unsigned long long)c->h_tot.n_unique);
+    }
+  }
+  c->finalized = true;
+  return SHK_OK;
+}
+
+int shk_histograms(shk_ctx *c, uint64_t *out) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (!c->finalized) return fail(c, SHK_ERR_STATE, "shk_histograms before shk_finalize");
+  if (c->cfg.chunks == 0) return SHK_OK;
+  if (!out) return fail(c, SHK_ERR_BAD_ARG, "null output");
+  memcpy(out, c->h_hist.data(), (size_t)c->cfg.chunks * (c->cfg.histo_max + 2) * sizeof(uint64_t));
+  return SHK_OK;
+}
+
+int shk_get_counters(shk_ctx *c, shk_counters *o) {
+  if (!c || !o) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  memset(o, 0, sizeof *o);
+  for (auto v : c->lane_reads) o->n_reads_ingested += v;
+  o->n_bases_read = c->n_bases_read;
+  std::vector<unsigned long long> lb(c->n_lanes);
+  HIPC(c, hipMemcpyAsync(lb.data(), c->d_lane_bases, sizeof(unsigned long long) * c->n_lanes,
+                         hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  for (auto v : lb) o->n_bases_ingested += v;
+  if (c->finalized) {
+    o->n_kmers_ingested = c->h_tot.n_lane_sum;
+    o->n_unique_kmers = c->h_tot.n_unique;
+    o->n_hashed_kmers = c->h_tot.n_hashed;
+    o->any_saturated = (uint32_t)c->h_tot.any_saturated;
+    if (c->cfg.chunks > 0)
+      o->n_singleton_kmers = c->h_hist[(size_t)(c->cfg.chunks - 1) * (c->cfg.histo_max + 2) + 1];
+  }
+  o->n_chunks = c->n_lanes;
+  o->table_capacity = c->tb.cap;
+  o->n_grows = c->n_grows;
+  o->n_spilled = c->n_spilled;
+  return SHK_OK;
+}
+
+int shk_get_timings(shk_ctx *c, shk_timings *o) {
+  if (!c || !o) return SHK_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  resolve_timings(c);
+  *o = c->timings;
+  return SHK_OK;
+}
+
+int shk_reset_timings(shk_ctx *c) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  resolve_timings(c);
+  memset(&c->timings, 0, sizeof c->timings);
+  return SHK_OK;
+}
+
+int shk_export_table(shk_ctx *c, uint64_t *kmers, uint32_t *counts, uint64_t cap, uint64_t *n_out) {
+  if (!c || !n_out) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  HIPC(c, c->misc.ensure(cap * 12 + 16));
+  uint8_t *p = (uint8_t *)c->misc.p;
+  unsigned long long *dn = (unsigned long long *)p;
+  uint64_t *dk = (uint64_t *)(p + 16);
+  uint32_t *dc = (uint32_t *)(p + 16 + cap * 8);
+  HIPC(c, hipMemsetAsync(dn, 0, 8, c->stream));
+  uint64_t s0 = 0, s1 = c->tb.cap;
+  if (c->own_set) {
+    s0 = c->own_p0 << PAGE_LOG;
+    s1 = c->own_p1 << PAGE_LOG;
+  }
+  {
+    ScopedTimer t(c, SHK_K_EXPORT);
+    hipLaunchKernelGGL(k_export, dim3(grid_for(s1 - s0, WG * 4, 4096)), dim3(WG), 0, c->stream, c->tb, s0,
+                       s1, dk, dc, cap, dn);
+  }
+  unsigned long long n = 0;
+  HIPC(c, hipMemcpyAsync(&n, dn, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  *n_out = n;
+  uint64_t m = std::min<uint64_t>(n, cap);
+  if (m && kmers) HIPC(c, hipMemcpy(kmers, dk, m * 8, hipMemcpyDeviceToHost));
+  if (m && counts) HIPC(c, hipMemcpy(counts, dc, m * 4, hipMemcpyDeviceToHost));
+  return SHK_OK;
+}
+
+int shk_lookup(shk_ctx *c, const uint64_t *kmers, uint32_t *counts, uint64_t n, int canonical) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (n == 0) return SHK_OK;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  HIPC(c, c->misc.ensure(n * 12));
+  uint64_t *dk = (uint64_t *)c->misc.p;
+  uint32_t *dc = (uint32_t *)((uint8_t *)c->misc.p + n * 8);
+  HIPC(c, hipMemcpyAsync(dk, kmers, n * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedTimer t(c, SHK_K_LOOKUP);
+    hipLaunchKernelGGL(k_lookup, dim3((uint32_t)((n + WG - 1) / WG)), dim3(WG), 0, c->stream, c->tb, dk, dc,
+                       n, canonical, (int)c->cfg.k);
+  }
+  HIPC(c, hipMemcpyAsync(counts, dc, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return SHK_OK;
+}
+
+int shk_table_geometry(shk_ctx *c, uint64_t *n_pages, uint32_t *page_slots, uint32_t *n_lanes) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (n_pages) *n_pages = 1ull << c->tb.log_pages;
+  if (page_slots) *page_slots = PAGE_SLOTS;
+  if (n_lanes) *n_lanes = c->n_lanes;
+  return SHK_OK;
+}
+
+int shk_table_reserve_pages(shk_ctx *c, uint64_t n_pages) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  uint32_t lp = 0;
+  while ((1ull << lp) < n_pages) lp++;
+  c->finalized = false;
+  return grow_to(c, lp);
+}
+
+int shk_table_device_ptrs(shk_ctx *c, void **d_keys, void **d_vals) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  if (d_keys) *d_keys = c->tb.keys;
+  if (d_vals) *d_vals = c->tb.vals;
+  return SHK_OK;
+}
+
+int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, const void *d_vals) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (p1 <= p0) return SHK_OK;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  c->finalized = false;
+  const uint64_t n_slots = (p1 - p0) << PAGE_LOG;
+  // worst case every peer key is new here
+  HIPC(c, c->spillA.ensure(n_slots * c->n_lanes * 16));
+  SpillRef sp = spill_ref(c->spillA, n_slots * c->n_lanes);
+  HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  {
+    ScopedTimer t(c, SHK_K_MERGE);
+    hipLaunchKernelGGL(k_merge, dim3(grid_for(n_slots, WG, 8192)), dim3(WG), 0, c->stream, c->tb,
+                       p0 << PAGE_LOG, n_slots, (const uint64_t *)d_keys, (const uint32_t *)d_vals,
+                       c->d_stats, sp);
+  }
+  int rc = read_stats(c);
+  if (rc != SHK_OK) return rc;
+  return drain_spill(c, n_slots * c->n_lanes);
+}
+
+int shk_set_owned_pages(shk_ctx *c, uint64_t p0, uint64_t p1) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (p1 < p0 || p1 > (1ull << c->tb.log_pages)) return fail(c, SHK_ERR_BAD_ARG, "bad page range");
+  c->own_p0 = p0;
+  c->own_p1 = p1;
+  c->own_set = true;
+  c->finalized = false;
+  return SHK_OK;
+}
+
+void *shk_alloc_pinned(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void shk_free_pinned(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+void *shk_alloc_device(shk_ctx *c, size_t bytes) {
+  if (!c) return nullptr;
+  (void)hipSetDevice(c->cfg.device);
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  return p;
+}
+void shk_free_device(shk_ctx *c, void *p) {
+  if (!c || !p) return;
+  (void)hipSetDevice(c->cfg.device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(p);
+}
+
+int shk_synth_reads_device(shk_ctx *c, const shk_synth *spec, uint64_t first_read, uint64_t n_reads,
+                           void *d_bases, void *d_offsets) {
+  if (!c || !spec) return SHK_ERR_BAD_ARG;
+  if (spec->read_len == 0 || spec->genome_len < spec->read_len)
+    return fail(c, SHK_ERR_BAD_ARG, "bad synth spec");
+  HIPC(c, hipSetDevice(c->cfg.device));
+  SynthSpec s{spec->seed_genome, spec->seed_reads, spec->genome_len, spec->read_len,
+              spec->sub_per_64k, spec->n_per_64k, 0};
+  uint64_t total = n_reads * spec->read_len;
+  uint64_t items = std::max<uint64_t>(total, n_reads + 1);
+  uint64_t threads = (items + 7) / 8;
+  {
+    ScopedTimer t(c, SHK_K_SYNTH);
+    hipLaunchKernelGGL(k_synth, dim3((uint32_t)((threads + WG - 1) / WG)), dim3(WG), 0, c->stream, s,
+                       first_read, n_reads, (uint8_t *)d_bases, (uint64_t *)d_offsets);
+  }
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return SHK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+"""ctypes host mirror of the libshk C ABI (include/shk.h).
+
+`KmerEngine` plays the role the reference's `FastqReadState` + `Chunk`s +
+`consolidate_and_histogram` play in src/io.rs: sequences go in (explicit chunk
+like drain_batch, io.rs:355-361, or striped by read index like read_fastq,
+io.rs:335-343), histograms and totals come out (io.rs:1020-1028, 545-552).
+Errors surface as `ShkError` carrying the reference's message text.
+
+The library is loaded from sharkmer_amd/csrc/libshk.so (in-tree).  If it is
+missing the import of this module still works, but any use raises — there is no
+fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+N_READS_PER_BATCH = 1000  # io.rs:15
+
+FLAG_TIMING = 1
+FLAG_FORCE_DIRECT = 2
+FLAG_FORCE_PAGED = 4
+
+KERNEL_NAMES = ["mark", "scan", "direct", "scatter", "pages", "histo", "grow", "insert",
+                "lookup", "export", "synth", "merge"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "csrc", "libshk.so")
+
+
+class ShkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[shk {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class _Config(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("chunks", C.c_uint32), ("histo_max", C.c_uint64),
+                ("device", C.c_int32), ("flags", C.c_uint32),
+                ("table_capacity_hint", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+
+
+class _Counters(C.Structure):
+    _fields_ = [("n_reads_ingested", C.c_uint64), ("n_bases_read", C.c_uint64),
+                ("n_bases_ingested", C.c_uint64), ("n_kmers_ingested", C.c_uint64),
+                ("n_unique_kmers", C.c_uint64), ("n_hashed_kmers", C.c_uint64),
+                ("n_singleton_kmers", C.c_uint64), ("any_saturated", C.c_uint32),
+                ("n_chunks", C.c_uint32), ("table_capacity", C.c_uint64),
+                ("n_grows", C.c_uint64), ("n_spilled", C.c_uint64)]
+
+
+class _Timings(C.Structure):
+    _fields_ = [("ms", C.c_double * 16), ("launches", C.c_uint64 * 16)]
+
+
+class _Synth(C.Structure):
+    _fields_ = [("seed_genome", C.c_uint64), ("seed_reads", C.c_uint64), ("genome_len", C.c_uint64),
+                ("read_len", C.c_uint32), ("sub_per_64k", C.c_uint32), ("n_per_64k", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+# every symbol include/shk.h declares (tests check the .so exports them all)
+ABI_SYMBOLS = [
+    "shk_abi_version", "shk_create", "shk_destroy", "shk_reset", "shk_last_error", "shk_ingest_batch",
+    "shk_ingest_reads", "shk_ingest_reads_device", "shk_insert_counts", "shk_sync", "shk_finalize",
+    "shk_histograms", "shk_get_counters", "shk_get_timings", "shk_reset_timings",
+    "shk_export_table", "shk_lookup", "shk_table_geometry", "shk_table_reserve_pages",
+    "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
+    "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_synth_reads_device",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libshk.so and type its entry points.  Raises if the HIP build is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ShkError(-9, f"{p} not found: build it with __graft_entry__.build() "
+                           f"(hipcc --offload-arch=gfx950); libshk has no CPU fallback")
+    L = C.CDLL(p)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.shk_abi_version.restype = C.c_int
+    L.shk_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
+    L.shk_create.restype = C.c_int
+    L.shk_destroy.argtypes = [vp]
+    L.shk_destroy.restype = None
+    L.shk_reset.argtypes = [vp]
+    L.shk_last_error.argtypes = [vp]
+    L.shk_last_error.restype = C.c_char_p
+    L.shk_ingest_batch.argtypes = [vp, u32, vp, vp, u64]
+    L.shk_ingest_reads.argtypes = [vp, vp, vp, u64]
+    L.shk_ingest_reads_device.argtypes = [vp, vp, vp, u64, u64]
+    L.shk_insert_counts.argtypes = [vp, u32, vp, vp, u64]
+    L.shk_sync.argtypes = [vp]
+    L.shk_finalize.argtypes = [vp]
+    L.shk_histograms.argtypes = [vp, vp]
+    L.shk_get_counters.argtypes = [vp, C.POINTER(_Counters)]
+    L.shk_get_timings.argtypes = [vp, C.POINTER(_Timings)]
+    L.shk_reset_timings.argtypes = [vp]
+    L.shk_export_table.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+    L.shk_lookup.argtypes = [vp, vp, vp, u64, C.c_int]
+    L.shk_table_geometry.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
+    L.shk_table_reserve_pages.argtypes = [vp, u64]
+    L.shk_table_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.shk_merge_pages.argtypes = [vp, u64, u64, vp, vp]
+    L.shk_set_owned_pages.argtypes = [vp, u64, u64]
+    L.shk_alloc_pinned.argtypes = [C.c_size_t]
+    L.shk_alloc_pinned.restype = vp
+    L.shk_free_pinned.argtypes = [vp]
+    L.shk_free_pinned.restype = None
+    L.shk_alloc_device.argtypes = [vp, C.c_size_t]
+    L.shk_alloc_device.restype = vp
+    L.shk_free_device.argtypes = [vp, vp]
+    L.shk_free_device.restype = None
+    L.shk_synth_reads_device.argtypes = [vp, C.POINTER(_Synth), u64, u64, vp, vp]
+    for name in ABI_SYMBOLS:
+        getattr(L, name)  # AttributeError here = the .so is stale
+    _lib = L
+    return L
+
+
+class KmerEngine:
+    """One counting context on one GPU.
+
+    k, chunks, histo_max: the reference's -k / --chunks / --histo-max
+    (cli.rs:207-224; validated like cli.rs:659-677 except "k odd", which is the
+    CLI's rule).  capacity_hint: expected number of distinct k-mers."""
+
+    def __init__(self, k: int, chunks: int = 0, histo_max: int = 10000, device: int = 0,
+                 capacity_hint: int = 0, flags: int = 0):
+        self._L = load_library()
+        self.k, self.chunks, self.histo_max = k, chunks, histo_max
+        cfg = _Config(k=k, chunks=chunks, histo_max=histo_max, device=device, flags=flags,
+                      table_capacity_hint=capacity_hint)
+        h = C.c_void_p()
+        rc = self._L.shk_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise ShkError(rc, (self._L.shk_last_error(None) or b"").decode("utf-8", "replace"))
+        self._h = h
+
+    # -- plumbing ------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise ShkError(rc, (self._L.shk_last_error(self._h) or b"").decode("utf-8", "replace"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.shk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @staticmethod
+    def _pack(seqs):
+        bs = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in seqs]
+        offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            offsets[1:] = np.cumsum([len(b) for b in bs])
+        bases = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, dtype=np.uint8)
+        return bases, offsets
+
+    # -- ingest --------------------------------------------------------------------------
+    def ingest_batch(self, chunk_id: int, bases: np.ndarray, offsets: np.ndarray):
+        """drain_batch body (io.rs:356-358): all sequences to `chunk_id`."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self._L.shk_ingest_batch(self._h, chunk_id, bases.ctypes.data, offsets.ctypes.data,
+                                             len(offsets) - 1))
+
+    def ingest_reads(self, bases: np.ndarray, offsets: np.ndarray):
+        """read_fastq cadence (io.rs:335-343,355-361): read i → chunk (i//1000) % n_chunks."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self._L.shk_ingest_reads(self._h, bases.ctypes.data, offsets.ctypes.data,
+                                             len(offsets) - 1))
+
+    def ingest_seqs(self, seqs):
+        """Convenience: a list of str/bytes sequences in input order."""
+        self.ingest_reads(*self._pack(seqs))
+
+    def ingest_seq(self, seq, chunk_id: int = 0):
+        """Chunk::ingest_seq (chunk.rs:25-30) for one sequence (launch-bound; tests only)."""
+        self.ingest_batch(chunk_id, *self._pack([seq]))
+
+    def ingest_reads_device(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int):
+        self._check(self._L.shk_ingest_reads_device(self._h, d_bases, d_offsets, n_seqs, n_bases))
+
+    def insert(self, kmers, counts, chunk_id: int = 0):
+        """KmerCounts::insert (counting.rs:152-154)."""
+        kmers = np.ascontiguousarray(np.atleast_1d(kmers), dtype=np.uint64)
+        counts = np.ascontiguousarray(np.atleast_1d(counts), dtype=np.uint32)
+        assert len(kmers) == len(counts)
+        self._check(self._L.shk_insert_counts(self._h, chunk_id, kmers.ctypes.data, counts.ctypes.data,
+                                              len(kmers)))
+
+    def sync(self):
+        self._check(self._L.shk_sync(self._h))
+
+    def reset(self):
+        """Empty chunks and zero counters, keeping allocations (a fresh FastqReadState)."""
+        self._check(self._L.shk_reset(self._h))
+
+    # -- consolidate -------------------------------------------------------------------
+    def finalize(self):
+        self._check(self._L.shk_finalize(self._h))
+        return self
+
+    def histograms(self) -> np.ndarray:
+        """histo_vecs (io.rs:1020-1028): (chunks, histo_max+2) u64."""
+        out = np.zeros((self.chunks, self.histo_max + 2), dtype=np.uint64)
+        self._check(self._L.shk_histograms(self._h, out.ctypes.data))
+        return out
+
+    def counters(self) -> dict:
+        c = _Counters()
+        self._check(self._L.shk_get_counters(self._h, C.byref(c)))
+        return {f: int(getattr(c, f)) for f, _ in _Counters._fields_}
+
+    def timings(self) -> dict:
+        t = _Timings()
+        self._check(self._L.shk_get_timings(self._h, C.byref(t)))
+        return {KERNEL_NAMES[i]: (float(t.ms[i]), int(t.launches[i]))
+                for i in range(len(KERNEL_NAMES)) if t.launches[i]}
+
+    def reset_timings(self):
+        self._check(self._L.shk_reset_timings(self._h))
+
+    # -- merged-table read API ------------------------------------------------------
+    def export_table(self):
+        """KmerCounts::iter (counting.rs:239-241), sorted by k-mer for comparison."""
+        n = C.c_uint64(0)
+        self._check(self._L.shk_export_table(self._h, None, None, 0, C.byref(n)))
+        cap = int(n.value)
+        keys = np.zeros(cap, dtype=np.uint64)
+        cnts = np.zeros(cap, dtype=np.uint32)
+        if cap:
+            self._check(self._L.shk_export_table(self._h, keys.ctypes.data, cnts.ctypes.data, cap,
+                                                 C.byref(n)))
+        o = np.argsort(keys, kind="stable")
+        return keys[o], cnts[o]
+
+    def lookup(self, kmers, canonical: bool = False) -> np.ndarray:
+        """get_count (counting.rs:224-226) / get_canonical_count (:205-209)."""
+        kmers = np.ascontiguousarray(np.atleast_1d(kmers), dtype=np.uint64)
+        out = np.zeros(len(kmers), dtype=np.uint32)
+        self._check(self._L.shk_lookup(self._h, kmers.ctypes.data, out.ctypes.data, len(kmers),
+                                       1 if canonical else 0))
+        return out
+
+    # -- multi-GPU hooks ---------------------------------------------------------------
+    def table_geometry(self):
+        p, s, l = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.shk_table_geometry(self._h, C.byref(p), C.byref(s), C.byref(l)))
+        return int(p.value), int(s.value), int(l.value)
+
+    def reserve_pages(self, n_pages: int):
+        self._check(self._L.shk_table_reserve_pages(self._h, n_pages))
+
+    def table_device_ptrs(self):
+        k, v = C.c_void_p(), C.c_void_p()
+        self._check(self._L.shk_table_device_ptrs(self._h, C.byref(k), C.byref(v)))
+        return int(k.value), int(v.value)
+
+    def merge_pages(self, p0: int, p1: int, d_keys: int, d_vals: int):
+        self._check(self._L.shk_merge_pages(self._h, p0, p1, d_keys, d_vals))
+
+    def set_owned_pages(self, p0: int, p1: int):
+        self._check(self._L.shk_set_owned_pages(self._h, p0, p1))
+
+    # -- device memory + synthetic input ---------------------------------------------
+    def alloc_device(self, nbytes: int) -> int:
+        p = self._L.shk_alloc_device(self._h, nbytes)
+        if not p:
+            raise ShkError(-4, f"device allocation of {nbytes} bytes failed")
+        return int(p)
+
+    def free_device(self, p: int):
+        self._L.shk_free_device(self._h, p)
+
+    def synth_reads_device(self, spec, first_read: int, n_reads: int, d_bases: int, d_offsets: int):
+        s = _Synth(seed_genome=spec.seed_genome, seed_reads=spec.seed_reads,
+                   genome_len=spec.genome_len, read_len=spec.read_len,
+                   sub_per_64k=spec.sub_per_64k, n_per_64k=spec.n_per_64k)
+        self._check(self._L.shk_synth_reads_device(self._h, C.byref(s), first_read, n_reads,
+                                                   d_bases, d_offsets))

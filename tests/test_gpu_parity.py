@@ -1,0 +1,297 @@
+"""GPU parity tests: the HIP path, called through the C ABI (sharkmer_amd.KmerEngine is a
+ctypes shim over include/shk.h), against the CPU oracle on identical inputs.  Bit-exact:
+every comparison is integer equality.  Test names follow the reference's own tests
+(src/kmer/mod.rs, src/kmer/counting.rs, tests/spcr_18s.rs) where they mirror one."""
+import numpy as np
+import pytest
+
+import sharkmer_amd as sa
+
+pytestmark = pytest.mark.gpu
+
+FLAGSETS = [0, sa.FLAG_FORCE_DIRECT]
+
+
+def pack(seqs):
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offsets[1:] = np.cumsum([len(b) for b in bs])
+    return np.frombuffer(b"".join(bs), dtype=np.uint8), offsets
+
+
+def ragged_reads(rng, n, max_len=200, p_n=0.01, alphabet=b"ACGT"):
+    """Variable-length reads incl. empty, shorter than k, all-N."""
+    lens = rng.integers(0, max_len, size=n)
+    lens[rng.random(n) < 0.05] = 0
+    total = int(lens.sum())
+    codes = rng.integers(0, len(alphabet), size=total)
+    bases = np.frombuffer(alphabet, dtype=np.uint8)[codes].copy()
+    bases[rng.random(total) < p_n] = ord("N")
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    return bases, offsets
+
+
+def check_against_oracle(orc, bases, offsets, k, chunks, histo_max, flags=0, hint=0, splits=None,
+                         check_table=True):
+    ref = orc.run_batch(bases, offsets, k, chunks, histo_max)
+    with sa.KmerEngine(k, chunks, histo_max, capacity_hint=hint, flags=flags) as eng:
+        n = len(offsets) - 1
+        cuts = [0] + sorted(splits or []) + [n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            eng.ingest_reads(bases, offsets[a:b + 1])
+        eng.finalize()
+        got = eng.histograms()
+        cnt = eng.counters()
+        keys, cnts = eng.export_table() if check_table else (None, None)
+    want = ref.histograms()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"histogram mismatch k={k} chunks={chunks}"
+    st = ref.stats
+    assert cnt["n_reads_ingested"] == st["n_reads_ingested"]
+    assert cnt["n_bases_read"] == st["n_bases_read"]
+    assert cnt["n_bases_ingested"] == st["n_bases_ingested"]
+    assert cnt["n_kmers_ingested"] == st["n_kmers_ingested"]
+    assert cnt["n_unique_kmers"] == st["n_unique_kmers"]
+    assert cnt["n_hashed_kmers"] == st["n_hashed_kmers"]
+    if chunks > 0:
+        assert cnt["n_singleton_kmers"] == st["n_singleton_kmers"]
+    if check_table:
+        rk, rc = ref.merged().export()
+        assert np.array_equal(keys, rk) and np.array_equal(cnts, rc)
+    return cnt
+
+
+# ---- known-answer tests through the C ABI ------------------------------------------------
+
+@pytest.mark.parametrize("flags", FLAGSETS)
+def test_ingest_seq(flags):
+    """counting.rs:482-490: ACGT, k=3 → one canonical k-mer with count 2."""
+    with sa.KmerEngine(3, 1, 10, flags=flags) as eng:
+        eng.ingest_seq("ACGT")
+        eng.finalize()
+        c = eng.counters()
+        assert c["n_unique_kmers"] == 1 and c["n_kmers_ingested"] == 2
+        assert list(eng.histograms()[0]) == [0, 0, 1] + [0] * 9
+
+
+def test_histogram_kat():
+    """kmer/mod.rs:288-305: counts {5,5,7,11,12}, histo_max 10."""
+    with sa.KmerEngine(11, 1, 10) as eng:
+        eng.insert([1, 20, 2, 11, 12], [5, 5, 7, 11, 12])
+        eng.finalize()
+        assert list(eng.histograms()[0]) == [0, 0, 0, 0, 0, 2, 0, 1, 0, 0, 0, 2]
+
+
+def test_insert_accumulates_and_saturates():
+    """counting.rs:384-399."""
+    with sa.KmerEngine(5, 1, 10) as eng:
+        eng.insert([42], [3])
+        eng.insert([42], [7])
+        eng.insert([1], [0xFFFFFFFF])
+        eng.insert([1], [1])
+        assert list(eng.lookup([42, 1, 99])) == [10, 0xFFFFFFFF, 0]
+
+
+@pytest.mark.parametrize("flags", FLAGSETS)
+def test_saturating_add_under_ingest(orc, flags):
+    """counting.rs:82-85: ingest increments saturate exactly at u32::MAX."""
+    seq = "ACGTTGCATGCATGAC" * 4
+    kms = sorted(set(orc.kmers_from_ascii(seq, 5)))
+    target = kms[0]
+    n_occ = orc.kmers_from_ascii(seq, 5).count(target)
+    assert n_occ >= 2
+    with sa.KmerEngine(5, 1, 10, flags=flags) as eng:
+        eng.insert([target], [0xFFFFFFFF - 1])
+        eng.ingest_seq(seq)
+        assert int(eng.lookup([target])[0]) == 0xFFFFFFFF
+        other = kms[1]
+        assert int(eng.lookup([other])[0]) == orc.kmers_from_ascii(seq, 5).count(other)
+
+
+_CASES = ["CGTAATGCGGCGA", "CGTANATGCGGCGA", "NCGTANATGCGGCGA", "NCGTANATGCGGCGANN",
+          "NNCGTANATGCGGCGA", "TANCACN", "NTANCACNAGAAAATC", "AAAA", "ACGTACGTACGT"]
+
+
+@pytest.mark.parametrize("k", [3, 5, 9, 11])
+def test_kmers_from_ascii_cases(orc, k):
+    """kmer/mod.rs:249-270: the reference's 9 N-placement strings, one per read."""
+    bases, offsets = pack(_CASES)
+    check_against_oracle(orc, bases, offsets, k, 1, 20)
+    for seq in _CASES:  # and each string on its own: exact multiset of k-mers
+        want = sorted(orc.kmers_from_ascii(seq, k))
+        with sa.KmerEngine(k, 0, 10) as eng:
+            eng.ingest_seq(seq)
+            keys, cnts = eng.export_table()
+        got = sorted(int(x) for x, c in zip(keys, cnts) for _ in range(int(c)))
+        assert got == want, (seq, k)
+
+
+def test_short_sequences(orc):
+    """kmer/mod.rs:272-278 + chunk.rs:27: reads shorter than k count as reads, emit nothing."""
+    bases, offsets = pack(["ACGT", "ACGTACGTA", "", "NNN", "A"])
+    cnt = check_against_oracle(orc, bases, offsets, 9, 1, 10)
+    assert cnt["n_reads_ingested"] == 5 and cnt["n_kmers_ingested"] == 1
+    assert cnt["n_bases_ingested"] == 14 and cnt["n_bases_read"] == 17
+
+
+@pytest.mark.parametrize("seq,bad", [("ACGTX", "X"), ("acgt", "a"), ("ACG T", " "), ("ACGT\n", "\n")])
+def test_invalid_character(seq, bad):
+    """encoding.rs:353-356: same message; the run is aborted (context poisoned)."""
+    with sa.KmerEngine(3, 1, 10) as eng:
+        eng.ingest_seq("ACGTACGT")
+        with pytest.raises(sa.ShkError) as e:
+            eng.ingest_seqs(["ACGT", seq, "ACZT"])
+        assert e.value.code == -1
+        assert e.value.msg == f"Invalid character '{bad}' in sequence. Only ACGTN allowed."
+        with pytest.raises(sa.ShkError):
+            eng.finalize()
+
+
+def test_no_reads_is_an_error():
+    """io.rs:578-580."""
+    with sa.KmerEngine(21, 1, 10) as eng:
+        with pytest.raises(sa.ShkError) as e:
+            eng.finalize()
+        assert e.value.code == -5 and "No reads were ingested" in e.value.msg
+
+
+@pytest.mark.parametrize("k,histo_max", [(0, 10), (32, 10), (21, 0), (21, 1_000_001)])
+def test_validate_args(k, histo_max):
+    """cli.rs:659-677."""
+    with pytest.raises(sa.ShkError) as e:
+        sa.KmerEngine(k, 1, histo_max)
+    assert e.value.code == -2
+
+
+# ---- randomized parity vs the oracle ---------------------------------------------------------
+
+@pytest.mark.parametrize("flags", FLAGSETS)
+@pytest.mark.parametrize("k,chunks", [(21, 1), (21, 0), (31, 3), (5, 2), (1, 1), (3, 10), (13, 7)])
+def test_ragged_parity(orc, k, chunks, flags):
+    rng = np.random.default_rng(1000 * k + chunks)
+    bases, offsets = ragged_reads(rng, 12_345)
+    check_against_oracle(orc, bases, offsets, k, chunks, 50, flags=flags)
+
+
+@pytest.mark.parametrize("flags", FLAGSETS)
+def test_parity_variant_errors_and_n(orc, flags):
+    """SURVEY.md §8d parity variant: 0.5 % substitutions, 0.1 % N, tiny genome so counts exceed
+    histo_max (overflow bin) and singletons dominate."""
+    spec = sa.SynthSpec(genome_len=2000, sub_per_64k=328, n_per_64k=66)
+    bases, offsets = sa.synth_reads(spec, 0, 30_000)
+    cnt = check_against_oracle(orc, bases, offsets, 21, 5, 100, flags=flags)
+    assert cnt["n_singleton_kmers"] > 0
+
+
+def test_split_calls_match_single_call(orc):
+    """State persists across calls like FastqReadState across files (io.rs:498-512): batches
+    of 1000 span call boundaries."""
+    rng = np.random.default_rng(7)
+    bases, offsets = ragged_reads(rng, 9_876, max_len=120)
+    check_against_oracle(orc, bases, offsets, 15, 4, 30, splits=[1, 999, 1000, 1001, 2500, 7777])
+
+
+def test_explicit_chunk_batches(orc):
+    """shk_ingest_batch = drain_batch body: caller-chosen chunk per batch."""
+    rng = np.random.default_rng(11)
+    bases, offsets = ragged_reads(rng, 5_000, max_len=100)
+    ref = orc.run_batch(bases, offsets, 11, 3, 40)
+    with sa.KmerEngine(11, 3, 40) as eng:
+        for b in range(5):
+            eng.ingest_batch(b % 3, bases, offsets[b * 1000:(b + 1) * 1000 + 1])
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms())
+
+
+@pytest.mark.parametrize("flags", FLAGSETS)
+def test_growth_and_spill_keep_results_exact(orc, flags):
+    """No capacity hint, nearly all k-mers distinct: the table must grow (and may spill)
+    without losing or double counting anything."""
+    rng = np.random.default_rng(3)
+    n = 20_000
+    codes = rng.integers(0, 4, size=n * 150)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].copy()
+    offsets = np.arange(n + 1, dtype=np.uint64) * 150
+    cnt = check_against_oracle(orc, bases, offsets, 31, 2, 10, flags=flags, check_table=False)
+    assert cnt["n_grows"] >= 1
+    assert cnt["n_unique_kmers"] > 2_000_000
+
+
+def test_incremental_histogram_consistency(orc):
+    """tests/spcr_18s.rs:437-528: the final histogram does not depend on the chunk count."""
+    spec = sa.SynthSpec(genome_len=50_000, sub_per_64k=328, n_per_64k=66)
+    bases, offsets = sa.synth_reads(spec, 0, 40_000)
+    finals = []
+    for chunks in (1, 20):
+        with sa.KmerEngine(21, chunks, 1000) as eng:
+            eng.ingest_reads(bases, offsets)
+            eng.finalize()
+            finals.append(eng.histograms()[-1])
+    assert np.array_equal(finals[0], finals[1])
+    ref = orc.run_batch(bases, offsets, 21, 20, 1000)
+    assert np.array_equal(finals[1], ref.histograms()[-1])
+
+
+def test_lookup_canonical(orc):
+    """counting.rs:205-209, 224-226."""
+    seq = "ACGGTCATTGCAAGCTAGCTAGGATCGA"
+    with sa.KmerEngine(7, 0, 10) as eng:
+        eng.ingest_seq(seq)
+        kc = orc.KmerCounts(7)
+        kc.ingest_seq(seq)
+        fwd = [orc.seq_to_kmer(seq[i:i + 7]) for i in range(len(seq) - 6)]
+        assert list(eng.lookup(fwd, canonical=True)) == [kc.get_canonical_count(x) for x in fwd]
+        assert list(eng.lookup(fwd, canonical=False)) == [kc.get_count(x) for x in fwd]
+
+
+# ---- device-resident input + device generator --------------------------------------------------
+
+def test_device_synth_matches_host_generator():
+    import torch
+    spec = sa.SynthSpec(genome_len=10_000, sub_per_64k=400, n_per_64k=80)
+    n = 3_001
+    hb, ho = sa.synth_reads(spec, 17, n)
+    with sa.KmerEngine(21, 1, 10) as eng:
+        db = torch.empty(n * 150, dtype=torch.uint8, device="cuda")
+        do = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        eng.synth_reads_device(spec, 17, n, db.data_ptr(), do.data_ptr())
+        assert np.array_equal(db.cpu().numpy(), hb)
+        assert np.array_equal(do.cpu().numpy().astype(np.uint64), ho)
+
+
+def test_device_resident_ingest(orc):
+    import torch
+    spec = sa.SynthSpec(genome_len=30_000, sub_per_64k=328, n_per_64k=66)
+    n = 25_000
+    hb, ho = sa.synth_reads(spec, 0, n)
+    ref = orc.run_batch(hb, ho, 21, 4, 200)
+    with sa.KmerEngine(21, 4, 200) as eng:
+        db = torch.from_numpy(hb).cuda()
+        do = torch.from_numpy(ho.astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        eng.ingest_reads_device(db.data_ptr(), do.data_ptr(), n, len(hb))
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms())
+
+
+# ---- BASELINE.json config 2 at full size: 1 M reads, k=21 ------------------------------------------
+
+@pytest.mark.parametrize("flags", FLAGSETS)
+def test_config2_full_size(orc, flags):
+    spec = sa.SynthSpec(genome_len=3_000_000)
+    n = 1_000_000
+    bases, offsets = sa.synth_reads(spec, 0, n)
+    ref = orc.run_batch(bases, offsets, 21, 1, 10000)
+    with sa.KmerEngine(21, 1, 10000, capacity_hint=3_000_000, flags=flags) as eng:
+        eng.ingest_reads(bases, offsets)
+        eng.finalize()
+        got = eng.histograms()
+        cnt = eng.counters()
+    assert np.array_equal(got, ref.histograms())
+    assert cnt["n_kmers_ingested"] == 130 * n
+    # size-independent properties: Σ freq·count = k-mer occurrences; Σ freq = distinct
+    col = got[0].astype(object)
+    assert sum(int(f) * i for i, f in enumerate(col)) == 130 * n  # no count exceeds histo_max here
+    assert int(got[0].sum()) == cnt["n_unique_kmers"]
