@@ -692,3 +692,231 @@ __global__ void __launch_bounds__(WG) k_synth(SynthSpec sp, uint64_t first_read,
 }
 
 }  // namespace shk
+
+// ##########################################################################################
+// Paged path: the table is a sequence of PAGE_SLOTS-slot pages, each an independent
+// open-addressing table that fits in LDS (32 KiB keys + 16 KiB counts).  One counting pass =
+//   K_SCATTER  a) k_part_count    extract k-mers, count them per page      (LDS histogram)
+//              b) k_part_scan1/2  exclusive scans → a private, contiguous output run for
+//                                 every (workgroup, page): no global atomics anywhere
+//              c) k_part_scatter  extract again, append each k-mer to its page's run
+//   K_PAGES    k_pages            one workgroup per page: page → LDS, stream the page's run
+//                                 through LDS atomics, page → HBM
+// HBM traffic per k-mer occurrence: 8 B written + 8 B read, all of it streaming; the table
+// is read and written once per pass.  counting.rs:82-85 semantics, exact incl. saturation.
+// ##########################################################################################
+namespace shk {
+
+constexpr int MAX_PARTS = 8192;   // pages addressable by the LDS page histogram (32 KiB)
+constexpr int PG_WG = 512;        // k_pages workgroup: 8 waves, 3 workgroups per CU by LDS
+constexpr uint32_t PAGE_FILL_CAP = PAGE_SLOTS - PAGE_SLOTS / 8;  // new keys spill beyond this
+
+__global__ void __launch_bounds__(WG) k_part_count(BatchRef b, uint32_t log_pages,
+                                                   uint32_t lane_filter,
+                                                   uint32_t *__restrict__ counts,
+                                                   const DevStats *__restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+  const uint32_t P = 1u << log_pages;
+  uint8_t *lds = reinterpret_cast<uint8_t *>(sh);   // TILE_LDS bytes (multiple of 16)
+  uint32_t *cnt = sh + TILE_LDS / 4;                // P counters
+  for (uint32_t i = threadIdx.x; i < P; i += WG) cnt[i] = 0;
+  __syncthreads();
+  if (stats->bad == ~0ull) {
+    for (uint64_t t = blockIdx.x;; t += gridDim.x) {
+      uint64_t t0, t1;
+      uint32_t lane;
+      if (!tile_get(b, t, t0, t1, lane)) break;
+      if (lane != lane_filter) continue;
+      __syncthreads();
+      stage_tile(b, t0, lds);
+      __syncthreads();
+      walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) {
+        atomicAdd(&cnt[(uint32_t)page_of(hash64(kmer), log_pages)], 1u);
+      });
+    }
+  }
+  __syncthreads();
+  uint32_t *out = counts + (uint64_t)blockIdx.x * P;
+  for (uint32_t i = threadIdx.x; i < P; i += WG) out[i] = cnt[i];
+}
+
+// exclusive scan over workgroups, per page: counts[g][p] → offset of workgroup g inside page
+// p's run; totals[p] = run length
+__global__ void __launch_bounds__(WG) k_part_scan1(uint32_t *__restrict__ counts, uint32_t G,
+                                                   uint32_t P,
+                                                   unsigned long long *__restrict__ totals) {
+  uint32_t p = blockIdx.x * WG + threadIdx.x;
+  if (p >= P) return;
+  uint32_t run = 0;
+  for (uint32_t g = 0; g < G; ++g) {
+    uint32_t c = counts[(uint64_t)g * P + p];
+    counts[(uint64_t)g * P + p] = run;
+    run += c;
+  }
+  totals[p] = run;
+}
+
+// exclusive scan over pages: part_base[p] = Σ_{q<p} totals[q]; part_base[P] = total
+__global__ void __launch_bounds__(1024) k_part_scan2(const unsigned long long *__restrict__ totals,
+                                                     uint32_t P,
+                                                     unsigned long long *__restrict__ part_base) {
+  __shared__ unsigned long long sc[1024];
+  const uint32_t per = (P + 1023) / 1024;
+  const uint32_t lo = threadIdx.x * per;
+  unsigned long long s = 0;
+  for (uint32_t i = 0; i < per; ++i)
+    if (lo + i < P) s += totals[lo + i];
+  sc[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    unsigned long long v = threadIdx.x >= (unsigned)d ? sc[threadIdx.x - d] : 0;
+    __syncthreads();
+    sc[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned long long run = sc[threadIdx.x] - s;
+  for (uint32_t i = 0; i < per; ++i)
+    if (lo + i < P) {
+      part_base[lo + i] = run;
+      run += totals[lo + i];
+    }
+  if (threadIdx.x == 1023) part_base[P] = sc[1023];
+}
+
+__global__ void __launch_bounds__(WG) k_part_scatter(BatchRef b, uint32_t log_pages,
+                                                     uint32_t lane_filter,
+                                                     const uint32_t *__restrict__ counts,
+                                                     const unsigned long long *__restrict__ part_base,
+                                                     uint64_t *__restrict__ part_buf,
+                                                     const DevStats *__restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+  const uint32_t P = 1u << log_pages;
+  uint8_t *lds = reinterpret_cast<uint8_t *>(sh);
+  uint32_t *cur = sh + TILE_LDS / 4;
+  if (stats->bad != ~0ull) return;
+  const uint32_t *mine = counts + (uint64_t)blockIdx.x * P;
+  for (uint32_t i = threadIdx.x; i < P; i += WG) cur[i] = (uint32_t)part_base[i] + mine[i];
+  for (uint64_t t = blockIdx.x;; t += gridDim.x) {
+    uint64_t t0, t1;
+    uint32_t lane;
+    if (!tile_get(b, t, t0, t1, lane)) break;
+    if (lane != lane_filter) continue;
+    __syncthreads();
+    stage_tile(b, t0, lds);
+    __syncthreads();
+    walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) {
+      uint32_t pos = atomicAdd(&cur[(uint32_t)page_of(hash64(kmer), log_pages)], 1u);
+      part_buf[pos] = kmer;
+    });
+  }
+}
+
+__device__ __forceinline__ void page_insert(uint64_t *keys, uint32_t *vals, uint32_t *occ,
+                                            uint64_t key, uint32_t log_pages, bool slow,
+                                            uint32_t lane, DevStats *stats, const SpillRef &sp,
+                                            uint32_t &n_new) {
+  uint32_t s = slot_of(hash64(key), log_pages);
+  for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
+    uint64_t cur = keys[s];
+    if (cur == EMPTY) {
+      if (*(volatile uint32_t *)occ >= PAGE_FILL_CAP) break;  // page (nearly) full → spill
+      uint64_t prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)EMPTY,
+                                (unsigned long long)key);
+      if (prev == EMPTY) {
+        atomicAdd(occ, 1u);
+        n_new++;
+        cur = key;
+      } else {
+        cur = prev;
+      }
+    }
+    if (cur == key) {
+      if (!slow) {
+        atomicAdd(&vals[s], 1u);  // cannot wrap: checked against the run length at page load
+      } else {
+        uint32_t old = atomicAdd(&vals[s], 1u);
+        if (old == 0xFFFFFFFFu) atomicMax(&vals[s], 0xFFFFFFFFu);
+      }
+      return;
+    }
+    s = (s + 1) & (PAGE_SLOTS - 1);
+  }
+  unsigned long long i = atomicAdd(&stats->spill_count, 1ull);
+  if (i < sp.cap) {
+    sp.keys[i] = key;
+    sp.lanes[i] = lane;
+    sp.counts[i] = 1u;
+  }
+}
+
+__global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
+                                                 const unsigned long long *__restrict__ part_base,
+                                                 const uint64_t *__restrict__ part_buf,
+                                                 DevStats *__restrict__ stats, SpillRef sp) {
+  __shared__ __attribute__((aligned(16))) uint64_t keys[PAGE_SLOTS];
+  __shared__ __attribute__((aligned(16))) uint32_t vals[PAGE_SLOTS];
+  __shared__ uint32_t occ, vmax, nnew;
+  if (stats->bad != ~0ull) return;
+  const uint32_t page = blockIdx.x;
+  const uint64_t r0 = part_base[page], r1 = part_base[page + 1];
+  if (r1 == r0) return;  // nothing for this page: leave it untouched in HBM
+  uint64_t *gk = tb.keys + ((uint64_t)page << PAGE_LOG);
+  uint32_t *gv = tb.vals + (uint64_t)lane * tb.cap + ((uint64_t)page << PAGE_LOG);
+  if (threadIdx.x == 0) {
+    occ = 0;
+    vmax = 0;
+    nnew = 0;
+  }
+  __syncthreads();
+  // page → LDS (16-B vectors), counting occupied slots and the largest count on the way
+  uint32_t my_occ = 0, my_max = 0;
+  for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 2; i += PG_WG) {
+    ulonglong2 v = reinterpret_cast<const ulonglong2 *>(gk)[i];
+    reinterpret_cast<ulonglong2 *>(keys)[i] = v;
+    my_occ += (v.x != EMPTY) + (v.y != EMPTY);
+  }
+  for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 4; i += PG_WG) {
+    uint4 v = reinterpret_cast<const uint4 *>(gv)[i];
+    reinterpret_cast<uint4 *>(vals)[i] = v;
+    uint32_t m = v.x > v.y ? v.x : v.y;
+    uint32_t n = v.z > v.w ? v.z : v.w;
+    m = m > n ? m : n;
+    my_max = my_max > m ? my_max : m;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    my_occ += __shfl_down(my_occ, off, 64);
+    uint32_t o = __shfl_down(my_max, off, 64);
+    my_max = my_max > o ? my_max : o;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&occ, my_occ);
+    atomicMax(&vmax, my_max);
+  }
+  __syncthreads();
+  const uint64_t n = r1 - r0;
+  // the plain add cannot wrap if max + run length stays below 2^32
+  const bool slow = (uint64_t)vmax + n > 0xFFFFFFFFull;
+  const uint64_t *src = part_buf + r0;
+  uint32_t n_new = 0;
+  uint64_t i = threadIdx.x;
+  for (; i + 3 * PG_WG < n; i += 4 * PG_WG) {  // four independent loads in flight per thread
+    uint64_t k0 = src[i], k1 = src[i + PG_WG], k2 = src[i + 2 * PG_WG], k3 = src[i + 3 * PG_WG];
+    page_insert(keys, vals, &occ, k0, tb.log_pages, slow, lane, stats, sp, n_new);
+    page_insert(keys, vals, &occ, k1, tb.log_pages, slow, lane, stats, sp, n_new);
+    page_insert(keys, vals, &occ, k2, tb.log_pages, slow, lane, stats, sp, n_new);
+    page_insert(keys, vals, &occ, k3, tb.log_pages, slow, lane, stats, sp, n_new);
+  }
+  for (; i < n; i += PG_WG)
+    page_insert(keys, vals, &occ, src[i], tb.log_pages, slow, lane, stats, sp, n_new);
+  for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
+  if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&nnew, n_new);
+  __syncthreads();
+  // LDS → page
+  for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 2; j += PG_WG)
+    reinterpret_cast<ulonglong2 *>(gk)[j] = reinterpret_cast<const ulonglong2 *>(keys)[j];
+  for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG)
+    reinterpret_cast<uint4 *>(gv)[j] = reinterpret_cast<const uint4 *>(vals)[j];
+  if (threadIdx.x == 0 && nnew) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
+}
+
+}  // namespace shk

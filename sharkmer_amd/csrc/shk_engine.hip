@@ -68,11 +68,11 @@ struct shk_ctx {
   HistoTotals h_tot{};
   std::vector<uint64_t> h_hist;
   // scratch
-  DevBuf in_bases, in_offsets, startbits, tiles, spillA, spillB, misc, part;
+  DevBuf in_bases, in_offsets, startbits, tiles, spillA, spillB, misc, part, part_meta;
   // host counters
   std::vector<uint64_t> lane_reads;
   uint64_t n_reads_read = 0, n_bases_read = 0;
-  uint64_t n_grows = 0, n_spilled = 0;
+  uint64_t n_grows = 0, n_spilled = 0, n_inserted = 0;
   uint64_t own_p0 = 0, own_p1 = 0;  // owned page range for finalize (0,0 = all)
   bool own_set = false;
   bool finalized = false, poisoned = false;
@@ -337,14 +337,60 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
 
 // count_tiles: one counting pass over b's tile range; picks the paged (LDS) or the direct
 // (global atomics) path, then repairs spills and keeps the load ≤ 1/2.
-static bool paged_available() { return false; }
-static int paged_count(shk_ctx *, const BatchRef &, uint64_t, SpillRef) { return SHK_ERR_STATE; }
+// Paged (LDS) counting is possible when every page has an LDS histogram slot and the lane
+// rounds stay few; it pays when the batch is at least comparable to the table, because every
+// touched page is read and written once per pass.
+static bool paged_feasible(const shk_ctx *c) {
+  return (1ull << c->tb.log_pages) <= (uint64_t)MAX_PARTS && c->n_lanes <= 16;
+}
+static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
+  return c->tb.log_pages >= 8 && sub_kmers_ub >= c->tb.cap / 2;
+}
+
+static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp) {
+  const uint32_t lp = c->tb.log_pages;
+  const uint32_t P = 1u << lp;
+  const uint32_t G = grid_for(b.tile_count, 1, 1024);
+  const size_t counts_b = (size_t)G * P * 4, totals_b = (size_t)P * 8, base_b = (size_t)(P + 1) * 8;
+  HIPC(c, c->part_meta.ensure(counts_b + totals_b + base_b + 64));
+  HIPC(c, c->part.ensure(sub_kmers_ub * 8));
+  uint8_t *m = (uint8_t *)c->part_meta.p;
+  uint32_t *counts = (uint32_t *)m;
+  unsigned long long *totals = (unsigned long long *)(m + counts_b);
+  unsigned long long *part_base = (unsigned long long *)(m + counts_b + totals_b);
+  uint64_t *part_buf = (uint64_t *)c->part.p;
+  const size_t lds = TILE_LDS + (size_t)P * 4;
+  const bool multi = b.tiles != nullptr;
+  const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
+  for (uint32_t lane = lane_lo; lane < lane_hi; ++lane) {
+    {
+      ScopedTimer t(c, SHK_K_SCATTER);
+      hipLaunchKernelGGL(k_part_count, dim3(G), dim3(WG), lds, c->stream, b, lp, lane, counts,
+                         (const DevStats *)c->d_stats);
+      hipLaunchKernelGGL(k_part_scan1, dim3((P + WG - 1) / WG), dim3(WG), 0, c->stream, counts, G, P,
+                         totals);
+      hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, c->stream,
+                         (const unsigned long long *)totals, P, part_base);
+      hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(WG), lds, c->stream, b, lp, lane,
+                         (const uint32_t *)counts, (const unsigned long long *)part_base, part_buf,
+                         (const DevStats *)c->d_stats);
+    }
+    {
+      ScopedTimer t(c, SHK_K_PAGES);
+      hipLaunchKernelGGL(k_pages, dim3(P), dim3(PG_WG), 0, c->stream, c->tb, lane,
+                         (const unsigned long long *)part_base, (const uint64_t *)part_buf,
+                         c->d_stats, sp);
+    }
+  }
+  return SHK_OK;
+}
 
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub) {
   HIPC(c, c->spillA.ensure(sub_kmers_ub * 16));
   SpillRef sp = spill_ref(c->spillA, sub_kmers_ub);
   HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
-  bool use_paged = paged_available() && !(c->cfg.flags & SHK_FLAG_FORCE_DIRECT);
+  bool use_paged = paged_feasible(c) && !(c->cfg.flags & SHK_FLAG_FORCE_DIRECT) &&
+                   ((c->cfg.flags & SHK_FLAG_FORCE_PAGED) || paged_pays(c, sub_kmers_ub));
   if (use_paged) {
     int rc = paged_count(c, b, sub_kmers_ub, sp);
     if (rc != SHK_OK) return rc;
@@ -466,6 +512,7 @@ void shk_destroy(shk_ctx *c) {
   c->spillB.release();
   c->misc.release();
   c->part.release();
+  c->part_meta.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -482,6 +529,7 @@ int shk_reset(shk_ctx *c) {
   HIPC(c, hipStreamSynchronize(c->stream));
   std::fill(c->lane_reads.begin(), c->lane_reads.end(), 0);
   c->n_reads_read = c->n_bases_read = 0;
+  c->n_inserted = 0;
   c->own_set = false;
   c->finalized = c->poisoned = false;
   c->poison_code = 0;
@@ -548,6 +596,7 @@ int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, cons
                                      (unsigned long long)kmers[i], c->cfg.k);
   int rc = ensure_capacity(c, n);
   if (rc != SHK_OK) return rc;
+  c->n_inserted += n;
   HIPC(c, c->misc.ensure(n * 12));
   uint64_t *dk = (uint64_t *)c->misc.p;
   uint32_t *dc = (uint32_t *)((uint8_t *)c->misc.p + n * 8);
@@ -581,7 +630,7 @@ int shk_finalize(shk_ctx *c) {
   HIPC(c, hipSetDevice(c->cfg.device));
   uint64_t n_reads = 0;
   for (auto v : c->lane_reads) n_reads += v;
-  if (n_reads == 0 && !c->own_set)  // io.rs:578-580
+  if (n_reads == 0 && c->n_inserted == 0 && !c->own_set)  // io.rs:578-580
     return fail(c, SHK_ERR_NO_READS,
                 "No reads were ingested. Check that input files contain valid FASTQ records.");
   const uint32_t n_cols = c->cfg.chunks;

@@ -78,6 +78,30 @@ ABI_SYMBOLS = [
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the same
+    as /opt/rocm's).  Two HIP/HSA runtimes in one process cannot both open the GPU, so when
+    torch is installed we load ITS copy first (by path, without importing torch); libshk's
+    NEEDED libamdhip64.so.7 then binds to it, and a later `import torch` reuses the same
+    file.  Without torch, libshk uses the system ROCm runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen libshk.so and type its entry points.  Raises if the HIP build is missing."""
     global _lib
@@ -87,6 +111,7 @@ def load_library():
     if not os.path.exists(p):
         raise ShkError(-9, f"{p} not found: build it with __graft_entry__.build() "
                            f"(hipcc --offload-arch=gfx950); libshk has no CPU fallback")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(p)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     L.shk_abi_version.restype = C.c_int

@@ -9,7 +9,7 @@ import sharkmer_amd as sa
 
 pytestmark = pytest.mark.gpu
 
-FLAGSETS = [0, sa.FLAG_FORCE_DIRECT]
+FLAGSETS = [0, sa.FLAG_FORCE_DIRECT, sa.FLAG_FORCE_PAGED]
 
 
 def pack(seqs):
