@@ -119,16 +119,62 @@ __device__ __forceinline__ uint32_t codes4(uint32_t w) {
   return c | (z >> 5);  // 'N' (0x4E) already maps to base bits 00
 }
 
+// Is byte c one of A,C,G,T,N?  (A=0x41 C=0x43 G=0x47 N=0x4E T=0x54 → bits 1,3,7,14,20 of
+// the 0x40..0x5F word.)  encoding.rs:341-356.
+__device__ __forceinline__ bool byte_is_acgtn(uint32_t c) {
+  return (c >> 5) == 2 && ((0x0010408Au >> (c & 31)) & 1u);
+}
+// 0x80 in every byte of w that equals the byte replicated in x4
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t x4) {
+  uint32_t t = w ^ x4;
+  return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+}
+
 // Stage positions [t0-HALO, t0+TILE_T) of the batch into LDS as one code byte per base:
 // bits 0-1 base, bit 2 = N / outside the batch (resets the window), bit 3 = first base
 // of a read (resets the window before the base is taken).  encoding.rs:341-352.
-__device__ __forceinline__ void stage_tile(const BatchRef &b, uint64_t t0, uint8_t *lds) {
+// VALIDATE: additionally check every byte of [t0,t1) against ACGTN (encoding.rs:353-356;
+// the first offender in input order is reported through stats->bad) and return this
+// thread's count of non-N bytes in [t0,t1) (count_valid_bases, encoding.rs:374-376).
+template <bool VALIDATE>
+__device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, uint64_t t1,
+                                               uint8_t *lds, DevStats *stats) {
   const int64_t p0 = (int64_t)t0 - HALO;
+  uint32_t n_non_n = 0;
   for (int m = threadIdx.x; m < TILE_LDS / 16; m += WG) {
     int64_t p = p0 + (int64_t)m * 16;
     uint32_t w[4];
     if (p >= 0 && (uint64_t)p + 16 <= b.n_bases) {
       __builtin_memcpy(w, b.bases + p, 16);  // unaligned 16-B global load (one dwordx4)
+      if (VALIDATE && (uint64_t)p >= t0 && (uint64_t)p < t1) {
+        if ((uint64_t)p + 16 <= t1) {
+          uint32_t bad = 0, nn = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint32_t en = eq_bytes(w[q], 0x4E4E4E4Eu);
+            uint32_t ok = en | eq_bytes(w[q], 0x41414141u) | eq_bytes(w[q], 0x43434343u) |
+                          eq_bytes(w[q], 0x47474747u) | eq_bytes(w[q], 0x54545454u);
+            bad |= ~ok & 0x80808080u;
+            nn += __builtin_popcount(en);
+          }
+          n_non_n += 16 - nn;
+          if (bad) {
+            for (int r = 0; r < 16; ++r) {
+              uint32_t c = (w[r >> 2] >> (8 * (r & 3))) & 0xFF;
+              if (!byte_is_acgtn(c)) {
+                atomicMin(&stats->bad, ((unsigned long long)(p + r) << 8) | c);
+                break;
+              }
+            }
+          }
+        } else {
+          for (int r = 0; r < 16 && (uint64_t)p + r < t1; ++r) {
+            uint32_t c = (w[r >> 2] >> (8 * (r & 3))) & 0xFF;
+            if (!byte_is_acgtn(c)) atomicMin(&stats->bad, ((unsigned long long)(p + r) << 8) | c);
+            n_non_n += (c != 'N');
+          }
+        }
+      }
       w[0] = codes4(w[0]);
       w[1] = codes4(w[1]);
       w[2] = codes4(w[2]);
@@ -142,6 +188,10 @@ __device__ __forceinline__ void stage_tile(const BatchRef &b, uint64_t t0, uint8
           if (pp >= 0 && (uint64_t)pp < b.n_bases) {
             uint32_t a = b.bases[pp];
             c = a == 'N' ? 4u : (((a >> 1) ^ (a >> 2)) & 3u);
+            if (VALIDATE && (uint64_t)pp >= t0 && (uint64_t)pp < t1) {
+              if (!byte_is_acgtn(a)) atomicMin(&stats->bad, ((unsigned long long)pp << 8) | a);
+              n_non_n += (a != 'N');
+            }
           }
           ww |= c << (8 * r);
         }
@@ -170,6 +220,18 @@ __device__ __forceinline__ void stage_tile(const BatchRef &b, uint64_t t0, uint8
     uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
     *reinterpret_cast<uint4 *>(lds + m * 16) = v;
   }
+  return n_non_n;
+}
+
+// workgroup sum of a per-thread u32, result valid in thread 0 (red: WG/64 words of LDS)
+__device__ __forceinline__ uint32_t wg_sum(uint32_t v, uint32_t *red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t s = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < WG / 64; ++w) s += red[w];
+  return s;
 }
 
 // Walk this thread's SPAN end positions of the staged tile and hand every canonical
@@ -321,11 +383,6 @@ __global__ void __launch_bounds__(TB_WG) k_build_tiles(const uint64_t *__restric
 // (encoding.rs:374-376 via chunk.rs:28).  Runs before any counting kernel, so an invalid
 // byte aborts the batch with the table untouched.
 // ==========================================================================================
-__device__ __forceinline__ bool byte_is_acgtn(uint32_t c) {
-  // A=0x41 C=0x43 G=0x47 N=0x4E T=0x54 → bits 1,3,7,14,20 of the 0x40..0x5F word
-  return (c >> 5) == 2 && ((0x0010408Au >> (c & 31)) & 1u);
-}
-
 __global__ void __launch_bounds__(WG) k_scan(BatchRef b, DevStats *__restrict__ stats,
                                              unsigned long long *__restrict__ lane_bases) {
   __shared__ uint32_t red[WG / 64];
@@ -403,7 +460,7 @@ __global__ void __launch_bounds__(WG) k_direct(BatchRef b, TableRef tb, DevStats
     uint32_t lane;
     if (!tile_get(b, t, t0, t1, lane)) break;
     __syncthreads();
-    stage_tile(b, t0, lds);
+    stage_tile<false>(b, t0, t1, lds, stats);
     __syncthreads();
     walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) { count_one(tb, kmer, lane, stats, sp, n_new); });
   }
@@ -492,25 +549,39 @@ __global__ void __launch_bounds__(WG) k_histo(TableRef tb, uint64_t slot0, uint6
   __syncthreads();
   const uint64_t hlen = histo_max + 2;
   unsigned long long n_unique = 0, n_hashed = 0, n_lane = 0, sat = 0;
-  for (uint64_t s = slot0 + (uint64_t)blockIdx.x * WG + threadIdx.x; s < slot1;
-       s += (uint64_t)gridDim.x * WG) {
-    if (tb.keys[s] == EMPTY) continue;
-    n_unique++;
-    uint32_t cum = 0;
+  // four consecutive slots per thread per step: keys as 2×16 B, each lane's counts as 16 B,
+  // all loads issued before any is consumed (slot0/slot1 are multiples of PAGE_SLOTS)
+  for (uint64_t s = slot0 + ((uint64_t)blockIdx.x * WG + threadIdx.x) * 4; s < slot1;
+       s += (uint64_t)gridDim.x * WG * 4) {
+    ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(tb.keys + s);
+    ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(tb.keys + s + 2);
+    uint32_t cum[4] = {0, 0, 0, 0};
+    const bool occ[4] = {ka.x != EMPTY, ka.y != EMPTY, kb.x != EMPTY, kb.y != EMPTY};
+    if (!(occ[0] | occ[1] | occ[2] | occ[3])) continue;
     for (uint32_t l = 0; l < tb.n_lanes; ++l) {
-      uint32_t v = tb.vals[(uint64_t)l * tb.cap + s];
-      n_lane += v;
-      cum = sat_add_u32(cum, v);
-      if (l < n_cols && cum > 0) {
-        uint64_t bin = cum <= histo_max ? cum : histo_max + 1;
-        if (bin < lds_bins)
-          atomicAdd(&lh[l * lds_bins + (uint32_t)bin], 1u);
-        else
-          atomicAdd(&hist[(uint64_t)l * hlen + bin], 1ull);
+      uint4 v4 = *reinterpret_cast<const uint4 *>(tb.vals + (uint64_t)l * tb.cap + s);
+      const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!occ[q]) continue;
+        n_lane += v[q];
+        cum[q] = sat_add_u32(cum[q], v[q]);
+        if (l < n_cols && cum[q] > 0) {
+          uint64_t bin = cum[q] <= histo_max ? cum[q] : histo_max + 1;
+          if (bin < lds_bins)
+            atomicAdd(&lh[l * lds_bins + (uint32_t)bin], 1u);
+          else
+            atomicAdd(&hist[(uint64_t)l * hlen + bin], 1ull);
+        }
       }
     }
-    n_hashed += cum;
-    sat |= (cum == 0xFFFFFFFFu);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!occ[q]) continue;
+      n_unique++;
+      n_hashed += cum[q];
+      sat |= (cum[q] == 0xFFFFFFFFu);
+    }
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < n_l; i += WG) {
@@ -714,46 +785,69 @@ constexpr uint32_t PAGE_FILL_CAP = PAGE_SLOTS - PAGE_SLOTS / 8;  // new keys spi
 __global__ void __launch_bounds__(WG) k_part_count(BatchRef b, uint32_t log_pages,
                                                    uint32_t lane_filter,
                                                    uint32_t *__restrict__ counts,
-                                                   const DevStats *__restrict__ stats) {
+                                                   DevStats *__restrict__ stats,
+                                                   unsigned long long *__restrict__ lane_bases) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+  __shared__ uint32_t red[WG / 64];
   const uint32_t P = 1u << log_pages;
   uint8_t *lds = reinterpret_cast<uint8_t *>(sh);   // TILE_LDS bytes (multiple of 16)
   uint32_t *cnt = sh + TILE_LDS / 4;                // P counters
   for (uint32_t i = threadIdx.x; i < P; i += WG) cnt[i] = 0;
   __syncthreads();
-  if (stats->bad == ~0ull) {
-    for (uint64_t t = blockIdx.x;; t += gridDim.x) {
-      uint64_t t0, t1;
-      uint32_t lane;
-      if (!tile_get(b, t, t0, t1, lane)) break;
-      if (lane != lane_filter) continue;
-      __syncthreads();
-      stage_tile(b, t0, lds);
-      __syncthreads();
-      walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) {
-        atomicAdd(&cnt[(uint32_t)page_of(hash64(kmer), log_pages)], 1u);
-      });
-    }
+  // This pass also is the validation pass (encoding.rs:353-356) and the non-N base count
+  // (chunk.rs:28): both ride on the staging loads.  An invalid byte found by ANY workgroup
+  // stops k_part_scatter / k_pages (they test stats->bad), so the table stays untouched.
+  uint32_t n_non_n = 0;
+  for (uint64_t t = blockIdx.x;; t += gridDim.x) {
+    uint64_t t0, t1;
+    uint32_t lane;
+    if (!tile_get(b, t, t0, t1, lane)) break;
+    if (lane != lane_filter) continue;
+    __syncthreads();
+    n_non_n += stage_tile<true>(b, t0, t1, lds, stats);
+    __syncthreads();
+    walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) {
+      atomicAdd(&cnt[(uint32_t)page_of(hash64(kmer), log_pages)], 1u);
+    });
   }
   __syncthreads();
+  uint32_t tot = wg_sum(n_non_n, red);
+  if (threadIdx.x == 0 && tot) atomicAdd(&lane_bases[lane_filter], (unsigned long long)tot);
   uint32_t *out = counts + (uint64_t)blockIdx.x * P;
   for (uint32_t i = threadIdx.x; i < P; i += WG) out[i] = cnt[i];
 }
 
-// exclusive scan over workgroups, per page: counts[g][p] → offset of workgroup g inside page
-// p's run; totals[p] = run length
-__global__ void __launch_bounds__(WG) k_part_scan1(uint32_t *__restrict__ counts, uint32_t G,
-                                                   uint32_t P,
-                                                   unsigned long long *__restrict__ totals) {
-  uint32_t p = blockIdx.x * WG + threadIdx.x;
+// exclusive scan over workgroups, per page: offs[g][p] = Σ_{g'<g} counts[g'][p] (the start
+// of workgroup g inside page p's run); totals[p] = run length.  One workgroup per 64 pages;
+// its 16 waves each own a 1/16 slice of the workgroups: slice sums, then slice-local scans.
+constexpr int SC_WAVES = 16;
+__global__ void __launch_bounds__(64 * SC_WAVES) k_part_scan1(const uint32_t *__restrict__ counts,
+                                                              uint32_t *__restrict__ offs,
+                                                              uint32_t G, uint32_t P,
+                                                              unsigned long long *__restrict__ totals) {
+  __shared__ uint32_t part[SC_WAVES][64];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t p = blockIdx.x * 64 + lane;
+  const uint32_t per = (G + SC_WAVES - 1) / SC_WAVES;
+  const uint32_t g0 = w * per, g1 = g0 + per < G ? g0 + per : G;
+  uint32_t s = 0;
+  if (p < P)
+    for (uint32_t g = g0; g < g1; ++g) s += counts[(uint64_t)g * P + p];
+  part[w][lane] = s;
+  __syncthreads();
   if (p >= P) return;
-  uint32_t run = 0;
-  for (uint32_t g = 0; g < G; ++g) {
+  uint32_t run = 0, tot = 0;
+  for (uint32_t i = 0; i < SC_WAVES; ++i) {
+    uint32_t v = part[i][lane];
+    if (i < w) run += v;
+    tot += v;
+  }
+  for (uint32_t g = g0; g < g1; ++g) {
     uint32_t c = counts[(uint64_t)g * P + p];
-    counts[(uint64_t)g * P + p] = run;
+    offs[(uint64_t)g * P + p] = run;
     run += c;
   }
-  totals[p] = run;
+  if (w == 0) totals[p] = tot;
 }
 
 // exclusive scan over pages: part_base[p] = Σ_{q<p} totals[q]; part_base[P] = total
@@ -802,7 +896,7 @@ __global__ void __launch_bounds__(WG) k_part_scatter(BatchRef b, uint32_t log_pa
     if (!tile_get(b, t, t0, t1, lane)) break;
     if (lane != lane_filter) continue;
     __syncthreads();
-    stage_tile(b, t0, lds);
+    stage_tile<false>(b, t0, t1, lds, nullptr);
     __syncthreads();
     walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) {
       uint32_t pos = atomicAdd(&cur[(uint32_t)page_of(hash64(kmer), log_pages)], 1u);

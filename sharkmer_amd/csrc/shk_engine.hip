@@ -309,13 +309,6 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   b.lane0 = lane_fixed >= 0 ? (uint32_t)lane_fixed : (striped ? (uint32_t)((g0 / 1000) % NL) : 0u);
   b.k = (int)c->cfg.k;
 
-  // 2. validate + count bases (encoding.rs:353-356, 374-376)
-  {
-    ScopedTimer t(c, SHK_K_SCAN);
-    hipLaunchKernelGGL(k_scan, dim3(grid_for(n_tiles_ub, 1, 4096)), dim3(WG), 0, c->stream, b,
-                       c->d_stats, c->d_lane_bases);
-  }
-
   // 3. count, in sub-ranges of tiles
   const uint64_t tiles_per_sub = MAX_SUB_BASES / TILE_T;
   for (uint64_t ta = 0; ta < n_tiles_ub; ta += tiles_per_sub) {
@@ -350,14 +343,16 @@ static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
 static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp) {
   const uint32_t lp = c->tb.log_pages;
   const uint32_t P = 1u << lp;
-  const uint32_t G = grid_for(b.tile_count, 1, 1024);
+  static const uint32_t g_cap = getenv("SHK_PART_G") ? (uint32_t)atoi(getenv("SHK_PART_G")) : 1024u;
+  const uint32_t G = grid_for(b.tile_count, 1, g_cap);
   const size_t counts_b = (size_t)G * P * 4, totals_b = (size_t)P * 8, base_b = (size_t)(P + 1) * 8;
-  HIPC(c, c->part_meta.ensure(counts_b + totals_b + base_b + 64));
+  HIPC(c, c->part_meta.ensure(2 * counts_b + totals_b + base_b + 64));
   HIPC(c, c->part.ensure(sub_kmers_ub * 8));
   uint8_t *m = (uint8_t *)c->part_meta.p;
   uint32_t *counts = (uint32_t *)m;
-  unsigned long long *totals = (unsigned long long *)(m + counts_b);
-  unsigned long long *part_base = (unsigned long long *)(m + counts_b + totals_b);
+  uint32_t *offs = (uint32_t *)(m + counts_b);
+  unsigned long long *totals = (unsigned long long *)(m + 2 * counts_b);
+  unsigned long long *part_base = (unsigned long long *)(m + 2 * counts_b + totals_b);
   uint64_t *part_buf = (uint64_t *)c->part.p;
   const size_t lds = TILE_LDS + (size_t)P * 4;
   const bool multi = b.tiles != nullptr;
@@ -366,13 +361,13 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     {
       ScopedTimer t(c, SHK_K_SCATTER);
       hipLaunchKernelGGL(k_part_count, dim3(G), dim3(WG), lds, c->stream, b, lp, lane, counts,
-                         (const DevStats *)c->d_stats);
-      hipLaunchKernelGGL(k_part_scan1, dim3((P + WG - 1) / WG), dim3(WG), 0, c->stream, counts, G, P,
-                         totals);
+                         c->d_stats, c->d_lane_bases);
+      hipLaunchKernelGGL(k_part_scan1, dim3((P + 63) / 64), dim3(64 * SC_WAVES), 0, c->stream,
+                         (const uint32_t *)counts, offs, G, P, totals);
       hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, c->stream,
                          (const unsigned long long *)totals, P, part_base);
       hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(WG), lds, c->stream, b, lp, lane,
-                         (const uint32_t *)counts, (const unsigned long long *)part_base, part_buf,
+                         (const uint32_t *)offs, (const unsigned long long *)part_base, part_buf,
                          (const DevStats *)c->d_stats);
     }
     {
@@ -395,6 +390,11 @@ static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub) {
     int rc = paged_count(c, b, sub_kmers_ub, sp);
     if (rc != SHK_OK) return rc;
   } else {
+    {  // validate + count bases first (encoding.rs:353-356, 374-376); k_direct tests stats->bad
+      ScopedTimer t(c, SHK_K_SCAN);
+      hipLaunchKernelGGL(k_scan, dim3(grid_for(b.tile_count, 1, 4096)), dim3(WG), 0, c->stream, b,
+                         c->d_stats, c->d_lane_bases);
+    }
     ScopedTimer t(c, SHK_K_DIRECT);
     hipLaunchKernelGGL(k_direct, dim3(grid_for(b.tile_count, 1, 256 * 8)), dim3(WG), 0, c->stream, b,
                        c->tb, c->d_stats, sp);
@@ -648,7 +648,7 @@ int shk_finalize(shk_ctx *c) {
   if (n_cols && (uint64_t)lds_bins * n_cols * 4 > 65536) lds_bins = 65536 / 4 / n_cols;
   {
     ScopedTimer t(c, SHK_K_HISTO);
-    hipLaunchKernelGGL(k_histo, dim3(grid_for(s1 - s0, WG * 8, 2048)), dim3(WG),
+    hipLaunchKernelGGL(k_histo, dim3(grid_for(s1 - s0, WG * 16, 512)), dim3(WG),
                        (size_t)lds_bins * n_cols * 4, c->stream, c->tb, s0, s1, c->cfg.histo_max,
                        n_cols, lds_bins, c->d_hist, c->d_tot);
   }
