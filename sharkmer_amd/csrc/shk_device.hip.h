@@ -23,9 +23,10 @@ constexpr int PAGE_LOG = 12;
 constexpr uint32_t PAGE_SLOTS = 1u << PAGE_LOG;     // 4096 slots: 32 KiB keys + 16 KiB vals in LDS
 constexpr int WG = 256;                             // 4 waves
 constexpr int TILE_T = 16384;                       // k-mer end positions per tile
-constexpr int SPAN = TILE_T / WG;                   // 64 end positions per thread
 constexpr int HALO = 32;                            // ≥ k-1 bases before the tile (k ≤ 31)
-constexpr int TILE_LDS = TILE_T + HALO;
+constexpr int TILE_LDS = TILE_T + HALO;               // code bytes of one staged tile
+constexpr int TILE_GROUPS = TILE_LDS / 16;            // 16-base groups
+constexpr int STAGE_BYTES = TILE_LDS + 4 * TILE_GROUPS;  // + one (N|start) mask word per group
 
 struct TileDesc {
   uint64_t begin;  // first k-mer END position owned by the tile
@@ -70,19 +71,30 @@ struct SpillRef {
   uint64_t cap;
 };
 
-// ---- hashing: 2-round multiply/xorshift; page from the top bits, in-page slot from
-// the next 12.  Results never depend on it — only speed does.
-__device__ __forceinline__ uint64_t hash64(uint64_t key) {
-  uint64_t h = key * 0x9E3779B97F4A7C15ull;
-  h ^= h >> 32;
-  h *= 0xD6E8FEB86659FD93ull;
+// ---- hashing.  Results never depend on it — only speed does, and on gfx950
+// 32-bit integer multiplies issue at quarter rate while 24-bit ones (v_mad_u32_u24) are full
+// rate.  So: multilinear hash of the key's three 24-bit chunks (full rate) + one xorshift-
+// multiply finaliser.  Page = top log_pages bits, in-page home slot = the next 12.
+// tools/hash_eval.py: page occupancy and slot collisions match a Poisson process on random,
+// AT-rich, tandem-repeat and sequential keys (without the finaliser sequential keys collide).
+constexpr uint32_t MAX_LOG_PAGES = 20;  // log_pages + PAGE_LOG ≤ 32 hash bits
+__device__ __forceinline__ uint32_t hash64(uint64_t key) {
+  const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+  const uint32_t c0 = lo & 0xFFFFFFu;
+  const uint32_t c1 = __builtin_amdgcn_alignbit(hi, lo, 24) & 0xFFFFFFu;
+  const uint32_t c2 = hi >> 16;
+  uint32_t h = __umul24(c0, 0x9E3779B1u & 0xFFFFFFu) + __umul24(c1, 0x85EBCA77u & 0xFFFFFFu) +
+               __umul24(c2, 0xC2B2AE3Du & 0xFFFFFFu);
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
   return h;
 }
-__device__ __forceinline__ uint64_t page_of(uint64_t h, uint32_t log_pages) {
-  return log_pages ? (h >> (64 - log_pages)) : 0ull;
+__device__ __forceinline__ uint64_t page_of(uint32_t h, uint32_t log_pages) {
+  return log_pages ? (uint64_t)(h >> (32 - log_pages)) : 0ull;
 }
-__device__ __forceinline__ uint32_t slot_of(uint64_t h, uint32_t log_pages) {
-  return (uint32_t)(h >> (64 - PAGE_LOG - log_pages)) & (PAGE_SLOTS - 1);
+__device__ __forceinline__ uint32_t slot_of(uint32_t h, uint32_t log_pages) {
+  return (h >> (32 - PAGE_LOG - log_pages)) & (PAGE_SLOTS - 1);
 }
 
 __device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
@@ -110,13 +122,14 @@ __device__ __forceinline__ bool tile_get(const BatchRef &b, uint64_t t, uint64_t
   return true;
 }
 
-// ASCII → code for 4 bytes at once: A,C,G,T → 0..3 via ((c>>1)^(c>>2))&3; 'N' → 4.
-// (Validity is established by k_scan before any counting kernel runs.)
-__device__ __forceinline__ uint32_t codes4(uint32_t w) {
+// ASCII → 2-bit base for 4 bytes at once: A,C,G,T → 0..3 via ((c>>1)^(c>>2))&3 ('N' → 0);
+// *nmask4 gets one bit per byte that is 'N'.
+__device__ __forceinline__ uint32_t codes4(uint32_t w, uint32_t *nmask4) {
   uint32_t c = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
   uint32_t t = w ^ 0x4E4E4E4Eu;  // zero byte ⇔ 'N'
-  uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 per zero byte
-  return c | (z >> 5);  // 'N' (0x4E) already maps to base bits 00
+  uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 per 'N' byte
+  *nmask4 = (z * 0x00204081u) >> 28;  // gather the four byte-MSBs, byte order kept
+  return c;
 }
 
 // Is byte c one of A,C,G,T,N?  (A=0x41 C=0x43 G=0x47 N=0x4E T=0x54 → bits 1,3,7,14,20 of
@@ -131,19 +144,25 @@ __device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t x4) {
 }
 
 // Stage positions [t0-HALO, t0+TILE_T) of the batch into LDS as one code byte per base:
-// bits 0-1 base, bit 2 = N / outside the batch (resets the window), bit 3 = first base
-// of a read (resets the window before the base is taken).  encoding.rs:341-352.
+// bits 0-1 = base, bit 2 = "a valid k-mer ENDS here", i.e. the k bases up to and including
+// this one lie in one read and none is N (encoding.rs:346-352,363: n_valid ≥ k).  The bit is
+// computed bit-parallel for 16 positions at a time from per-group masks of N positions and
+// read-start positions (smeared over k resp. k-1 positions), so the walks below carry no
+// per-base validity state at all.
 // VALIDATE: additionally check every byte of [t0,t1) against ACGTN (encoding.rs:353-356;
 // the first offender in input order is reported through stats->bad) and return this
 // thread's count of non-N bytes in [t0,t1) (count_valid_bases, encoding.rs:374-376).
-template <bool VALIDATE>
+// Contains one __syncthreads(); the caller adds another before reading the codes.
+template <bool VALIDATE, int NT = WG>
 __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, uint64_t t1,
                                                uint8_t *lds, DevStats *stats) {
+  uint32_t *gmask = reinterpret_cast<uint32_t *>(lds + TILE_LDS);  // nmask16 | smask16<<16
   const int64_t p0 = (int64_t)t0 - HALO;
   uint32_t n_non_n = 0;
-  for (int m = threadIdx.x; m < TILE_LDS / 16; m += WG) {
+  for (int m = threadIdx.x; m < TILE_GROUPS; m += NT) {
     int64_t p = p0 + (int64_t)m * 16;
     uint32_t w[4];
+    uint32_t nmask = 0;
     if (p >= 0 && (uint64_t)p + 16 <= b.n_bases) {
       __builtin_memcpy(w, b.bases + p, 16);  // unaligned 16-B global load (one dwordx4)
       if (VALIDATE && (uint64_t)p >= t0 && (uint64_t)p < t1) {
@@ -175,25 +194,29 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
           }
         }
       }
-      w[0] = codes4(w[0]);
-      w[1] = codes4(w[1]);
-      w[2] = codes4(w[2]);
-      w[3] = codes4(w[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t n4;
+        w[q] = codes4(w[q], &n4);
+        nmask |= n4 << (4 * q);
+      }
     } else {
       for (int q = 0; q < 4; ++q) {
         uint32_t ww = 0;
         for (int r = 0; r < 4; ++r) {
           int64_t pp = p + q * 4 + r;
-          uint32_t c = 4;
+          uint32_t c = 0, isn = 1;  // outside the batch: behaves like N
           if (pp >= 0 && (uint64_t)pp < b.n_bases) {
             uint32_t a = b.bases[pp];
-            c = a == 'N' ? 4u : (((a >> 1) ^ (a >> 2)) & 3u);
+            isn = a == 'N';
+            c = isn ? 0u : (((a >> 1) ^ (a >> 2)) & 3u);
             if (VALIDATE && (uint64_t)pp >= t0 && (uint64_t)pp < t1) {
               if (!byte_is_acgtn(a)) atomicMin(&stats->bad, ((unsigned long long)pp << 8) | a);
               n_non_n += (a != 'N');
             }
           }
           ww |= c << (8 * r);
+          nmask |= isn << (q * 4 + r);
         }
         w[q] = ww;
       }
@@ -209,59 +232,106 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
       uint32_t lo = b.startbits[0];
       f = (lo << (uint32_t)(-p)) & 0xFFFFu;
     }
-    if (f) {
-      for (int q = 0; q < 4; ++q) {
-        uint32_t fq = (f >> (4 * q)) & 0xF;
-        // spread 4 flag bits into bit 3 of 4 bytes
-        uint32_t s = ((fq & 1) << 3) | ((fq & 2) << 10) | ((fq & 4) << 17) | ((fq & 8) << 24);
-        w[q] |= s;
-      }
+    *reinterpret_cast<uint4 *>(lds + m * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    gmask[m] = nmask | (f << 16);
+  }
+  __syncthreads();
+  // "k-mer ends here" bits: position j is bad if an N lies in [j-k+1, j] or a read starts in
+  // [j-k+2, j].  48 mask bits (this group and the two before it) are smeared upwards.
+  const int k = b.k;
+  for (int m = 2 + threadIdx.x; m < TILE_GROUPS; m += NT) {
+    const uint32_t g0 = gmask[m - 2], g1 = gmask[m - 1], g2 = gmask[m];
+    uint64_t N = (uint64_t)(g0 & 0xFFFFu) | ((uint64_t)(g1 & 0xFFFFu) << 16) |
+                 ((uint64_t)(g2 & 0xFFFFu) << 32);
+    uint64_t S = (uint64_t)(g0 >> 16) | ((uint64_t)(g1 >> 16) << 16) | ((uint64_t)(g2 >> 16) << 32);
+    int s = 1;
+    while (2 * s <= k) {
+      N |= N << s;
+      s *= 2;
     }
-    uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
-    *reinterpret_cast<uint4 *>(lds + m * 16) = v;
+    if (k > s) N |= N << (k - s);
+    if (k >= 2) {
+      s = 1;
+      while (2 * s <= k - 1) {
+        S |= S << s;
+        s *= 2;
+      }
+      if (k - 1 > s) S |= S << (k - 1 - s);
+    } else {
+      S = 0;
+    }
+    uint32_t ok = ~(uint32_t)((N | S) >> 32) & 0xFFFFu;  // m ≥ 2: ≥ 32 ≥ k-1 bases of history
+    if (ok) {
+      uint4 c4 = *reinterpret_cast<const uint4 *>(lds + m * 16);
+      uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t fq = (ok >> (4 * q)) & 0xF;
+        cw[q] |= ((fq & 1) << 2) | ((fq & 2) << 9) | ((fq & 4) << 16) | ((fq & 8) << 23);
+      }
+      *reinterpret_cast<uint4 *>(lds + m * 16) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+    }
   }
   return n_non_n;
 }
 
 // workgroup sum of a per-thread u32, result valid in thread 0 (red: WG/64 words of LDS)
+template <int NT = WG>
 __device__ __forceinline__ uint32_t wg_sum(uint32_t v, uint32_t *red) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   uint32_t s = 0;
   if (threadIdx.x == 0)
-    for (int w = 0; w < WG / 64; ++w) s += red[w];
+    for (int w = 0; w < NT / 64; ++w) s += red[w];
   return s;
 }
 
-// Walk this thread's SPAN end positions of the staged tile and hand every canonical
-// k-mer to emit(kmer).  Rolling forward/reverse frames exactly as encoding.rs:359-367.
-template <class Emit>
+// Rolling frames of encoding.rs:359-367, kept as 32-bit halves so that every step is a
+// handful of full-rate 32-bit ops: the forward frame right-aligned and masked to 2k bits, the
+// reverse-complement frame LEFT-aligned in 64 bits (its new base always enters at bit 62).
+struct Roll {
+  uint32_t f_lo, f_hi, r_lo, r_hi;
+};
+__device__ __forceinline__ void roll_step(Roll &x, uint32_t base, uint32_t mask_lo, uint32_t mask_hi) {
+  x.f_hi = __builtin_amdgcn_alignbit(x.f_hi, x.f_lo, 30) & mask_hi;
+  x.f_lo = ((x.f_lo << 2) | base) & mask_lo;
+  x.r_lo = __builtin_amdgcn_alignbit(x.r_hi, x.r_lo, 2);
+  x.r_hi = (x.r_hi >> 2) | ((base ^ 3u) << 30);
+}
+__device__ __forceinline__ uint64_t roll_canonical(const Roll &x, int k) {
+  uint64_t fwd = ((uint64_t)x.f_hi << 32) | x.f_lo;
+  uint64_t rev = (((uint64_t)x.r_hi << 32) | x.r_lo) >> (64 - 2 * k);
+  return fwd < rev ? fwd : rev;
+}
+
+// Walk this thread's SPAN end positions of the staged tile and hand every canonical k-mer to
+// emit(kmer).  The walk starts k-1 bases early (rounded down to a ds_read_b64 boundary) to
+// warm the frames up; bit 2 of the code byte says where a k-mer may be emitted.
+template <int NT = WG, class Emit>
 __device__ __forceinline__ void walk_tile(const uint8_t *lds, uint64_t t0, uint64_t t1, int k,
                                           Emit &&emit) {
+  constexpr int SPAN = TILE_T / NT;
   const uint64_t mask = (1ull << (2 * k)) - 1;
-  const int rsh = 2 * (k - 1);
+  const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
   const int e0 = threadIdx.x * SPAN;  // first end position (tile-relative)
   const int n_end = (int)(t1 - t0);   // valid end positions in this tile
   if (e0 >= n_end) return;
-  // start k-1 bases early, rounded down to a multiple of 8 for ds_read_b64
-  int j0 = (HALO + e0 - (k - 1)) & ~7;
-  const int jend = HALO + (e0 + SPAN < n_end ? e0 + SPAN : n_end);
   const int jemit = HALO + e0;
-  uint64_t fwd = 0, rev = 0;
-  int n_valid = 0;
-  for (int j = j0; j < jend; j += 8) {
+  const int jend = HALO + (e0 + SPAN < n_end ? e0 + SPAN : n_end);
+  Roll x{0, 0, 0, 0};
+  for (int j = (jemit - (k - 1)) & ~7; j < jemit; j += 8) {  // warm-up: no emission
+    uint64_t w = *reinterpret_cast<const uint64_t *>(lds + j);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) roll_step(x, (uint32_t)(w >> (8 * r)) & 3u, mask_lo, mask_hi);
+  }
+  for (int j = jemit; j < jend; j += 8) {
     uint64_t w = *reinterpret_cast<const uint64_t *>(lds + j);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       uint32_t c = (uint32_t)(w >> (8 * r)) & 0xFF;
-      int jj = j + r;
-      if (c & 8) n_valid = 0;
-      uint64_t bb = c & 3;
-      fwd = ((fwd << 2) | bb) & mask;
-      rev = (rev >> 2) | ((3 - bb) << rsh);
-      n_valid = (c & 4) ? 0 : n_valid + 1;
-      if (n_valid >= k && jj >= jemit && jj < jend) emit(fwd < rev ? fwd : rev);
+      roll_step(x, c & 3u, mask_lo, mask_hi);
+      if ((c & 4u) && j + r < jend) emit(roll_canonical(x, k));
     }
   }
 }
@@ -431,7 +501,7 @@ __global__ void __launch_bounds__(WG) k_scan(BatchRef b, DevStats *__restrict__ 
 __device__ __forceinline__ void count_one(const TableRef &tb, uint64_t key, uint32_t lane,
                                           DevStats *stats, const SpillRef &sp,
                                           uint32_t &n_new) {
-  uint64_t h = hash64(key);
+  uint32_t h = hash64(key);
   uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
   bool inserted = false;
   int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
@@ -452,7 +522,7 @@ __device__ __forceinline__ void count_one(const TableRef &tb, uint64_t key, uint
 
 __global__ void __launch_bounds__(WG) k_direct(BatchRef b, TableRef tb, DevStats *__restrict__ stats,
                                                SpillRef sp) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[TILE_LDS];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE_BYTES];
   uint32_t n_new = 0;
   if (stats->bad != ~0ull) return;  // k_scan found an invalid byte: leave the table untouched
   for (uint64_t t = blockIdx.x;; t += gridDim.x) {
@@ -483,7 +553,7 @@ __global__ void __launch_bounds__(WG) k_insert(const uint64_t *__restrict__ kmer
     uint64_t key = kmers[i];
     uint32_t lane = lanes ? lanes[i] : lane0;
     uint32_t cnt = counts ? counts[i] : 1u;
-    uint64_t h = hash64(key);
+    uint32_t h = hash64(key);
     uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
     bool inserted = false;
     int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
@@ -512,7 +582,7 @@ __global__ void __launch_bounds__(WG) k_grow(TableRef oldt, TableRef newt) {
        i += (uint64_t)gridDim.x * WG) {
     uint64_t key = oldt.keys[i];
     if (key == EMPTY) continue;
-    uint64_t h = hash64(key);
+    uint32_t h = hash64(key);
     uint64_t base = page_of(h, newt.log_pages) << PAGE_LOG;
     bool inserted = false;
     int64_t s = find_or_insert(newt.keys, base, slot_of(h, newt.log_pages), key, inserted);
@@ -619,7 +689,7 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t kmer, int k) {
 }
 
 __device__ __forceinline__ uint32_t merged_count(const TableRef &tb, uint64_t key) {
-  uint64_t h = hash64(key);
+  uint32_t h = hash64(key);
   uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
   int64_t s = find_slot(tb.keys, base, slot_of(h, tb.log_pages), key);
   if (s < 0) return 0;
@@ -672,7 +742,7 @@ __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t slot0, uint6
        i += (uint64_t)gridDim.x * WG) {
     uint64_t key = pkeys[i];
     if (key == EMPTY) continue;
-    uint64_t h = hash64(key);
+    uint32_t h = hash64(key);
     uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
     bool inserted = false;
     int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
@@ -782,17 +852,18 @@ constexpr int MAX_PARTS = 8192;   // pages addressable by the LDS page histogram
 constexpr int PG_WG = 512;        // k_pages workgroup: 8 waves, 3 workgroups per CU by LDS
 constexpr uint32_t PAGE_FILL_CAP = PAGE_SLOTS - PAGE_SLOTS / 8;  // new keys spill beyond this
 
-__global__ void __launch_bounds__(WG) k_part_count(BatchRef b, uint32_t log_pages,
+template <int NT>
+__global__ void __launch_bounds__(NT) k_part_count(BatchRef b, uint32_t log_pages /* = log2(#partitions) */,
                                                    uint32_t lane_filter,
                                                    uint32_t *__restrict__ counts,
                                                    DevStats *__restrict__ stats,
                                                    unsigned long long *__restrict__ lane_bases) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
-  __shared__ uint32_t red[WG / 64];
+  __shared__ uint32_t red[NT / 64];
   const uint32_t P = 1u << log_pages;
   uint8_t *lds = reinterpret_cast<uint8_t *>(sh);   // TILE_LDS bytes (multiple of 16)
-  uint32_t *cnt = sh + TILE_LDS / 4;                // P counters
-  for (uint32_t i = threadIdx.x; i < P; i += WG) cnt[i] = 0;
+  uint32_t *cnt = sh + STAGE_BYTES / 4;             // P counters
+  for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
   __syncthreads();
   // This pass also is the validation pass (encoding.rs:353-356) and the non-N base count
   // (chunk.rs:28): both ride on the staging loads.  An invalid byte found by ANY workgroup
@@ -804,17 +875,17 @@ __global__ void __launch_bounds__(WG) k_part_count(BatchRef b, uint32_t log_page
     if (!tile_get(b, t, t0, t1, lane)) break;
     if (lane != lane_filter) continue;
     __syncthreads();
-    n_non_n += stage_tile<true>(b, t0, t1, lds, stats);
+    n_non_n += stage_tile<true, NT>(b, t0, t1, lds, stats);
     __syncthreads();
-    walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) {
+    walk_tile<NT>(lds, t0, t1, b.k, [&](uint64_t kmer) {
       atomicAdd(&cnt[(uint32_t)page_of(hash64(kmer), log_pages)], 1u);
     });
   }
   __syncthreads();
-  uint32_t tot = wg_sum(n_non_n, red);
+  uint32_t tot = wg_sum<NT>(n_non_n, red);
   if (threadIdx.x == 0 && tot) atomicAdd(&lane_bases[lane_filter], (unsigned long long)tot);
   uint32_t *out = counts + (uint64_t)blockIdx.x * P;
-  for (uint32_t i = threadIdx.x; i < P; i += WG) out[i] = cnt[i];
+  for (uint32_t i = threadIdx.x; i < P; i += NT) out[i] = cnt[i];
 }
 
 // exclusive scan over workgroups, per page: offs[g][p] = Σ_{g'<g} counts[g'][p] (the start
@@ -886,7 +957,7 @@ __global__ void __launch_bounds__(WG) k_part_scatter(BatchRef b, uint32_t log_pa
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   const uint32_t P = 1u << log_pages;
   uint8_t *lds = reinterpret_cast<uint8_t *>(sh);
-  uint32_t *cur = sh + TILE_LDS / 4;
+  uint32_t *cur = sh + STAGE_BYTES / 4;
   if (stats->bad != ~0ull) return;
   const uint32_t *mine = counts + (uint64_t)blockIdx.x * P;
   for (uint32_t i = threadIdx.x; i < P; i += WG) cur[i] = (uint32_t)part_base[i] + mine[i];
@@ -905,11 +976,225 @@ __global__ void __launch_bounds__(WG) k_part_scatter(BatchRef b, uint32_t log_pa
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_part_scatter_sorted: the same job as k_part_scatter, but every tile is counting-sorted by
+// partition in LDS first, so that a partition's k-mers leave the CU as runs of consecutive
+// 8-B records (coalesced 64..512-B requests) instead of one 8-B request per k-mer.
+// Measured on MI355X (tools/wbench.hip): 8-B scattered stores 0.6 TB/s, 64-B chunks 3.2 TB/s,
+// ≥128-B chunks 4.9 TB/s.
+//   walk    : rolling extraction; per k-mer a returning LDS add gives its rank inside its
+//             partition; (partition, rank) stays in a register
+//   scan    : exclusive scan of the tile's partition counts
+//   place   : sorted[tstart[p] + rank] = end position (u16), aliasing the dead code bytes
+//   write   : entry i → k-mer re-read from the 2-bit packed copy of the tile → its place in
+//             the partition's output run
+// ------------------------------------------------------------------------------------------
+#ifndef SORTED_WAVES_PER_SIMD
+#define SORTED_WAVES_PER_SIMD 4
+#endif
+constexpr int PACK_WORDS = TILE_LDS / 16 + 2;  // 16 bases per u32, MSB first, + 2 pad words
+constexpr int SORT_REGION = 2 * TILE_T > STAGE_BYTES ? 2 * TILE_T : STAGE_BYTES;
+
+__device__ __forceinline__ uint32_t pack4(uint32_t w) {  // 4 code bytes → 8 bits, first base on top
+  return ((w & 3u) << 6) | (((w >> 8) & 3u) << 4) | (((w >> 16) & 3u) << 2) | ((w >> 24) & 3u);
+}
+
+// canonical k-mer whose LAST base sits at LDS position j (halo included) of the packed tile
+__device__ __forceinline__ uint64_t kmer_at(const uint32_t *packed, int j, int k) {
+  const int s = 2 * (j - k + 1);
+  const int wi = s >> 5, off = s & 31;
+  uint64_t x = ((uint64_t)packed[wi] << 32) | packed[wi + 1];
+  if (off) x = (x << off) | ((uint64_t)packed[wi + 2] >> (32 - off));
+  uint64_t fwd = x >> (64 - 2 * k);
+  uint64_t rev = revcomp(fwd, k);
+  return fwd < rev ? fwd : rev;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sorted(
+    BatchRef b, uint32_t log_parts, uint32_t lane_filter, const uint32_t *__restrict__ offs,
+    const unsigned long long *__restrict__ part_base, uint64_t *__restrict__ part_buf,
+    const DevStats *__restrict__ stats, unsigned long long *__restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+  __shared__ uint32_t wsum[NT / 64];
+  constexpr int SPAN = TILE_T / NT;
+  const uint32_t P = 1u << log_parts;
+  uint8_t *codes = reinterpret_cast<uint8_t *>(sh);                 // SORT_REGION bytes
+  uint16_t *sorted = reinterpret_cast<uint16_t *>(sh);              // aliases codes
+  uint32_t *packed = sh + SORT_REGION / 4;                          // PACK_WORDS
+  uint32_t *cnt = packed + PACK_WORDS;                              // P
+  uint32_t *tstart = cnt + P;                                       // P
+  uint32_t *gcur = tstart + P;                                      // P
+#ifdef SHK_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#define STAMP(i)                                        \
+  do {                                                  \
+    unsigned long long tn = __builtin_readcyclecounter(); \
+    ph[i] += tn - tprev;                                \
+    tprev = tn;                                         \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+  if (stats->bad != ~0ull) return;
+  const uint32_t *mine = offs + (uint64_t)blockIdx.x * P;
+  for (uint32_t i = threadIdx.x; i < P; i += NT) gcur[i] = (uint32_t)part_base[i] + mine[i];
+  const int k = b.k;
+  const uint64_t mask = (1ull << (2 * k)) - 1;
+  const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
+  const uint32_t per = P / NT ? P / NT : 1;  // partitions per thread in the scan (P ≥ WG or P < WG)
+
+  for (uint64_t t = blockIdx.x;; t += gridDim.x) {
+    uint64_t t0, t1;
+    uint32_t lane;
+    if (!tile_get(b, t, t0, t1, lane)) break;
+    if (lane != lane_filter) continue;
+    __syncthreads();  // previous tile's write phase is done with sorted/cnt/tstart
+#ifdef SHK_PHASE_TIMING
+    tprev = __builtin_readcyclecounter();
+#endif
+    for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
+    stage_tile<false, NT>(b, t0, t1, codes, nullptr);
+    __syncthreads();
+    STAMP(0);
+    // 2-bit packed copy of the staged tile (N / out-of-range bases pack as 0; never read back
+    // for a k-mer that the walk did not emit)
+    for (int m = threadIdx.x; m < PACK_WORDS; m += NT) {
+      uint32_t v = 0;
+      if (m < TILE_LDS / 16) {
+        uint4 c4 = *reinterpret_cast<const uint4 *>(codes + m * 16);
+        v = (pack4(c4.x) << 24) | (pack4(c4.y) << 16) | (pack4(c4.z) << 8) | pack4(c4.w);
+      }
+      packed[m] = v;
+    }
+    STAMP(1);
+    // ---- walk: (partition, rank) per end position, kept in registers -------------------
+    uint32_t pr[SPAN];
+    {
+      const int e0 = threadIdx.x * SPAN;
+      const int n_end = (int)(t1 - t0);
+      const int jemit = HALO + e0;
+      const int jend = HALO + (e0 + SPAN < n_end ? e0 + SPAN : n_end);
+      Roll x{0, 0, 0, 0};
+      if (e0 < n_end) {
+        for (int j = (jemit - (k - 1)) & ~7; j < jemit; j += 8) {  // warm-up: no emission
+          uint64_t w = *reinterpret_cast<const uint64_t *>(codes + j);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) roll_step(x, (uint32_t)(w >> (8 * r)) & 3u, mask_lo, mask_hi);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < SPAN / 8; ++q) {
+        uint64_t w = 0;
+        if (jemit + q * 8 < jend) w = *reinterpret_cast<const uint64_t *>(codes + jemit + q * 8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          uint32_t c = (uint32_t)(w >> (8 * r)) & 0xFF;
+          roll_step(x, c & 3u, mask_lo, mask_hi);
+          uint32_t v = 0xFFFFFFFFu;
+          if ((c & 4u) && jemit + q * 8 + r < jend) {
+            uint32_t pc = (uint32_t)page_of(hash64(roll_canonical(x, k)), log_parts);
+            v = (pc << 16) | atomicAdd(&cnt[pc], 1u);
+          }
+          pr[q * 8 + r] = v;
+        }
+      }
+    }
+    __syncthreads();
+    STAMP(2);
+    // ---- exclusive scan of cnt → tstart ---------------------------------------------------
+    {
+      uint32_t lo = threadIdx.x * per, s = 0;
+      if (lo < P)
+        for (uint32_t i = 0; i < per; ++i) s += cnt[lo + i];
+      uint32_t inc = s;
+      for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) inc += o;
+      }
+      if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+      __syncthreads();
+      uint32_t woff = 0;
+      for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+      uint32_t run = woff + inc - s;
+      if (lo < P)
+        for (uint32_t i = 0; i < per; ++i) {
+          tstart[lo + i] = run;
+          run += cnt[lo + i];
+        }
+    }
+    __syncthreads();  // codes are dead from here: `sorted` may overwrite them
+    STAMP(3);
+    // ---- place ---------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < SPAN; ++i) {
+      uint32_t v = pr[i];
+      if (v != 0xFFFFFFFFu) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = (uint16_t)(threadIdx.x * SPAN + i);
+    }
+    __syncthreads();
+    STAMP(4);
+    // ---- write: consecutive entries of a partition go to consecutive addresses ---------------
+    const uint32_t n_tile = tstart[P - 1] + cnt[P - 1];
+    {
+      // four entries per thread per step, each stage issued for all four before the next
+      // stage consumes it (the chain sorted → packed words → partition cursors is 3 dependent
+      // LDS round trips per entry otherwise)
+      uint32_t i = threadIdx.x;
+      for (; i + 3 * NT < n_tile; i += 4 * NT) {
+        uint32_t e[4];
+        uint32_t w0[4], w1[4], w2[4];
+        uint64_t km[4];
+        uint32_t pc[4], dst[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = sorted[i + q * NT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int sbit = 2 * (HALO + (int)e[q] - k + 1);
+          const int wi = sbit >> 5;
+          w0[q] = packed[wi];
+          w1[q] = packed[wi + 1];
+          w2[q] = packed[wi + 2];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int off = (2 * (HALO + (int)e[q] - k + 1)) & 31;
+          uint64_t x = ((uint64_t)w0[q] << 32) | w1[q];
+          if (off) x = (x << off) | ((uint64_t)w2[q] >> (32 - off));
+          uint64_t fwd = x >> (64 - 2 * k);
+          uint64_t rev = revcomp(fwd, k);
+          km[q] = fwd < rev ? fwd : rev;
+          pc[q] = (uint32_t)page_of(hash64(km[q]), log_parts);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = gcur[pc[q]] + (i + q * NT - tstart[pc[q]]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part_buf[dst[q]] = km[q];
+      }
+      for (; i < n_tile; i += NT) {
+        uint32_t e1 = sorted[i];
+        uint64_t km1 = kmer_at(packed, HALO + (int)e1, k);
+        uint32_t pc1 = (uint32_t)page_of(hash64(km1), log_parts);
+        part_buf[gcur[pc1] + (i - tstart[pc1])] = km1;
+      }
+    }
+    __syncthreads();
+    STAMP(5);
+    for (uint32_t i = threadIdx.x; i < P; i += NT) gcur[i] += cnt[i];
+  }
+#ifdef SHK_PHASE_TIMING
+  if (dbg && threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i) dbg[(uint64_t)blockIdx.x * 8 + i] = ph[i];
+#endif
+}
+
 __device__ __forceinline__ void page_insert(uint64_t *keys, uint32_t *vals, uint32_t *occ,
                                             uint64_t key, uint32_t log_pages, bool slow,
                                             uint32_t lane, DevStats *stats, const SpillRef &sp,
-                                            uint32_t &n_new) {
-  uint32_t s = slot_of(hash64(key), log_pages);
+                                            uint32_t &n_new, uint32_t page, bool filter) {
+  const uint32_t h = hash64(key);
+  if (filter && (uint32_t)page_of(h, log_pages) != page) return;  // a sibling page's k-mer
+  uint32_t s = slot_of(h, log_pages);
   for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
     uint64_t cur = keys[s];
     if (cur == EMPTY) {
@@ -943,7 +1228,11 @@ __device__ __forceinline__ void page_insert(uint64_t *keys, uint32_t *vals, uint
   }
 }
 
-__global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
+// coarse > 0: a partition run holds the k-mers of 2^coarse sibling pages; each sibling's
+// workgroup streams the whole run and keeps its own.  Block ids are laid out so that the
+// siblings are dispatched together on one XCD (ids equal mod 8 — speed only): the run is then
+// fetched from HBM once and re-read from that XCD's L2.
+__global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uint32_t coarse,
                                                  const unsigned long long *__restrict__ part_base,
                                                  const uint64_t *__restrict__ part_buf,
                                                  DevStats *__restrict__ stats, SpillRef sp) {
@@ -951,8 +1240,19 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
   __shared__ __attribute__((aligned(16))) uint32_t vals[PAGE_SLOTS];
   __shared__ uint32_t occ, vmax, nnew;
   if (stats->bad != ~0ull) return;
-  const uint32_t page = blockIdx.x;
-  const uint64_t r0 = part_base[page], r1 = part_base[page + 1];
+  uint32_t page = blockIdx.x, part = blockIdx.x;
+  if (coarse) {
+    const uint32_t sib = 1u << coarse, grp = 8u * sib;
+    if ((gridDim.x % grp) == 0) {
+      const uint32_t r = blockIdx.x & 7, sub = (blockIdx.x >> 3) & (sib - 1), base = blockIdx.x / grp;
+      part = base * 8 + r;
+      page = (part << coarse) | sub;
+    } else {
+      part = page >> coarse;
+    }
+  }
+  const bool filter = coarse != 0;
+  const uint64_t r0 = part_base[part], r1 = part_base[part + 1];
   if (r1 == r0) return;  // nothing for this page: leave it untouched in HBM
   uint64_t *gk = tb.keys + ((uint64_t)page << PAGE_LOG);
   uint32_t *gv = tb.vals + (uint64_t)lane * tb.cap + ((uint64_t)page << PAGE_LOG);
@@ -993,15 +1293,39 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
   const uint64_t *src = part_buf + r0;
   uint32_t n_new = 0;
   uint64_t i = threadIdx.x;
+  if (!slow && !filter) {
+    // Fast path: eight k-mers per thread per step.  All eight global loads, then all eight
+    // home-slot LDS reads, are in flight together; a k-mer whose key already sits in its home
+    // slot (the common case at load ≤ 1/2 and ≥ 2× coverage) costs one non-returning LDS add.
+    // Everything else falls through to the general probe.
+    for (; i + 7 * PG_WG < n; i += 8 * PG_WG) {
+      uint64_t kk[8];
+      uint32_t ss[8];
+      uint64_t cc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kk[q] = src[i + q * PG_WG];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ss[q] = slot_of(hash64(kk[q]), tb.log_pages);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cc[q] = keys[ss[q]];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (cc[q] == kk[q])
+          atomicAdd(&vals[ss[q]], 1u);
+        else
+          page_insert(keys, vals, &occ, kk[q], tb.log_pages, false, lane, stats, sp, n_new, page, false);
+      }
+    }
+  }
   for (; i + 3 * PG_WG < n; i += 4 * PG_WG) {  // four independent loads in flight per thread
     uint64_t k0 = src[i], k1 = src[i + PG_WG], k2 = src[i + 2 * PG_WG], k3 = src[i + 3 * PG_WG];
-    page_insert(keys, vals, &occ, k0, tb.log_pages, slow, lane, stats, sp, n_new);
-    page_insert(keys, vals, &occ, k1, tb.log_pages, slow, lane, stats, sp, n_new);
-    page_insert(keys, vals, &occ, k2, tb.log_pages, slow, lane, stats, sp, n_new);
-    page_insert(keys, vals, &occ, k3, tb.log_pages, slow, lane, stats, sp, n_new);
+    page_insert(keys, vals, &occ, k0, tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
+    page_insert(keys, vals, &occ, k1, tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
+    page_insert(keys, vals, &occ, k2, tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
+    page_insert(keys, vals, &occ, k3, tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
   }
   for (; i < n; i += PG_WG)
-    page_insert(keys, vals, &occ, src[i], tb.log_pages, slow, lane, stats, sp, n_new);
+    page_insert(keys, vals, &occ, src[i], tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
   for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
   if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&nnew, n_new);
   __syncthreads();

@@ -199,7 +199,7 @@ int grow_to(shk_ctx *c, uint32_t new_log_pages) {
 
 uint32_t log_pages_for(uint64_t want_slots) {
   uint32_t lp = 0;
-  while (((uint64_t)PAGE_SLOTS << lp) < want_slots && lp < 40) lp++;
+  while (((uint64_t)PAGE_SLOTS << lp) < want_slots && lp < MAX_LOG_PAGES) lp++;
   return lp;
 }
 
@@ -340,10 +340,23 @@ static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
   return c->tb.log_pages >= 8 && sub_kmers_ub >= c->tb.cap / 2;
 }
 
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+constexpr int SC_NT = 512;  // threads of the partition count / sorted scatter workgroups
+
 static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp) {
   const uint32_t lp = c->tb.log_pages;
-  const uint32_t P = 1u << lp;
-  static const uint32_t g_cap = getenv("SHK_PART_G") ? (uint32_t)atoi(getenv("SHK_PART_G")) : 1024u;
+  const uint32_t n_pages = 1u << lp;
+  // partitions = groups of 2^coarse sibling pages: fewer, longer output runs for the scatter
+  static const int max_log_parts = env_int("SHK_PART_LOG", 13);
+  static const int sorted_scatter = env_int("SHK_SORTED_SCATTER", 1);
+  static const uint32_t g_cap = (uint32_t)env_int("SHK_PART_G", 768);
+  const uint32_t log_parts = std::min<uint32_t>(lp, (uint32_t)max_log_parts);
+  const uint32_t coarse = lp - log_parts;
+  const uint32_t P = 1u << log_parts;
   const uint32_t G = grid_for(b.tile_count, 1, g_cap);
   const size_t counts_b = (size_t)G * P * 4, totals_b = (size_t)P * 8, base_b = (size_t)(P + 1) * 8;
   HIPC(c, c->part_meta.ensure(2 * counts_b + totals_b + base_b + 64));
@@ -354,28 +367,55 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   unsigned long long *totals = (unsigned long long *)(m + 2 * counts_b);
   unsigned long long *part_base = (unsigned long long *)(m + 2 * counts_b + totals_b);
   uint64_t *part_buf = (uint64_t *)c->part.p;
-  const size_t lds = TILE_LDS + (size_t)P * 4;
+  unsigned long long *dbg = nullptr;
+#ifdef SHK_PHASE_TIMING
+  HIPC(c, c->misc.ensure((size_t)G * 64));
+  dbg = (unsigned long long *)c->misc.p;
+#endif
+  const size_t lds_count = STAGE_BYTES + (size_t)P * 4;
+  const size_t lds_sorted = SORT_REGION + (size_t)PACK_WORDS * 4 + (size_t)P * 12;
   const bool multi = b.tiles != nullptr;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
   for (uint32_t lane = lane_lo; lane < lane_hi; ++lane) {
     {
       ScopedTimer t(c, SHK_K_SCATTER);
-      hipLaunchKernelGGL(k_part_count, dim3(G), dim3(WG), lds, c->stream, b, lp, lane, counts,
-                         c->d_stats, c->d_lane_bases);
+      hipLaunchKernelGGL(k_part_count<SC_NT>, dim3(G), dim3(SC_NT), lds_count, c->stream, b, log_parts,
+                         lane, counts, c->d_stats, c->d_lane_bases);
       hipLaunchKernelGGL(k_part_scan1, dim3((P + 63) / 64), dim3(64 * SC_WAVES), 0, c->stream,
                          (const uint32_t *)counts, offs, G, P, totals);
       hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, c->stream,
                          (const unsigned long long *)totals, P, part_base);
-      hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(WG), lds, c->stream, b, lp, lane,
-                         (const uint32_t *)offs, (const unsigned long long *)part_base, part_buf,
-                         (const DevStats *)c->d_stats);
+      if (sorted_scatter)
+        hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b,
+                           log_parts, lane, (const uint32_t *)offs,
+                           (const unsigned long long *)part_base, part_buf,
+                           (const DevStats *)c->d_stats, dbg);
+      else
+        hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(WG), lds_count, c->stream, b, log_parts,
+                           lane, (const uint32_t *)offs, (const unsigned long long *)part_base,
+                           part_buf, (const DevStats *)c->d_stats);
     }
     {
       ScopedTimer t(c, SHK_K_PAGES);
-      hipLaunchKernelGGL(k_pages, dim3(P), dim3(PG_WG), 0, c->stream, c->tb, lane,
+      hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane, coarse,
                          (const unsigned long long *)part_base, (const uint64_t *)part_buf,
                          c->d_stats, sp);
     }
+#ifdef SHK_PHASE_TIMING
+    {
+      std::vector<unsigned long long> h((size_t)G * 8);
+      HIPC(c, hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+      double ph[8] = {0};
+      for (uint32_t g = 0; g < G; ++g)
+        for (int i = 0; i < 8; ++i) ph[i] += (double)h[(size_t)g * 8 + i];
+      double tot = 0;
+      for (int i = 0; i < 8; ++i) tot += ph[i];
+      fprintf(stderr, "[phase cycles/WG] stage %.0f pack %.0f walk %.0f scan %.0f place %.0f write %.0f | share:",
+              ph[0] / G, ph[1] / G, ph[2] / G, ph[3] / G, ph[4] / G, ph[5] / G);
+      for (int i = 0; i < 6; ++i) fprintf(stderr, " %.1f%%", 100 * ph[i] / tot);
+      fprintf(stderr, "\n");
+    }
+#endif
   }
   return SHK_OK;
 }

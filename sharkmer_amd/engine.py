@@ -30,7 +30,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "csrc", "libshk.so")
+    # SHK_LIB_PATH: experiment hook to A/B two builds of the same HIP library in one session
+    return os.environ.get("SHK_LIB_PATH") or os.path.join(_HERE, "csrc", "libshk.so")
 
 
 class ShkError(RuntimeError):
