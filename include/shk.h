@@ -134,6 +134,11 @@ int shk_ingest_batch(shk_ctx *ctx, uint32_t chunk_id, const uint8_t *bases,
 int shk_ingest_reads(shk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets,
                      uint64_t n_seqs);
 
+/* Set the running read index used by shk_ingest_reads* for chunk striping (default 0).  A
+ * host that shards one input stream over several contexts/GPUs gives each shard the global
+ * index of its first read, so that read i still lands in chunk (i / 1000) % n_chunks. */
+int shk_set_read_index(shk_ctx *ctx, uint64_t next_read_index);
+
 /* Same as shk_ingest_reads with input already resident in device memory
  * (d_bases: n_bases bytes, d_offsets: n_seqs+1 u64).  Asynchronous on the
  * engine stream; errors surface at the next synchronising call. */
@@ -189,10 +194,11 @@ int shk_table_reserve_pages(shk_ctx *ctx, uint64_t n_pages);
  * vals u32[n_lanes][n_pages*page_slots]. Valid until the next growing call. */
 int shk_table_device_ptrs(shk_ctx *ctx, void **d_keys, void **d_vals);
 /* KmerCounts::extend across devices (counting.rs:157-166): merge a peer's
- * page range [p0,p1) (same geometry; device pointers to its keys and
- * lane-major vals for that range) into this table, saturating per lane. */
+ * page range [p0,p1) (same geometry; device pointers to its keys and to its
+ * lane-major vals for that range, lane l at d_vals + l*vals_lane_stride u32
+ * elements) into this table, saturating per lane. */
 int shk_merge_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1, const void *d_keys,
-                    const void *d_vals);
+                    const void *d_vals, uint64_t vals_lane_stride);
 /* Restrict finalize's histogram scan to pages [p0,p1) (owner shard). */
 int shk_set_owned_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1);
 

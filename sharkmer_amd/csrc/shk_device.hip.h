@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(WG) k_export(TableRef tb, uint64_t slot0, uint
 // K_MERGE: KmerCounts::extend across devices (counting.rs:157-166): fold a peer's page range
 // (same geometry) into this table, lane by lane, saturating.
 // ==========================================================================================
-__global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t slot0, uint64_t n_slots,
+__global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t n_slots, uint64_t lane_stride,
                                               const uint64_t *__restrict__ pkeys,
                                               const uint32_t *__restrict__ pvals,
                                               DevStats *__restrict__ stats, SpillRef sp) {
@@ -749,7 +749,7 @@ __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t slot0, uint6
     if (s < 0) {
       // page full: one spill record per non-zero lane
       for (uint32_t l = 0; l < tb.n_lanes; ++l) {
-        uint32_t v = pvals[(uint64_t)l * n_slots + i];
+        uint32_t v = pvals[(uint64_t)l * lane_stride + i];
         if (!v) continue;
         unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
         if (j < sp.cap) {
@@ -762,11 +762,10 @@ __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t slot0, uint6
     }
     n_new += inserted;
     for (uint32_t l = 0; l < tb.n_lanes; ++l) {
-      uint32_t v = pvals[(uint64_t)l * n_slots + i];
+      uint32_t v = pvals[(uint64_t)l * lane_stride + i];
       if (v) sat_add_cas(tb.vals + (uint64_t)l * tb.cap + (uint64_t)s, v);
     }
   }
-  (void)slot0;
   for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
   if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&stats->n_distinct, (unsigned long long)n_new);
 }

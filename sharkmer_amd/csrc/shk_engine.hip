@@ -615,6 +615,12 @@ int shk_ingest_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, 
   return ingest_host(c, bases, offsets, n_seqs, -1);
 }
 
+int shk_set_read_index(shk_ctx *c, uint64_t next_read_index) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  c->n_reads_read = next_read_index;
+  return SHK_OK;
+}
+
 int shk_ingest_reads_device(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs,
                             uint64_t n_bases) {
   if (!c) return SHK_ERR_BAD_ARG;
@@ -841,7 +847,8 @@ int shk_table_device_ptrs(shk_ctx *c, void **d_keys, void **d_vals) {
   return SHK_OK;
 }
 
-int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, const void *d_vals) {
+int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, const void *d_vals,
+                    uint64_t vals_lane_stride) {
   if (!c) return SHK_ERR_BAD_ARG;
   if (p1 <= p0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -854,7 +861,7 @@ int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, co
   {
     ScopedTimer t(c, SHK_K_MERGE);
     hipLaunchKernelGGL(k_merge, dim3(grid_for(n_slots, WG, 8192)), dim3(WG), 0, c->stream, c->tb,
-                       p0 << PAGE_LOG, n_slots, (const uint64_t *)d_keys, (const uint32_t *)d_vals,
+                       n_slots, vals_lane_stride, (const uint64_t *)d_keys, (const uint32_t *)d_vals,
                        c->d_stats, sp);
   }
   int rc = read_stats(c);

@@ -1,0 +1,105 @@
+"""Multi-GPU counting: one process per GPU, reads sharded across ranks, per-rank count tables
+merged by owner over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the
+CPU tests), histograms all-reduced.
+
+What it reproduces: the reference merges per-chunk tables into one with
+`KmerCounts::extend{,_with_histogram}` (counting.rs:157-202) and reads the histogram off the
+merged table (io.rs:1020-1028).  Here the "tables to merge" are the per-rank tables:
+
+  1. all ranks agree on a table geometry (all_reduce MAX of the page count; smaller tables grow)
+  2. rank r OWNS pages [r·P/W, (r+1)·P/W): a page is a contiguous slice of every table array,
+     so "send every peer its range" is ONE all_to_all_single per array, straight out of the
+     table memory — the fully connected xGMI mesh carries all W-1 transfers of a rank at once
+  3. every rank folds the W-1 received slices into its own slice (saturating per lane)
+  4. histogram scan restricted to the owned slice; bins are additive across disjoint key
+     shards, so a dense all_reduce(SUM) of the (chunks × (histo_max+2)) u64 histogram and of
+     the scalar totals finishes the job
+
+The engine object is duck-typed (`table_geometry, reserve_pages, table_tensors,
+merge_page_tensors, set_owned_pages, finalize, histograms, counters`): the product passes
+`KmerEngine` (HIP); the CPU tests pass a numpy stand-in to exercise the collective logic under
+gloo with world_size 2.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def shard_batches(n_reads: int, rank: int, world: int, batch: int = 1000):
+    """Round-robin assignment of whole 1000-read batches to ranks: returns
+    [(first_read, n_reads_in_batch), ...] for `rank`.  Chunk membership is a function of the
+    GLOBAL read index (io.rs:340-361), so sharding never changes it."""
+    out = []
+    n_batches = (n_reads + batch - 1) // batch
+    for b in range(rank, n_batches, world):
+        first = b * batch
+        out.append((first, min(batch, n_reads - first)))
+    return out
+
+
+class DistCounter:
+    def __init__(self, engine, dist, device=None):
+        self.eng = engine
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.device = device
+
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        return t if self.device is None else t.to(f"cuda:{self.device}")
+
+    def exchange_and_merge(self):
+        """Steps 1-3.  After it, this rank's owned page range holds the merged counts."""
+        dist, W = self.dist, self.world
+        n_pages, page_slots, n_lanes = self.eng.table_geometry()
+        t = self._dev(torch.tensor([max(n_pages, W)], dtype=torch.int64))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        P = int(t.item())
+        self.eng.reserve_pages(P)
+        n_pages, page_slots, n_lanes = self.eng.table_geometry()
+        assert n_pages == P and P % W == 0, (n_pages, P, W)
+        per = P // W                      # pages per owner
+        n = per * page_slots              # slots per owner slice
+        keys, vals = self.eng.table_tensors()          # [P*S], [L, P*S]
+        rk = torch.empty_like(keys)                     # rk[s*n:(s+1)*n] = rank s's slice of MY range
+        rv = torch.empty_like(vals)
+        dist.all_to_all_single(rk, keys)
+        for l in range(n_lanes):
+            dist.all_to_all_single(rv[l], vals[l])
+        p0, p1 = self.rank * per, (self.rank + 1) * per
+        for s in range(W):
+            if s == self.rank:
+                continue
+            self.eng.merge_page_tensors(p0, p1, rk[s * n:(s + 1) * n], rv[:, s * n:(s + 1) * n])
+        self.eng.set_owned_pages(p0, p1)
+        return p0, p1
+
+    def finalize_histograms(self):
+        """Steps 1-4.  Returns the (chunks, histo_max+2) uint64 histogram of the union of all
+        ranks' reads — identical on every rank — and stores the reduced totals in self.totals."""
+        dist = self.dist
+        self.exchange_and_merge()
+        self.eng.finalize()
+        h = self.eng.histograms()
+        c = self.eng.counters()
+        ht = self._dev(torch.from_numpy(h.astype(np.int64)))
+        if ht.numel():
+            dist.all_reduce(ht, op=dist.ReduceOp.SUM)
+        names = ["n_reads_ingested", "n_bases_read", "n_bases_ingested", "n_kmers_ingested",
+                 "n_unique_kmers", "n_hashed_kmers", "any_saturated"]
+        tot = self._dev(torch.tensor([c[k] for k in names], dtype=torch.int64))
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        self.totals = {k: int(v) for k, v in zip(names, tot.cpu().tolist())}
+        hist = ht.cpu().numpy().astype(np.uint64)
+        if hist.shape[0] > 0:
+            self.totals["n_singleton_kmers"] = int(hist[-1, 1])
+            # io.rs:1042-1047 / 1120-1132 on the merged whole
+            if self.totals["n_hashed_kmers"] != self.totals["n_kmers_ingested"]:
+                raise RuntimeError(
+                    f"The total count of hashed kmers ({self.totals['n_hashed_kmers']}) does not equal "
+                    f"the number of ingested kmers ({self.totals['n_kmers_ingested']})")
+            if int(hist[-1, 1:].sum()) != self.totals["n_unique_kmers"]:
+                raise RuntimeError("The total count of unique kmers in the histogram does not equal "
+                                   "the total count of hashed kmers")
+        return hist

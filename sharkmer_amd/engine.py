@@ -69,7 +69,7 @@ class _Synth(C.Structure):
 # every symbol include/shk.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
     "shk_abi_version", "shk_create", "shk_destroy", "shk_reset", "shk_last_error", "shk_ingest_batch",
-    "shk_ingest_reads", "shk_ingest_reads_device", "shk_insert_counts", "shk_sync", "shk_finalize",
+    "shk_ingest_reads", "shk_set_read_index", "shk_ingest_reads_device", "shk_insert_counts", "shk_sync", "shk_finalize",
     "shk_histograms", "shk_get_counters", "shk_get_timings", "shk_reset_timings",
     "shk_export_table", "shk_lookup", "shk_table_geometry", "shk_table_reserve_pages",
     "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
@@ -138,7 +138,8 @@ def load_library():
     L.shk_table_geometry.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
     L.shk_table_reserve_pages.argtypes = [vp, u64]
     L.shk_table_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
-    L.shk_merge_pages.argtypes = [vp, u64, u64, vp, vp]
+    L.shk_merge_pages.argtypes = [vp, u64, u64, vp, vp, u64]
+    L.shk_set_read_index.argtypes = [vp, u64]
     L.shk_set_owned_pages.argtypes = [vp, u64, u64]
     L.shk_alloc_pinned.argtypes = [C.c_size_t]
     L.shk_alloc_pinned.restype = vp
@@ -307,8 +308,37 @@ class KmerEngine:
         self._check(self._L.shk_table_device_ptrs(self._h, C.byref(k), C.byref(v)))
         return int(k.value), int(v.value)
 
-    def merge_pages(self, p0: int, p1: int, d_keys: int, d_vals: int):
-        self._check(self._L.shk_merge_pages(self._h, p0, p1, d_keys, d_vals))
+    def merge_pages(self, p0: int, p1: int, d_keys: int, d_vals: int, lane_stride: int):
+        self._check(self._L.shk_merge_pages(self._h, p0, p1, d_keys, d_vals, lane_stride))
+
+    def set_read_index(self, next_read_index: int):
+        """Global index of the next read (chunk striping of a sharded stream)."""
+        self._check(self._L.shk_set_read_index(self._h, next_read_index))
+
+    # -- torch views for the multi-GPU driver (sharkmer_amd/dist.py) ---------------------
+    def table_tensors(self):
+        """(keys int64[capacity], vals int32[n_lanes, capacity]) as zero-copy CUDA tensors over
+        the live table (valid until the table grows)."""
+        import torch
+        n_pages, page_slots, n_lanes = self.table_geometry()
+        cap = n_pages * page_slots
+        dk, dv = self.table_device_ptrs()
+
+        class _Raw:  # minimal __cuda_array_interface__ carrier
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr,
+                                                 "data": (ptr, False), "version": 2}
+
+        keys = torch.as_tensor(_Raw(dk, (cap,), "<i8"), device="cuda")
+        vals = torch.as_tensor(_Raw(dv, (n_lanes, cap), "<i4"), device="cuda")
+        return keys, vals
+
+    def merge_page_tensors(self, p0: int, p1: int, keys_t, vals_t):
+        """KmerCounts::extend of a peer's page range held in torch tensors
+        (keys_t int64[(p1-p0)*page_slots], vals_t int32[n_lanes, same])."""
+        assert keys_t.is_contiguous() and vals_t.stride(-1) == 1
+        self.merge_pages(p0, p1, keys_t.data_ptr(), vals_t.data_ptr(),
+                         vals_t.stride(0) if vals_t.dim() == 2 else keys_t.numel())
 
     def set_owned_pages(self, p0: int, p1: int):
         self._check(self._L.shk_set_owned_pages(self._h, p0, p1))

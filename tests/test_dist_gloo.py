@@ -1,0 +1,182 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU merge logic in sharkmer_amd/dist.py: batch
+sharding, geometry agreement, owner-range all_to_all, merge, owned-shard histogram, all_reduce.
+The per-rank engine is a numpy stand-in with the same duck-typed interface KmerEngine offers
+(the HIP engine itself needs a GPU); k-mers come from the oracle's numpy extractor, and the
+result is checked against the oracle run over ALL reads."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+EMPTY = np.int64(-1)
+
+
+def _hash32(key: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        h = (key.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)
+    return h.astype(np.uint64)
+
+
+class NumpyPagedEngine:
+    """Stand-in for KmerEngine: a dict of per-lane counts, materialised on demand as the same
+    paged arrays (page = top hash bits) the HIP table uses."""
+    PAGE_SLOTS = 64
+
+    def __init__(self, k, chunks, histo_max):
+        self.k, self.chunks, self.histo_max = k, chunks, histo_max
+        self.n_lanes = max(chunks, 1)
+        self.counts = {}
+        self.log_pages = 2
+        self.n_reads = self.n_bases = self.n_valid = 0
+        self.owned = None
+
+    # ---- ingest (oracle-side extraction; chunk of read i = (i // 1000) % n_lanes) ------------
+    def ingest(self, orc, bases, offsets, first_read_index):
+        offsets = np.asarray(offsets, dtype=np.int64)
+        seg = bases[offsets[0]:offsets[-1]]
+        rel = offsets - offsets[0]
+        kmers, rid = orc.canonical_kmers_numpy(seg, rel, self.k, return_read_id=True)
+        lanes = ((first_read_index + rid) // 1000) % self.n_lanes
+        for key, lane in zip(kmers.tolist(), lanes.tolist()):
+            v = self.counts.setdefault(key, np.zeros(self.n_lanes, dtype=np.int64))
+            v[lane] = min(v[lane] + 1, 0xFFFFFFFF)
+        self.n_reads += len(offsets) - 1
+        self.n_bases += len(seg)
+        self.n_valid += int((seg != ord("N")).sum())
+
+    # ---- the interface DistCounter uses -----------------------------------------------------------
+    def _page(self, key):
+        return int(_hash32(np.array([key], dtype=np.uint64))[0]) >> (32 - self.log_pages)
+
+    def _fits(self):
+        load = {}
+        for key in self.counts:
+            p = self._page(key)
+            load[p] = load.get(p, 0) + 1
+        return all(v <= self.PAGE_SLOTS for v in load.values())
+
+    def table_geometry(self):
+        while not self._fits():
+            self.log_pages += 1
+        return 1 << self.log_pages, self.PAGE_SLOTS, self.n_lanes
+
+    def reserve_pages(self, n_pages):
+        while (1 << self.log_pages) < n_pages:
+            self.log_pages += 1
+        while not self._fits():
+            self.log_pages += 1
+
+    def table_tensors(self):
+        P, S = 1 << self.log_pages, self.PAGE_SLOTS
+        keys = np.full(P * S, EMPTY, dtype=np.int64)
+        vals = np.zeros((self.n_lanes, P * S), dtype=np.int32)
+        fill = [0] * P
+        for key, v in self.counts.items():
+            p = self._page(key)
+            i = p * S + fill[p]
+            fill[p] += 1
+            keys[i] = key
+            vals[:, i] = np.array(v, dtype=np.uint32).view(np.int32)
+        return torch.from_numpy(keys), torch.from_numpy(vals)
+
+    def merge_page_tensors(self, p0, p1, keys_t, vals_t):
+        keys = keys_t.numpy()
+        vals = vals_t.numpy().view(np.uint32)
+        for i in np.nonzero(keys != EMPTY)[0]:
+            key = int(keys[i])
+            assert p0 <= self._page(key) < p1, "peer sent a key outside my range"
+            v = self.counts.setdefault(key, np.zeros(self.n_lanes, dtype=np.int64))
+            v[:] = np.minimum(v + vals[:, i].astype(np.int64), 0xFFFFFFFF)
+
+    def set_owned_pages(self, p0, p1):
+        self.owned = (p0, p1)
+
+    def finalize(self):
+        hm = self.histo_max
+        self.hist = np.zeros((self.chunks, hm + 2), dtype=np.uint64)
+        self.n_unique = self.n_hashed = self.n_lane_sum = 0
+        for key, v in self.counts.items():
+            if self.owned and not (self.owned[0] <= self._page(key) < self.owned[1]):
+                continue
+            self.n_unique += 1
+            self.n_lane_sum += int(v.sum())
+            cum = 0
+            for l in range(self.n_lanes):
+                cum = min(cum + int(v[l]), 0xFFFFFFFF)
+                if l < self.chunks and cum > 0:
+                    self.hist[l, min(cum, hm + 1)] += 1
+            self.n_hashed += cum
+
+    def histograms(self):
+        return self.hist
+
+    def counters(self):
+        return {"n_reads_ingested": self.n_reads, "n_bases_read": self.n_bases,
+                "n_bases_ingested": self.n_valid, "n_kmers_ingested": self.n_lane_sum,
+                "n_unique_kmers": self.n_unique, "n_hashed_kmers": self.n_hashed, "any_saturated": 0}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, k, chunks, histo_max, n_reads, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import sharkmer_amd as sa
+    from sharkmer_amd.dist import DistCounter, shard_batches
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = sa.SynthSpec(genome_len=3000, sub_per_64k=400, n_per_64k=100)
+    bases, offsets = sa.synth_reads(spec, 0, n_reads)
+    eng = NumpyPagedEngine(k, chunks, histo_max)
+    for first, n in shard_batches(n_reads, rank, world):
+        eng.ingest(orc, bases, offsets[first:first + n + 1], first)
+    dc = DistCounter(eng, dist)
+    hist = dc.finalize_histograms()
+    np.save(os.path.join(out_dir, f"hist_{rank}.npy"), hist)
+    np.save(os.path.join(out_dir, f"tot_{rank}.npy"),
+            np.array([dc.totals[x] for x in ("n_reads_ingested", "n_bases_read", "n_bases_ingested",
+                                             "n_kmers_ingested", "n_unique_kmers")], dtype=np.int64))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,chunks,n_reads", [(21, 1, 2500), (15, 3, 4321), (9, 0, 1800)])
+def test_two_rank_merge_matches_single_oracle(orc, tmp_path, k, chunks, n_reads):
+    import sharkmer_amd as sa
+    histo_max = 40
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, k, chunks, histo_max, n_reads, str(tmp_path)), nprocs=2, join=True)
+    spec = sa.SynthSpec(genome_len=3000, sub_per_64k=400, n_per_64k=100)
+    bases, offsets = sa.synth_reads(spec, 0, n_reads)
+    ref = orc.run_batch(bases, offsets, k, chunks, histo_max)
+    h0 = np.load(tmp_path / "hist_0.npy")
+    h1 = np.load(tmp_path / "hist_1.npy")
+    assert np.array_equal(h0, h1)
+    assert np.array_equal(h0, ref.histograms())
+    t0 = np.load(tmp_path / "tot_0.npy")
+    st = ref.stats
+    assert list(t0) == [st["n_reads_ingested"], st["n_bases_read"], st["n_bases_ingested"],
+                        st["n_kmers_ingested"], st["n_unique_kmers"]]
+
+
+def test_shard_batches_cover_every_read_once():
+    from sharkmer_amd.dist import shard_batches
+    for n, w in [(0, 2), (999, 2), (1000, 2), (2500, 2), (10_001, 8), (123_456, 4)]:
+        seen = np.zeros(n, dtype=np.int32)
+        for r in range(w):
+            for first, cnt in shard_batches(n, r, w):
+                assert first % 1000 == 0 and 0 < cnt <= 1000
+                seen[first:first + cnt] += 1
+        assert (seen == 1).all()
