@@ -65,9 +65,10 @@ def main():
     torch.cuda.set_device(dev)
     L = 150
     n_reads = args.reads
-    # weak scaling: the genome grows with the number of GPUs so the distinct load per GPU and
-    # the coverage (≈50×) stay those of config 2
-    genome = args.genome * n_gpus
+    # weak scaling: every GPU counts its own 1 M reads of the SAME 3 Mb genome, so the per-GPU
+    # work (k-mer occurrences, distinct load, table size) is exactly config 2's at every N; the
+    # merged histogram is that of N × 50× coverage
+    genome = args.genome
     spec = sa.SynthSpec(genome_len=genome, read_len=L)
     flags = sa.FLAG_TIMING
     if args.path == "direct":
@@ -88,6 +89,7 @@ def main():
 
     def step():
         eng.reset()
+        eng.set_read_index(rank * n_reads)
         eng.ingest_reads_device(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases)
         if world > 1:
             return dc.finalize_histograms()
@@ -120,24 +122,51 @@ def main():
     value = total_bases / dt / 1e9
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (SURVEY.md §8d algorithmic bytes) ----------------
+        # ---- roofline (HBM-bound path; algorithmic bytes per launch) --------------
         kpr = L - args.k + 1
         n_kmers = n_reads * kpr
-        n_distinct = cnt["n_unique_kmers"] if world == 1 else None
-        count_kernels = {k_: v for k_, v in tim.items() if k_ in ("direct", "scatter", "pages")}
-        dom = max(tim.items(), key=lambda kv: kv[1][0])[0] if tim else None
+        nd = cnt["n_unique_kmers"] if world == 1 else min(genome, n_kmers)
+        cap = cnt["table_capacity"]
+        lanes = max(args.chunks, 1)
+        # per-kernel algorithmic bytes of ONE launch (what the kernel must move by design):
+        alg = {
+            "pcount": n_bases * 1,                       # ASCII bases read once
+            "scatter": n_bases * 1 + n_kmers * 8,        # bases read + one 8-B record per k-mer written
+            "pages": n_kmers * 8 + cap * 12 * 2,         # records read + every page (8-B key, 4-B count) in and out
+            "histo": cap * (8 + 4 * lanes),              # one table scan per histogram emit
+            "direct": n_bases * 1 + n_kmers * 16 + nd * 8,
+            "scan": n_bases * 1,
+        }
+        per_kernel = {}
+        for name, (ms, launches) in tim.items():
+            if name in alg and launches:
+                avg = ms / launches
+                per_kernel[name] = {"avg_launch_ms": round(avg, 4), "launches_per_step": launches / args.steps,
+                                    "alg_bytes_per_launch": int(alg[name]),
+                                    "achieved_GBps": round(alg[name] / (avg * 1e-3) / 1e9, 1)}
+        hot = [k_ for k_ in ("direct", "scatter", "pages", "pcount") if k_ in per_kernel]
+        dom = max(hot, key=lambda k_: per_kernel[k_]["avg_launch_ms"] * per_kernel[k_]["launches_per_step"]) if hot else None
         roof = None
-        if count_kernels:
-            # the counting kernels together carry B_alg's per-base and per-k-mer terms
-            ms_count = sum(v[0] for v in count_kernels.values()) / args.steps
-            nd = n_distinct if n_distinct is not None else min(genome, n_kmers)
-            b_alg = n_bases * 1 + n_kmers * 16 + nd * 8
-            achieved = b_alg / (ms_count * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "+".join(sorted(count_kernels)),
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "alg_bytes_per_launch": int(b_alg),
-                    "avg_launch_ms": round(ms_count, 4)}
+        if dom:
+            d = per_kernel[dom]
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath):  # PMC bytes of the same command, collected by tools/profile_round.sh
+                tj = json.load(open(tpath))
+                if tj.get("reads") == n_reads and tj.get("k") == args.k:
+                    traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(d["achieved_GBps"] / HBM_PEAK_GBS, 5),
+                    "traffic": traffic, "alg_bytes_per_launch": d["alg_bytes_per_launch"],
+                    "avg_launch_ms": d["avg_launch_ms"]}
+        # the whole counting path against SURVEY.md §8d's B_alg (1 B/base + 16 B/k-mer + 8 B/distinct
+        # + one table scan per emit), over the summed device time of its kernels
+        path_ms = sum(ms for name, (ms, _) in tim.items()
+                      if name in ("mark", "scan", "direct", "pcount", "pscan", "scatter", "pages", "histo")) / args.steps
+        b_alg = n_bases * 1 + n_kmers * 16 + nd * 8 + cap * (8 + 4 * lanes)
+        path_roof = {"alg_bytes_per_step": int(b_alg), "device_ms_per_step": round(path_ms, 4),
+                     "achieved_GBps": round(b_alg / (path_ms * 1e-3) / 1e9, 1) if path_ms else None,
+                     "frac": round(b_alg / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if path_ms else None}
         cpu = None
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
@@ -168,8 +197,8 @@ def main():
                        "reads_per_gpu": n_reads, "k": args.k, "chunks": args.chunks,
                        "genome": genome, "path": args.path},
             "roofline": roof, "cpu_baseline": cpu,
+            "roofline_path": path_roof, "kernels": per_kernel,
             "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in tim.items()},
-            "dominant_kernel": dom,
             "table": {"capacity": cnt["table_capacity"], "n_unique": cnt["n_unique_kmers"],
                       "n_grows": cnt["n_grows"], "n_spilled": cnt["n_spilled"]},
         }

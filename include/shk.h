@@ -90,7 +90,7 @@ enum {
   SHK_K_MARK = 0,      /* read-start bitmap + tile list */
   SHK_K_SCAN = 1,      /* validate / count bases / partition histogram */
   SHK_K_DIRECT = 2,    /* extract + global-atomic insert */
-  SHK_K_SCATTER = 3,   /* extract + partition scatter */
+  SHK_K_SCATTER = 3,   /* extract + LDS-sorted partition scatter (k_part_scatter_sorted) */
   SHK_K_PAGES = 4,     /* LDS page count */
   SHK_K_HISTO = 5,     /* table scan → histograms + totals */
   SHK_K_GROW = 6,      /* rehash into a bigger table */
@@ -98,7 +98,9 @@ enum {
   SHK_K_LOOKUP = 8,
   SHK_K_EXPORT = 9,
   SHK_K_SYNTH = 10,
-  SHK_K_MERGE = 11
+  SHK_K_MERGE = 11,
+  SHK_K_PCOUNT = 12,   /* validate + count k-mers per partition (k_part_count) */
+  SHK_K_PSCAN = 13     /* the two small exclusive scans between count and scatter */
 };
 
 /* ---- lifecycle ------------------------------------------------------------ */

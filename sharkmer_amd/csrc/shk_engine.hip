@@ -378,13 +378,19 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
   for (uint32_t lane = lane_lo; lane < lane_hi; ++lane) {
     {
-      ScopedTimer t(c, SHK_K_SCATTER);
+      ScopedTimer t(c, SHK_K_PCOUNT);
       hipLaunchKernelGGL(k_part_count<SC_NT>, dim3(G), dim3(SC_NT), lds_count, c->stream, b, log_parts,
                          lane, counts, c->d_stats, c->d_lane_bases);
+    }
+    {
+      ScopedTimer t(c, SHK_K_PSCAN);
       hipLaunchKernelGGL(k_part_scan1, dim3((P + 63) / 64), dim3(64 * SC_WAVES), 0, c->stream,
                          (const uint32_t *)counts, offs, G, P, totals);
       hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, c->stream,
                          (const unsigned long long *)totals, P, part_base);
+    }
+    {
+      ScopedTimer t(c, SHK_K_SCATTER);
       if (sorted_scatter)
         hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b,
                            log_parts, lane, (const uint32_t *)offs,

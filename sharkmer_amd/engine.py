@@ -24,7 +24,7 @@ FLAG_FORCE_DIRECT = 2
 FLAG_FORCE_PAGED = 4
 
 KERNEL_NAMES = ["mark", "scan", "direct", "scatter", "pages", "histo", "grow", "insert",
-                "lookup", "export", "synth", "merge"]
+                "lookup", "export", "synth", "merge", "pcount", "pscan"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

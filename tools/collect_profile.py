@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into the
+committed evidence under profiles/: the rocprofv3 --stats kernel summary, the PMC counter
+means per kernel, and <round>_traffic.json (HBM bytes per launch per kernel; FETCH_SIZE is
+doubled, the gfx950 correction of MI355X_MICROARCH.md §HBM — WRITE_SIZE is exact)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+reads = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+k = int(sys.argv[4]) if len(sys.argv) > 4 else 21
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(stats, f"profiles/{rnd}_kernel_stats.csv")
+
+NAMES = {"k_part_scatter_sorted<512>": "scatter", "k_pages": "pages", "k_part_count<512>": "pcount",
+         "k_histo": "histo", "k_direct": "direct", "k_scan": "scan", "k_mark_starts": "mark"}
+
+
+def means(sub):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            kn = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("shk::", "")
+            acc[(kn, row["Counter_Name"])].append(float(row["Counter_Value"]))
+    return {key: sum(v) / len(v) for key, v in acc.items()}
+
+
+fetch, write = means("pmc_fetch"), means("pmc_write")
+with open(f"profiles/{rnd}_pmc_summary.csv", "w") as f:
+    f.write("kernel,counter,mean_per_launch_KB\n")
+    for (kn, c), v in sorted({**fetch, **write}.items()):
+        f.write(f"{kn},{c},{v:.1f}\n")
+kernels = {}
+for kn, short in NAMES.items():
+    fs, ws = fetch.get((kn, "FETCH_SIZE")), write.get((kn, "WRITE_SIZE"))
+    if fs is None and ws is None:
+        continue
+    fb, wb = 2 * (fs or 0) * 1024, (ws or 0) * 1024
+    kernels[short] = {"kernel": kn, "fetch_bytes_corrected": int(fb), "write_bytes": int(wb),
+                      "hbm_bytes_per_launch": int(fb + wb)}
+json.dump({"reads": reads, "k": k, "source": f"tools/profile_round.sh {tag}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+           "in separate passes over `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`",
+           "kernels": kernels}, open(f"profiles/{rnd}_traffic.json", "w"), indent=1)
+print(json.dumps(kernels, indent=1))

@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc = defaultdict(list)
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0].replace("shk::", "")
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("shk::", "")
             acc[(k, row["Counter_Name"])].append(float(row["Counter_Value"]))
         for (k, c), v in sorted(acc.items()):
             if k.startswith("k_"):
