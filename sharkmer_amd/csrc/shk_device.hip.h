@@ -93,8 +93,10 @@ __device__ __forceinline__ uint32_t hash64(uint64_t key) {
 __device__ __forceinline__ uint64_t page_of(uint32_t h, uint32_t log_pages) {
   return log_pages ? (uint64_t)(h >> (32 - log_pages)) : 0ull;
 }
+// Home slots are bucket-aligned (multiples of 4): a key is almost always found inside the 32-B
+// bucket its probe sequence starts in, which k_pages reads with two 16-B LDS loads.
 __device__ __forceinline__ uint32_t slot_of(uint32_t h, uint32_t log_pages) {
-  return (h >> (32 - PAGE_LOG - log_pages)) & (PAGE_SLOTS - 1);
+  return (h >> (32 - PAGE_LOG - log_pages)) & (PAGE_SLOTS - 4);
 }
 
 __device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
@@ -1197,7 +1199,8 @@ __device__ __forceinline__ void page_insert(uint64_t *keys, uint32_t *vals, uint
   for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
     uint64_t cur = keys[s];
     if (cur == EMPTY) {
-      if (*(volatile uint32_t *)occ >= PAGE_FILL_CAP) break;  // page (nearly) full → spill
+      if (__hip_atomic_load(occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= PAGE_FILL_CAP)
+        break;  // page (nearly) full → spill
       uint64_t prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)EMPTY,
                                 (unsigned long long)key);
       if (prev == EMPTY) {
@@ -1234,10 +1237,11 @@ __device__ __forceinline__ void page_insert(uint64_t *keys, uint32_t *vals, uint
 __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uint32_t coarse,
                                                  const unsigned long long *__restrict__ part_base,
                                                  const uint64_t *__restrict__ part_buf,
+                                                 uint64_t *__restrict__ miss_buf,
                                                  DevStats *__restrict__ stats, SpillRef sp) {
   __shared__ __attribute__((aligned(16))) uint64_t keys[PAGE_SLOTS];
   __shared__ __attribute__((aligned(16))) uint32_t vals[PAGE_SLOTS];
-  __shared__ uint32_t occ, vmax, nnew;
+  __shared__ uint32_t occ, vmax, nnew, n_miss;
   if (stats->bad != ~0ull) return;
   uint32_t page = blockIdx.x, part = blockIdx.x;
   if (coarse) {
@@ -1259,6 +1263,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uin
     occ = 0;
     vmax = 0;
     nnew = 0;
+    n_miss = 0;
   }
   __syncthreads();
   // page → LDS (16-B vectors), counting occupied slots and the largest count on the way
@@ -1293,28 +1298,60 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uin
   uint32_t n_new = 0;
   uint64_t i = threadIdx.x;
   if (!slow && !filter) {
-    // Fast path: eight k-mers per thread per step.  All eight global loads, then all eight
-    // home-slot LDS reads, are in flight together; a k-mer whose key already sits in its home
-    // slot (the common case at load ≤ 1/2 and ≥ 2× coverage) costs one non-returning LDS add.
-    // Everything else falls through to the general probe.
-    for (; i + 7 * PG_WG < n; i += 8 * PG_WG) {
-      uint64_t kk[8];
-      uint32_t ss[8];
-      uint64_t cc[8];
+    // Fast path: four k-mers per thread per step.  The four global loads, then the four 32-B
+    // home buckets (two ds_read_b128 each), are in flight together; a k-mer whose key sits in
+    // its home bucket (≈99 % at load ≤ 1/2) costs one non-returning LDS add.  The others (first
+    // occurrences, displaced keys) are only QUEUED here — the run's slice of miss_buf — and
+    // handled densely by the general probe afterwards: a divergent in-line slow path would be
+    // executed by nearly every wave for one or two lanes each.
+    uint64_t *mq = miss_buf + r0;
+    const uint32_t n_quads = (uint32_t)(n / (4 * PG_WG));  // steps of four k-mers per thread
+    constexpr uint32_t DRAIN_EVERY = 4;                     // quads between miss-queue drains
+    uint64_t nxt[4];
+    if (n_quads) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) kk[q] = src[i + q * PG_WG];
+      for (int q = 0; q < 4; ++q) nxt[q] = src[threadIdx.x + q * PG_WG];
+    }
+    for (uint32_t quad = 0; quad < n_quads; ++quad) {
+      uint64_t kk[4];
+      uint32_t ss[4];
+      ulonglong2 ba[4], bb[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) ss[q] = slot_of(hash64(kk[q]), tb.log_pages);
+      for (int q = 0; q < 4; ++q) kk[q] = nxt[q];
+      if (quad + 1 < n_quads) {  // next step's loads are in flight while this one is processed
+        const uint64_t ib = (uint64_t)(quad + 1) * 4 * PG_WG + threadIdx.x;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) cc[q] = keys[ss[q]];
+        for (int q = 0; q < 4; ++q) nxt[q] = src[ib + q * PG_WG];
+      }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (cc[q] == kk[q])
-          atomicAdd(&vals[ss[q]], 1u);
+      for (int q = 0; q < 4; ++q) ss[q] = slot_of(hash64(kk[q]), tb.log_pages);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ba[q] = *reinterpret_cast<const ulonglong2 *>(&keys[ss[q]]);
+        bb[q] = *reinterpret_cast<const ulonglong2 *>(&keys[ss[q] + 2]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint64_t kq = kk[q];
+        int hit = ba[q].x == kq ? 0 : ba[q].y == kq ? 1 : bb[q].x == kq ? 2 : bb[q].y == kq ? 3 : -1;
+        if (hit >= 0)
+          atomicAdd(&vals[ss[q] + hit], 1u);
         else
-          page_insert(keys, vals, &occ, kk[q], tb.log_pages, false, lane, stats, sp, n_new, page, false);
+          mq[atomicAdd(&n_miss, 1u)] = kq;
+      }
+      if ((quad % DRAIN_EVERY) == DRAIN_EVERY - 1 || quad + 1 == n_quads) {
+        __syncthreads();
+        const uint32_t nm = n_miss;
+        if (nm) {
+          for (uint32_t j = threadIdx.x; j < nm; j += PG_WG)
+            page_insert(keys, vals, &occ, mq[j], tb.log_pages, false, lane, stats, sp, n_new, page, false);
+          __syncthreads();
+          if (threadIdx.x == 0) n_miss = 0;
+          __syncthreads();
+        }
       }
     }
+    i = (uint64_t)n_quads * 4 * PG_WG + threadIdx.x;
   }
   for (; i + 3 * PG_WG < n; i += 4 * PG_WG) {  // four independent loads in flight per thread
     uint64_t k0 = src[i], k1 = src[i + PG_WG], k2 = src[i + 2 * PG_WG], k3 = src[i + 3 * PG_WG];

@@ -68,7 +68,7 @@ struct shk_ctx {
   HistoTotals h_tot{};
   std::vector<uint64_t> h_hist;
   // scratch
-  DevBuf in_bases, in_offsets, startbits, tiles, spillA, spillB, misc, part, part_meta;
+  DevBuf in_bases, in_offsets, startbits, tiles, spillA, spillB, misc, part, part2, part_meta;
   // host counters
   std::vector<uint64_t> lane_reads;
   uint64_t n_reads_read = 0, n_bases_read = 0;
@@ -361,6 +361,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const size_t counts_b = (size_t)G * P * 4, totals_b = (size_t)P * 8, base_b = (size_t)(P + 1) * 8;
   HIPC(c, c->part_meta.ensure(2 * counts_b + totals_b + base_b + 64));
   HIPC(c, c->part.ensure(sub_kmers_ub * 8));
+  HIPC(c, c->part2.ensure(sub_kmers_ub * 8));  // k_pages miss queues (same offsets as part)
   uint8_t *m = (uint8_t *)c->part_meta.p;
   uint32_t *counts = (uint32_t *)m;
   uint32_t *offs = (uint32_t *)(m + counts_b);
@@ -405,7 +406,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       ScopedTimer t(c, SHK_K_PAGES);
       hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane, coarse,
                          (const unsigned long long *)part_base, (const uint64_t *)part_buf,
-                         c->d_stats, sp);
+                         (uint64_t *)c->part2.p, c->d_stats, sp);
     }
 #ifdef SHK_PHASE_TIMING
     {
@@ -558,6 +559,7 @@ void shk_destroy(shk_ctx *c) {
   c->spillB.release();
   c->misc.release();
   c->part.release();
+  c->part2.release();
   c->part_meta.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
