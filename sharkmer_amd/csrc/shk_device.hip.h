@@ -124,6 +124,18 @@ __device__ __forceinline__ bool tile_get(const BatchRef &b, uint64_t t, uint64_t
   return true;
 }
 
+// Advance t (stride gridDim.x) to this workgroup's next tile, optionally only tiles of one
+// chunk lane.  Uniform across the workgroup.
+__device__ __forceinline__ bool next_tile(const BatchRef &b, uint64_t &t, bool use_filter,
+                                          uint32_t lane_filter, uint64_t &t0, uint64_t &t1,
+                                          uint32_t &lane) {
+  while (tile_get(b, t, t0, t1, lane)) {
+    if (!use_filter || lane == lane_filter) return true;
+    t += gridDim.x;
+  }
+  return false;
+}
+
 // ASCII → 2-bit base for 4 bytes at once: A,C,G,T → 0..3 via ((c>>1)^(c>>2))&3 ('N' → 0);
 // *nmask4 gets one bit per byte that is 'N'.
 __device__ __forceinline__ uint32_t codes4(uint32_t w, uint32_t *nmask4) {
@@ -155,18 +167,75 @@ __device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t x4) {
 // the first offender in input order is reported through stats->bad) and return this
 // thread's count of non-N bytes in [t0,t1) (count_valid_bases, encoding.rs:374-376).
 // Contains one __syncthreads(); the caller adds another before reading the codes.
+// Bytewise staging of a 16-base group that touches the start or the end of the batch (a few
+// groups per launch).  Kept out of line: inlined into the unrolled staging loop it costs the
+// callers > 100 VGPRs.  Returns x = the 16 base codes, 2 bits each (base i at bits 2i),
+// y = the group's N / outside-the-batch mask, z = its non-N count (VALIDATE only).
+__device__ __noinline__ uint4 stage_edge_group(const uint8_t *bases, uint64_t n_bases, int64_t p,
+                                               uint64_t t0, uint64_t t1, bool validate,
+                                               DevStats *stats) {
+  uint32_t codes = 0, nmask = 0, n_non_n = 0;
+  for (int r = 0; r < 16; ++r) {
+    int64_t pp = p + r;
+    uint32_t c = 0, isn = 1;  // outside the batch: behaves like N
+    if (pp >= 0 && (uint64_t)pp < n_bases) {
+      uint32_t a = bases[pp];
+      isn = a == 'N';
+      c = isn ? 0u : (((a >> 1) ^ (a >> 2)) & 3u);
+      if (validate && (uint64_t)pp >= t0 && (uint64_t)pp < t1) {
+        if (!byte_is_acgtn(a)) atomicMin(&stats->bad, ((unsigned long long)pp << 8) | a);
+        n_non_n += (a != 'N');
+      }
+    }
+    codes |= c << (2 * r);
+    nmask |= isn << r;
+  }
+  return make_uint4(codes, nmask, n_non_n, 0u);
+}
+
+// Raw bytes + read-start words of one thread's share of a tile, loaded ahead of time so that
+// the HBM latency of tile i+1 hides behind the processing of tile i.
+template <int NT>
+struct StageRegs {
+  static constexpr int R = (TILE_GROUPS + NT - 1) / NT;
+  uint32_t raw[R][4];
+  uint32_t sb0[R], sb1[R];
+};
+template <int NT>
+__device__ __forceinline__ void stage_prefetch(const BatchRef &b, uint64_t t0, StageRegs<NT> &pre) {
+  const int64_t p0 = (int64_t)t0 - HALO;
+#pragma unroll
+  for (int r = 0; r < StageRegs<NT>::R; ++r) {
+    const int m = threadIdx.x + r * NT;
+    const int64_t p = p0 + (int64_t)m * 16;
+    if (m < TILE_GROUPS && p >= 0 && (uint64_t)p + 16 <= b.n_bases) {
+      __builtin_memcpy(pre.raw[r], b.bases + p, 16);  // unaligned 16-B global load (one dwordx4)
+      pre.sb0[r] = b.startbits[(uint64_t)p >> 5];
+      pre.sb1[r] = b.startbits[((uint64_t)p >> 5) + 1];
+    }
+  }
+}
+
 template <bool VALIDATE, int NT = WG>
 __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, uint64_t t1,
-                                               uint8_t *lds, DevStats *stats) {
+                                               uint8_t *lds, DevStats *stats,
+                                               const StageRegs<NT> &pre) {
   uint32_t *gmask = reinterpret_cast<uint32_t *>(lds + TILE_LDS);  // nmask16 | smask16<<16
   const int64_t p0 = (int64_t)t0 - HALO;
   uint32_t n_non_n = 0;
-  for (int m = threadIdx.x; m < TILE_GROUPS; m += NT) {
+#pragma unroll
+  for (int r = 0; r < StageRegs<NT>::R; ++r) {
+    const int m = threadIdx.x + r * NT;
+    if (m >= TILE_GROUPS) continue;  // (no break: keeps r a compile-time index into `pre`)
     int64_t p = p0 + (int64_t)m * 16;
     uint32_t w[4];
     uint32_t nmask = 0;
-    if (p >= 0 && (uint64_t)p + 16 <= b.n_bases) {
-      __builtin_memcpy(w, b.bases + p, 16);  // unaligned 16-B global load (one dwordx4)
+    const bool fast = p >= 0 && (uint64_t)p + 16 <= b.n_bases;  // same test as stage_prefetch
+    if (fast) {
+      w[0] = pre.raw[r][0];
+      w[1] = pre.raw[r][1];
+      w[2] = pre.raw[r][2];
+      w[3] = pre.raw[r][3];
       if (VALIDATE && (uint64_t)p >= t0 && (uint64_t)p < t1) {
         if ((uint64_t)p + 16 <= t1) {
           uint32_t bad = 0, nn = 0;
@@ -203,29 +272,21 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
         nmask |= n4 << (4 * q);
       }
     } else {
+      uint4 e = stage_edge_group(b.bases, b.n_bases, p, t0, t1, VALIDATE, stats);
+#pragma unroll
       for (int q = 0; q < 4; ++q) {
-        uint32_t ww = 0;
-        for (int r = 0; r < 4; ++r) {
-          int64_t pp = p + q * 4 + r;
-          uint32_t c = 0, isn = 1;  // outside the batch: behaves like N
-          if (pp >= 0 && (uint64_t)pp < b.n_bases) {
-            uint32_t a = b.bases[pp];
-            isn = a == 'N';
-            c = isn ? 0u : (((a >> 1) ^ (a >> 2)) & 3u);
-            if (VALIDATE && (uint64_t)pp >= t0 && (uint64_t)pp < t1) {
-              if (!byte_is_acgtn(a)) atomicMin(&stats->bad, ((unsigned long long)pp << 8) | a);
-              n_non_n += (a != 'N');
-            }
-          }
-          ww |= c << (8 * r);
-          nmask |= isn << (q * 4 + r);
-        }
-        w[q] = ww;
+        uint32_t c8 = (e.x >> (8 * q)) & 0xFFu;  // four 2-bit codes
+        w[q] = (c8 & 3u) | (((c8 >> 2) & 3u) << 8) | (((c8 >> 4) & 3u) << 16) | (((c8 >> 6) & 3u) << 24);
       }
+      nmask = e.y;
+      n_non_n += e.z;
     }
     // read-start flags for these 16 positions: bits [p, p+16) of startbits
     uint32_t f = 0;
-    if (p >= 0 && (uint64_t)p < b.n_bases) {
+    if (fast) {
+      uint64_t two = (uint64_t)pre.sb0[r] | ((uint64_t)pre.sb1[r] << 32);
+      f = (uint32_t)(two >> ((uint32_t)p & 31)) & 0xFFFFu;
+    } else if (p >= 0 && (uint64_t)p < b.n_bases) {
       uint64_t wi = (uint64_t)p >> 5;
       uint32_t sh = (uint32_t)p & 31;
       uint64_t two = (uint64_t)b.startbits[wi] | ((uint64_t)b.startbits[wi + 1] << 32);
@@ -236,7 +297,8 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
     }
     *reinterpret_cast<uint4 *>(lds + m * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     gmask[m] = nmask | (f << 16);
-  }
+    __builtin_amdgcn_sched_barrier(0);  // one group at a time: interleaving the unrolled
+  }                                     // iterations costs > 100 VGPRs
   __syncthreads();
   // "k-mer ends here" bits: position j is bad if an N lies in [j-k+1, j] or a read starts in
   // [j-k+2, j].  48 mask bits (this group and the two before it) are smeared upwards.
@@ -527,14 +589,25 @@ __global__ void __launch_bounds__(WG) k_direct(BatchRef b, TableRef tb, DevStats
   __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE_BYTES];
   uint32_t n_new = 0;
   if (stats->bad != ~0ull) return;  // k_scan found an invalid byte: leave the table untouched
-  for (uint64_t t = blockIdx.x;; t += gridDim.x) {
-    uint64_t t0, t1;
-    uint32_t lane;
-    if (!tile_get(b, t, t0, t1, lane)) break;
+  uint64_t t = blockIdx.x, t0, t1;
+  uint32_t lane;
+  bool have = next_tile(b, t, false, 0, t0, t1, lane);
+  StageRegs<WG> pre;
+  if (have) stage_prefetch<WG>(b, t0, pre);
+  while (have) {
     __syncthreads();
-    stage_tile<false>(b, t0, t1, lds, stats);
+    stage_tile<false, WG>(b, t0, t1, lds, stats, pre);
+    uint64_t tn = t + gridDim.x, n0, n1;
+    uint32_t nl;
+    const bool hn = next_tile(b, tn, false, 0, n0, n1, nl);
+    if (hn) stage_prefetch<WG>(b, n0, pre);
     __syncthreads();
     walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) { count_one(tb, kmer, lane, stats, sp, n_new); });
+    t = tn;
+    t0 = n0;
+    t1 = n1;
+    lane = nl;
+    have = hn;
   }
   for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
   if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&stats->n_distinct, (unsigned long long)n_new);
@@ -870,23 +943,41 @@ __global__ void __launch_bounds__(NT) k_part_count(BatchRef b, uint32_t log_page
   // (chunk.rs:28): both ride on the staging loads.  An invalid byte found by ANY workgroup
   // stops k_part_scatter / k_pages (they test stats->bad), so the table stays untouched.
   uint32_t n_non_n = 0;
-  for (uint64_t t = blockIdx.x;; t += gridDim.x) {
-    uint64_t t0, t1;
-    uint32_t lane;
-    if (!tile_get(b, t, t0, t1, lane)) break;
-    if (lane != lane_filter) continue;
+  uint32_t *tot_p = cnt + P;  // per-partition totals over this workgroup's tiles
+  for (uint32_t i = threadIdx.x; i < P; i += NT) tot_p[i] = 0;
+  uint64_t t = blockIdx.x, t0, t1;
+  uint32_t lane;
+  bool have = next_tile(b, t, true, lane_filter, t0, t1, lane);
+  StageRegs<NT> pre;
+  if (have) stage_prefetch<NT>(b, t0, pre);
+  while (have) {
     __syncthreads();
-    n_non_n += stage_tile<true, NT>(b, t0, t1, lds, stats);
+    n_non_n += stage_tile<true, NT>(b, t0, t1, lds, stats, pre);
+    uint64_t tn = t + gridDim.x, n0, n1;
+    uint32_t nl;
+    const bool hn = next_tile(b, tn, true, lane_filter, n0, n1, nl);
+    if (hn) stage_prefetch<NT>(b, n0, pre);
     __syncthreads();
     walk_tile<NT>(lds, t0, t1, b.k, [&](uint64_t kmer) {
       atomicAdd(&cnt[(uint32_t)page_of(hash64(kmer), log_pages)], 1u);
     });
+    __syncthreads();
+    // every (tile, partition) run is padded to an even length (16-B aligned record pairs)
+    for (uint32_t i = threadIdx.x; i < P; i += NT) {
+      tot_p[i] += (cnt[i] + 1u) & ~1u;
+      cnt[i] = 0;
+    }
+    t = tn;
+    t0 = n0;
+    t1 = n1;
+    lane = nl;
+    have = hn;
   }
   __syncthreads();
   uint32_t tot = wg_sum<NT>(n_non_n, red);
   if (threadIdx.x == 0 && tot) atomicAdd(&lane_bases[lane_filter], (unsigned long long)tot);
   uint32_t *out = counts + (uint64_t)blockIdx.x * P;
-  for (uint32_t i = threadIdx.x; i < P; i += NT) out[i] = cnt[i];
+  for (uint32_t i = threadIdx.x; i < P; i += NT) out[i] = tot_p[i];
 }
 
 // exclusive scan over workgroups, per page: offs[g][p] = Σ_{g'<g} counts[g'][p] (the start
@@ -947,34 +1038,6 @@ __global__ void __launch_bounds__(1024) k_part_scan2(const unsigned long long *_
       run += totals[lo + i];
     }
   if (threadIdx.x == 1023) part_base[P] = sc[1023];
-}
-
-__global__ void __launch_bounds__(WG) k_part_scatter(BatchRef b, uint32_t log_pages,
-                                                     uint32_t lane_filter,
-                                                     const uint32_t *__restrict__ counts,
-                                                     const unsigned long long *__restrict__ part_base,
-                                                     uint64_t *__restrict__ part_buf,
-                                                     const DevStats *__restrict__ stats) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
-  const uint32_t P = 1u << log_pages;
-  uint8_t *lds = reinterpret_cast<uint8_t *>(sh);
-  uint32_t *cur = sh + STAGE_BYTES / 4;
-  if (stats->bad != ~0ull) return;
-  const uint32_t *mine = counts + (uint64_t)blockIdx.x * P;
-  for (uint32_t i = threadIdx.x; i < P; i += WG) cur[i] = (uint32_t)part_base[i] + mine[i];
-  for (uint64_t t = blockIdx.x;; t += gridDim.x) {
-    uint64_t t0, t1;
-    uint32_t lane;
-    if (!tile_get(b, t, t0, t1, lane)) break;
-    if (lane != lane_filter) continue;
-    __syncthreads();
-    stage_tile<false>(b, t0, t1, lds, nullptr);
-    __syncthreads();
-    walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) {
-      uint32_t pos = atomicAdd(&cur[(uint32_t)page_of(hash64(kmer), log_pages)], 1u);
-      part_buf[pos] = kmer;
-    });
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1046,17 +1109,22 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
   const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
   const uint32_t per = P / NT ? P / NT : 1;  // partitions per thread in the scan (P ≥ WG or P < WG)
 
-  for (uint64_t t = blockIdx.x;; t += gridDim.x) {
-    uint64_t t0, t1;
-    uint32_t lane;
-    if (!tile_get(b, t, t0, t1, lane)) break;
-    if (lane != lane_filter) continue;
+  uint64_t t = blockIdx.x, t0, t1;
+  uint32_t lane;
+  bool have = next_tile(b, t, true, lane_filter, t0, t1, lane);
+  StageRegs<NT> pre;
+  if (have) stage_prefetch<NT>(b, t0, pre);
+  while (have) {
     __syncthreads();  // previous tile's write phase is done with sorted/cnt/tstart
 #ifdef SHK_PHASE_TIMING
     tprev = __builtin_readcyclecounter();
 #endif
     for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
-    stage_tile<false, NT>(b, t0, t1, codes, nullptr);
+    stage_tile<false, NT>(b, t0, t1, codes, nullptr, pre);
+    uint64_t tn = t + gridDim.x, n0, n1;
+    uint32_t nl;
+    const bool hn = next_tile(b, tn, true, lane_filter, n0, n1, nl);
+    if (hn) stage_prefetch<NT>(b, n0, pre);  // in flight during the rest of this tile
     __syncthreads();
     STAMP(0);
     // 2-bit packed copy of the staged tile (N / out-of-range bases pack as 0; never read back
@@ -1104,11 +1172,11 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     }
     __syncthreads();
     STAMP(2);
-    // ---- exclusive scan of cnt → tstart ---------------------------------------------------
+    // ---- exclusive scan of the even-padded counts → tstart (every run starts on a pair) ------
     {
       uint32_t lo = threadIdx.x * per, s = 0;
       if (lo < P)
-        for (uint32_t i = 0; i < per; ++i) s += cnt[lo + i];
+        for (uint32_t i = 0; i < per; ++i) s += (cnt[lo + i] + 1u) & ~1u;
       uint32_t inc = s;
       for (int d = 1; d < 64; d <<= 1) {
         uint32_t o = __shfl_up(inc, d, 64);
@@ -1122,66 +1190,44 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
       if (lo < P)
         for (uint32_t i = 0; i < per; ++i) {
           tstart[lo + i] = run;
-          run += cnt[lo + i];
+          run += (cnt[lo + i] + 1u) & ~1u;
         }
     }
     __syncthreads();  // codes are dead from here: `sorted` may overwrite them
     STAMP(3);
-    // ---- place ---------------------------------------------------------------------------
+    // ---- place (the odd runs' padding slot gets the sentinel 0xFFFF) ---------------------------
 #pragma unroll
     for (int i = 0; i < SPAN; ++i) {
       uint32_t v = pr[i];
       if (v != 0xFFFFFFFFu) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = (uint16_t)(threadIdx.x * SPAN + i);
     }
+    for (uint32_t i = threadIdx.x; i < P; i += NT)
+      if (cnt[i] & 1u) sorted[tstart[i] + cnt[i]] = 0xFFFFu;
     __syncthreads();
     STAMP(4);
-    // ---- write: consecutive entries of a partition go to consecutive addresses ---------------
-    const uint32_t n_tile = tstart[P - 1] + cnt[P - 1];
-    {
-      // four entries per thread per step, each stage issued for all four before the next
-      // stage consumes it (the chain sorted → packed words → partition cursors is 3 dependent
-      // LDS round trips per entry otherwise)
-      uint32_t i = threadIdx.x;
-      for (; i + 3 * NT < n_tile; i += 4 * NT) {
-        uint32_t e[4];
-        uint32_t w0[4], w1[4], w2[4];
-        uint64_t km[4];
-        uint32_t pc[4], dst[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) e[q] = sorted[i + q * NT];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int sbit = 2 * (HALO + (int)e[q] - k + 1);
-          const int wi = sbit >> 5;
-          w0[q] = packed[wi];
-          w1[q] = packed[wi + 1];
-          w2[q] = packed[wi + 2];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int off = (2 * (HALO + (int)e[q] - k + 1)) & 31;
-          uint64_t x = ((uint64_t)w0[q] << 32) | w1[q];
-          if (off) x = (x << off) | ((uint64_t)w2[q] >> (32 - off));
-          uint64_t fwd = x >> (64 - 2 * k);
-          uint64_t rev = revcomp(fwd, k);
-          km[q] = fwd < rev ? fwd : rev;
-          pc[q] = (uint32_t)page_of(hash64(km[q]), log_parts);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = gcur[pc[q]] + (i + q * NT - tstart[pc[q]]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) part_buf[dst[q]] = km[q];
-      }
-      for (; i < n_tile; i += NT) {
-        uint32_t e1 = sorted[i];
-        uint64_t km1 = kmer_at(packed, HALO + (int)e1, k);
-        uint32_t pc1 = (uint32_t)page_of(hash64(km1), log_parts);
-        part_buf[gcur[pc1] + (i - tstart[pc1])] = km1;
-      }
+    // ---- write: one PAIR of records per lane per store (16 B, aligned: runs start on even
+    // record indices in LDS and in HBM); pairs never straddle partitions ----------------------
+    const uint32_t n_pairs = (tstart[P - 1] + ((cnt[P - 1] + 1u) & ~1u)) >> 1;
+    const uint32_t *sorted2 = reinterpret_cast<const uint32_t *>(sorted);
+    for (uint32_t i = threadIdx.x; i < n_pairs; i += NT) {
+      const uint32_t ee = sorted2[i];
+      const uint32_t e0 = ee & 0xFFFFu, e1 = ee >> 16;
+      const uint64_t km0 = kmer_at(packed, HALO + (int)e0, k);
+      const uint64_t km1 = e1 == 0xFFFFu ? EMPTY : kmer_at(packed, HALO + (int)e1, k);
+      const uint32_t pc = (uint32_t)page_of(hash64(km0), log_parts);
+      ulonglong2 rec;
+      rec.x = km0;
+      rec.y = km1;
+      *reinterpret_cast<ulonglong2 *>(part_buf + gcur[pc] + (2 * i - tstart[pc])) = rec;
     }
     __syncthreads();
     STAMP(5);
-    for (uint32_t i = threadIdx.x; i < P; i += NT) gcur[i] += cnt[i];
+    for (uint32_t i = threadIdx.x; i < P; i += NT) gcur[i] += (cnt[i] + 1u) & ~1u;
+    t = tn;
+    t0 = n0;
+    t1 = n1;
+    lane = nl;
+    have = hn;
   }
 #ifdef SHK_PHASE_TIMING
   if (dbg && threadIdx.x == 0)
@@ -1193,6 +1239,7 @@ __device__ __forceinline__ void page_insert(uint64_t *keys, uint32_t *vals, uint
                                             uint64_t key, uint32_t log_pages, bool slow,
                                             uint32_t lane, DevStats *stats, const SpillRef &sp,
                                             uint32_t &n_new, uint32_t page, bool filter) {
+  if (key == EMPTY) return;  // padding record of an odd (tile, partition) run
   const uint32_t h = hash64(key);
   if (filter && (uint32_t)page_of(h, log_pages) != page) return;  // a sibling page's k-mer
   uint32_t s = slot_of(h, log_pages);
@@ -1305,23 +1352,24 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uin
     // handled densely by the general probe afterwards: a divergent in-line slow path would be
     // executed by nearly every wave for one or two lanes each.
     uint64_t *mq = miss_buf + r0;
-    const uint32_t n_quads = (uint32_t)(n / (4 * PG_WG));  // steps of four k-mers per thread
-    constexpr uint32_t DRAIN_EVERY = 4;                     // quads between miss-queue drains
-    uint64_t nxt[4];
+    // runs are sequences of aligned record PAIRS (padding = EMPTY): one 16-B load per lane
+    // fetches two records; two such loads per step
+    const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(src);
+    const uint32_t n_quads = (uint32_t)(n / (4 * PG_WG));  // steps of four records per thread
+    constexpr uint32_t DRAIN_EVERY = 4;                     // steps between miss-queue drains
+    ulonglong2 nxt[2];
     if (n_quads) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) nxt[q] = src[threadIdx.x + q * PG_WG];
+      nxt[0] = src2[threadIdx.x];
+      nxt[1] = src2[threadIdx.x + PG_WG];
     }
     for (uint32_t quad = 0; quad < n_quads; ++quad) {
-      uint64_t kk[4];
+      uint64_t kk[4] = {nxt[0].x, nxt[0].y, nxt[1].x, nxt[1].y};
       uint32_t ss[4];
       ulonglong2 ba[4], bb[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) kk[q] = nxt[q];
       if (quad + 1 < n_quads) {  // next step's loads are in flight while this one is processed
-        const uint64_t ib = (uint64_t)(quad + 1) * 4 * PG_WG + threadIdx.x;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) nxt[q] = src[ib + q * PG_WG];
+        const uint64_t ib = (uint64_t)(quad + 1) * 2 * PG_WG + threadIdx.x;
+        nxt[0] = src2[ib];
+        nxt[1] = src2[ib + PG_WG];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) ss[q] = slot_of(hash64(kk[q]), tb.log_pages);
@@ -1334,17 +1382,21 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uin
       for (int q = 0; q < 4; ++q) {
         const uint64_t kq = kk[q];
         int hit = ba[q].x == kq ? 0 : ba[q].y == kq ? 1 : bb[q].x == kq ? 2 : bb[q].y == kq ? 3 : -1;
-        if (hit >= 0)
-          atomicAdd(&vals[ss[q] + hit], 1u);
-        else
-          mq[atomicAdd(&n_miss, 1u)] = kq;
+        if (hit >= 0) {
+          if (kq != EMPTY) atomicAdd(&vals[ss[q] + hit], 1u);  // EMPTY = padding record
+        } else {
+          mq[atomicAdd(&n_miss, 1u)] = kq;  // kq != EMPTY here: an EMPTY record always "hits"
+        }                                   // an empty slot or probes on; filtered in the drain
       }
       if ((quad % DRAIN_EVERY) == DRAIN_EVERY - 1 || quad + 1 == n_quads) {
         __syncthreads();
         const uint32_t nm = n_miss;
         if (nm) {
-          for (uint32_t j = threadIdx.x; j < nm; j += PG_WG)
-            page_insert(keys, vals, &occ, mq[j], tb.log_pages, false, lane, stats, sp, n_new, page, false);
+          for (uint32_t j = threadIdx.x; j < nm; j += PG_WG) {
+            const uint64_t kq = mq[j];
+            if (kq != EMPTY)
+              page_insert(keys, vals, &occ, kq, tb.log_pages, false, lane, stats, sp, n_new, page, false);
+          }
           __syncthreads();
           if (threadIdx.x == 0) n_miss = 0;
           __syncthreads();

@@ -352,7 +352,6 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const uint32_t n_pages = 1u << lp;
   // partitions = groups of 2^coarse sibling pages: fewer, longer output runs for the scatter
   static const int max_log_parts = env_int("SHK_PART_LOG", 13);
-  static const int sorted_scatter = env_int("SHK_SORTED_SCATTER", 1);
   static const uint32_t g_cap = (uint32_t)env_int("SHK_PART_G", 768);
   const uint32_t log_parts = std::min<uint32_t>(lp, (uint32_t)max_log_parts);
   const uint32_t coarse = lp - log_parts;
@@ -360,8 +359,10 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const uint32_t G = grid_for(b.tile_count, 1, g_cap);
   const size_t counts_b = (size_t)G * P * 4, totals_b = (size_t)P * 8, base_b = (size_t)(P + 1) * 8;
   HIPC(c, c->part_meta.ensure(2 * counts_b + totals_b + base_b + 64));
-  HIPC(c, c->part.ensure(sub_kmers_ub * 8));
-  HIPC(c, c->part2.ensure(sub_kmers_ub * 8));  // k_pages miss queues (same offsets as part)
+  // every (tile, partition) run may carry one padding record
+  const uint64_t rec_ub = sub_kmers_ub + (uint64_t)b.tile_count * P + 2;
+  HIPC(c, c->part.ensure(rec_ub * 8));
+  HIPC(c, c->part2.ensure(rec_ub * 8));  // k_pages miss queues (same offsets as part)
   uint8_t *m = (uint8_t *)c->part_meta.p;
   uint32_t *counts = (uint32_t *)m;
   uint32_t *offs = (uint32_t *)(m + counts_b);
@@ -373,7 +374,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   HIPC(c, c->misc.ensure((size_t)G * 64));
   dbg = (unsigned long long *)c->misc.p;
 #endif
-  const size_t lds_count = STAGE_BYTES + (size_t)P * 4;
+  const size_t lds_count = STAGE_BYTES + (size_t)P * 8;
   const size_t lds_sorted = SORT_REGION + (size_t)PACK_WORDS * 4 + (size_t)P * 12;
   const bool multi = b.tiles != nullptr;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
@@ -392,15 +393,10 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     }
     {
       ScopedTimer t(c, SHK_K_SCATTER);
-      if (sorted_scatter)
-        hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b,
-                           log_parts, lane, (const uint32_t *)offs,
-                           (const unsigned long long *)part_base, part_buf,
-                           (const DevStats *)c->d_stats, dbg);
-      else
-        hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(WG), lds_count, c->stream, b, log_parts,
-                           lane, (const uint32_t *)offs, (const unsigned long long *)part_base,
-                           part_buf, (const DevStats *)c->d_stats);
+      hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b,
+                         log_parts, lane, (const uint32_t *)offs,
+                         (const unsigned long long *)part_base, part_buf,
+                         (const DevStats *)c->d_stats, dbg);
     }
     {
       ScopedTimer t(c, SHK_K_PAGES);
