@@ -19,8 +19,8 @@
 namespace shk {
 
 constexpr uint64_t EMPTY = 0xFFFFFFFFFFFFFFFFull;  // never a k-mer: k<32 ⇒ key < 2^62
-constexpr int PAGE_LOG = 12;
-constexpr uint32_t PAGE_SLOTS = 1u << PAGE_LOG;     // 4096 slots: 32 KiB keys + 16 KiB vals in LDS
+constexpr int PAGE_LOG = 13;
+constexpr uint32_t PAGE_SLOTS = 1u << PAGE_LOG;     // 8192 slots: 64 KiB keys + 32 KiB counts in LDS
 constexpr int WG = 256;                             // 4 waves
 constexpr int TILE_T = 16384;                       // k-mer end positions per tile
 constexpr int HALO = 32;                            // ≥ k-1 bases before the tile (k ≤ 31)
@@ -77,7 +77,7 @@ struct SpillRef {
 // multiply finaliser.  Page = top log_pages bits, in-page home slot = the next 12.
 // tools/hash_eval.py: page occupancy and slot collisions match a Poisson process on random,
 // AT-rich, tandem-repeat and sequential keys (without the finaliser sequential keys collide).
-constexpr uint32_t MAX_LOG_PAGES = 20;  // log_pages + PAGE_LOG ≤ 32 hash bits
+constexpr uint32_t MAX_LOG_PAGES = 19;  // log_pages + PAGE_LOG ≤ 32 hash bits
 __device__ __forceinline__ uint32_t hash64(uint64_t key) {
   const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
   const uint32_t c0 = lo & 0xFFFFFFu;
@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(WG) k_synth(SynthSpec sp, uint64_t first_read,
 
 // ##########################################################################################
 // Paged path: the table is a sequence of PAGE_SLOTS-slot pages, each an independent
-// open-addressing table that fits in LDS (32 KiB keys + 16 KiB counts).  One counting pass =
+// open-addressing table that fits in LDS (64 KiB keys + 32 KiB counts).  One counting pass =
 //   K_SCATTER  a) k_part_count    extract k-mers, count them per page      (LDS histogram)
 //              b) k_part_scan1/2  exclusive scans → a private, contiguous output run for
 //                                 every (workgroup, page): no global atomics anywhere
@@ -922,8 +922,8 @@ __global__ void __launch_bounds__(WG) k_synth(SynthSpec sp, uint64_t first_read,
 // ##########################################################################################
 namespace shk {
 
-constexpr int MAX_PARTS = 8192;   // pages addressable by the LDS page histogram (32 KiB)
-constexpr int PG_WG = 512;        // k_pages workgroup: 8 waves, 3 workgroups per CU by LDS
+constexpr int MAX_PARTS = 4096;   // pages addressable by the LDS partition counters
+constexpr int PG_WG = 1024;       // k_pages workgroup: 16 waves, one workgroup (96 KiB LDS) per CU
 constexpr uint32_t PAGE_FILL_CAP = PAGE_SLOTS - PAGE_SLOTS / 8;  // new keys spill beyond this
 
 template <int NT>
