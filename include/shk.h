@@ -226,6 +226,76 @@ typedef struct shk_synth {
 int shk_synth_reads_device(shk_ctx *ctx, const shk_synth *spec, uint64_t first_read,
                            uint64_t n_reads, void *d_bases, void *d_offsets);
 
+/* ---- host side either side of the path --------------------------------- */
+
+/* FASTQ(.gz) front-end: read_fastq / open_fastq_reader / validate_fastq_record
+ * (io.rs:161-198, 271-352, 598-625).  Parses only; state (read count, validation cadence,
+ * --max-reads) persists across files like FastqReadState (io.rs:498-512).  n_paths == 0 reads
+ * stdin (io.rs:517-537).  Errors carry the reference's texts (shk_fastq_error). */
+typedef struct shk_fastq shk_fastq;
+int shk_fastq_open(const char *const *paths, uint32_t n_paths, uint64_t max_reads,
+                   uint64_t validate_every, shk_fastq **out);
+void shk_fastq_close(shk_fastq *r);
+const char *shk_fastq_error(const shk_fastq *r);
+/* Up to max_seqs sequences / bases_cap bytes, in input order; offsets[0] = 0.  A sequence that
+ * does not fit is delivered first by the next call. */
+int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint64_t *offsets,
+                         uint64_t max_seqs, uint64_t *n_seqs);
+int shk_fastq_stats(const shk_fastq *r, uint64_t *n_reads_read, uint64_t *n_bases_read,
+                    int *reached_max, int *done);
+
+/* {sample}.histo / {sample}.final.histo, io.rs:1009-1014, 1051-1094 (byte for byte). */
+int shk_write_histo(const char *path, const char *version, uint32_t k, uint32_t chunks,
+                    uint64_t histo_max, const uint64_t *histo);
+int shk_write_final_histo(const char *path, const char *version, uint32_t k, uint32_t chunks,
+                          uint64_t histo_max, const uint64_t *histo);
+
+/* RunStats (stats.rs:27-45) as filled at main.rs:182-197; pcr_results is always empty here. */
+typedef struct shk_run_stats {
+  const char *sharkmer_version;
+  const char *command;
+  const char *sample;
+  uint32_t kmer_length;
+  uint32_t chunks;
+  uint64_t n_reads_read;
+  uint64_t n_bases_read;
+  uint64_t n_subreads_ingested;
+  uint64_t n_bases_ingested;
+  uint64_t n_kmers;
+  uint64_t n_multi_kmers;      /* written only when has_histogram (chunks > 0) */
+  uint64_t n_singleton_kmers;  /* idem */
+  uint64_t peak_memory_bytes;  /* device memory in use at the end of the run */
+  uint32_t has_histogram;
+  uint32_t reserved;
+} shk_run_stats;
+int shk_write_stats_yaml(const char *path, const shk_run_stats *st); /* stats.rs:186-193 */
+
+/* cli.rs:659-673 + 645-652: 0<k<32, k odd, 0<histo_max≤1e6, sample-name charset; the message is
+ * available from shk_run_error(). */
+int shk_validate_args(uint32_t k, uint64_t histo_max, const char *sample);
+const char *shk_run_error(void);
+
+/* ingest_reads + consolidate_and_histogram + write_stats over local files (main.rs:74-78,
+ * 112-197 without sPCR): the flags -k --chunks --histo-max -m -s -o --validate-every. */
+typedef struct shk_run_config {
+  const char *const *inputs; /* FASTQ(.gz) paths; n_inputs == 0 ⇒ stdin */
+  uint32_t n_inputs;
+  uint32_t k;
+  uint32_t chunks;
+  int32_t device;
+  uint64_t histo_max;
+  uint64_t max_reads;       /* 0 = all */
+  uint64_t validate_every;  /* 0 = first record only */
+  const char *sample;
+  const char *outdir;       /* NULL = "./" */
+  const char *command;      /* recorded in stats.yaml */
+  const char *version;      /* NULL = "3.1.0" */
+  uint64_t table_capacity_hint;
+  uint64_t batch_reads;     /* reads per device super-batch; 0 = 1,000,000 */
+  uint64_t batch_bases;     /* pinned buffer bytes; 0 = 256 MiB */
+} shk_run_config;
+int shk_run_files(const shk_run_config *cfg, shk_run_stats *out_stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -172,6 +172,8 @@ def lib():
     L.orc_run_write_histo.restype = C.c_int
     L.orc_run_write_final_histo.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
     L.orc_run_write_final_histo.restype = C.c_int
+    L.orc_run_write_stats_yaml.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
+    L.orc_run_write_stats_yaml.restype = C.c_int
     _lib = L
     return L
 
@@ -429,6 +431,10 @@ class Run:
 
     def write_final_histo(self, path, version="3.1.0"):
         self._check(lib().orc_run_write_final_histo(self._p, path.encode(), version.encode()))
+
+    def write_stats_yaml(self, path, command, sample, peak_memory_bytes=0, version="3.1.0"):
+        self._check(lib().orc_run_write_stats_yaml(self._p, path.encode(), version.encode(),
+                                                   command.encode(), sample.encode(), peak_memory_bytes))
 
 
 def run_batch(bases: np.ndarray, offsets: np.ndarray, k: int, chunks: int, histo_max: int = 10000):

@@ -996,3 +996,31 @@ int orc_run_write_final_histo(const orc_run *r, const char *path, const char *ve
   fclose(f);
   return ORC_OK;
 }
+
+/* stats.rs:27-45,186-193 with main.rs:182-197 — RunStats as YAML, field order of the struct;
+ * n_multi_kmers / n_singleton_kmers only when chunks > 0; pcr_results omitted when empty. */
+int orc_run_write_stats_yaml(const orc_run *r, const char *path, const char *version,
+                             const char *command, const char *sample, uint64_t peak_memory_bytes) {
+  if (!r->finished) return ORC_ERR_INVARIANT;
+  FILE *f = fopen(path, "w");
+  if (!f) return ORC_ERR_IO;
+  fprintf(f, "sharkmer_version: %s\n", version);
+  fprintf(f, "command: %s\n", command);
+  fprintf(f, "sample: %s\n", sample);
+  fprintf(f, "kmer_length: %d\n", r->k);
+  fprintf(f, "chunks: %u\n", r->chunks_arg);
+  fprintf(f, "n_reads_read: %llu\n", (unsigned long long)r->st.n_reads_read);
+  fprintf(f, "n_bases_read: %llu\n", (unsigned long long)r->st.n_bases_read);
+  fprintf(f, "n_subreads_ingested: %llu\n", (unsigned long long)r->st.n_reads_ingested);
+  fprintf(f, "n_bases_ingested: %llu\n", (unsigned long long)r->st.n_bases_ingested);
+  fprintf(f, "n_kmers: %llu\n", (unsigned long long)r->st.n_kmers_ingested);
+  if (r->chunks_arg > 0) {
+    uint64_t s1 = r->st.n_singleton_kmers;
+    uint64_t multi = r->st.n_kmers_ingested >= s1 ? r->st.n_kmers_ingested - s1 : 0; /* saturating_sub */
+    fprintf(f, "n_multi_kmers: %llu\n", (unsigned long long)multi);
+    fprintf(f, "n_singleton_kmers: %llu\n", (unsigned long long)s1);
+  }
+  fprintf(f, "peak_memory_bytes: %llu\n", (unsigned long long)peak_memory_bytes);
+  fclose(f);
+  return ORC_OK;
+}

@@ -146,6 +146,9 @@ int orc_run_read_fastq(orc_run *r, const char *path, uint64_t max_reads,
 /* Writers (io.rs:1051-1094; stats.rs:27-45,186-193). version e.g. "3.1.0". */
 int orc_run_write_histo(const orc_run *r, const char *path, const char *version);
 int orc_run_write_final_histo(const orc_run *r, const char *path, const char *version);
+/* stats.rs:27-45,186-193 (plain scalars only: command/sample without YAML specials) */
+int orc_run_write_stats_yaml(const orc_run *r, const char *path, const char *version,
+                             const char *command, const char *sample, uint64_t peak_memory_bytes);
 
 #ifdef __cplusplus
 }

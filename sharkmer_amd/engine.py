@@ -60,6 +60,24 @@ class _Timings(C.Structure):
     _fields_ = [("ms", C.c_double * 16), ("launches", C.c_uint64 * 16)]
 
 
+class _RunStats(C.Structure):
+    _fields_ = [("sharkmer_version", C.c_char_p), ("command", C.c_char_p), ("sample", C.c_char_p),
+                ("kmer_length", C.c_uint32), ("chunks", C.c_uint32), ("n_reads_read", C.c_uint64),
+                ("n_bases_read", C.c_uint64), ("n_subreads_ingested", C.c_uint64),
+                ("n_bases_ingested", C.c_uint64), ("n_kmers", C.c_uint64), ("n_multi_kmers", C.c_uint64),
+                ("n_singleton_kmers", C.c_uint64), ("peak_memory_bytes", C.c_uint64),
+                ("has_histogram", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class _RunConfig(C.Structure):
+    _fields_ = [("inputs", C.POINTER(C.c_char_p)), ("n_inputs", C.c_uint32), ("k", C.c_uint32),
+                ("chunks", C.c_uint32), ("device", C.c_int32), ("histo_max", C.c_uint64),
+                ("max_reads", C.c_uint64), ("validate_every", C.c_uint64), ("sample", C.c_char_p),
+                ("outdir", C.c_char_p), ("command", C.c_char_p), ("version", C.c_char_p),
+                ("table_capacity_hint", C.c_uint64), ("batch_reads", C.c_uint64),
+                ("batch_bases", C.c_uint64)]
+
+
 class _Synth(C.Structure):
     _fields_ = [("seed_genome", C.c_uint64), ("seed_reads", C.c_uint64), ("genome_len", C.c_uint64),
                 ("read_len", C.c_uint32), ("sub_per_64k", C.c_uint32), ("n_per_64k", C.c_uint32),
@@ -74,6 +92,9 @@ ABI_SYMBOLS = [
     "shk_export_table", "shk_lookup", "shk_table_geometry", "shk_table_reserve_pages",
     "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
     "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_synth_reads_device",
+    "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_stats",
+    "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
+    "shk_run_error", "shk_run_files",
 ]
 
 _lib = None
@@ -150,6 +171,20 @@ def load_library():
     L.shk_free_device.argtypes = [vp, vp]
     L.shk_free_device.restype = None
     L.shk_synth_reads_device.argtypes = [vp, C.POINTER(_Synth), u64, u64, vp, vp]
+    L.shk_fastq_open.argtypes = [C.POINTER(C.c_char_p), u32, u64, u64, C.POINTER(vp)]
+    L.shk_fastq_close.argtypes = [vp]
+    L.shk_fastq_close.restype = None
+    L.shk_fastq_error.argtypes = [vp]
+    L.shk_fastq_error.restype = C.c_char_p
+    L.shk_fastq_next_batch.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.shk_fastq_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.shk_write_histo.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, vp]
+    L.shk_write_final_histo.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, vp]
+    L.shk_write_stats_yaml.argtypes = [C.c_char_p, C.POINTER(_RunStats)]
+    L.shk_validate_args.argtypes = [u32, u64, C.c_char_p]
+    L.shk_run_error.argtypes = []
+    L.shk_run_error.restype = C.c_char_p
+    L.shk_run_files.argtypes = [C.POINTER(_RunConfig), C.POINTER(_RunStats)]
     for name in ABI_SYMBOLS:
         getattr(L, name)  # AttributeError here = the .so is stale
     _lib = L
@@ -359,3 +394,99 @@ class KmerEngine:
                    sub_per_64k=spec.sub_per_64k, n_per_64k=spec.n_per_64k)
         self._check(self._L.shk_synth_reads_device(self._h, C.byref(s), first_read, n_reads,
                                                    d_bases, d_offsets))
+
+
+# ---- host side either side of the path: FASTQ front-end, writers, whole-run driver -----------------
+
+class FastqReader:
+    """read_fastq / open_fastq_reader (io.rs:271-352, 598-625) through libshk's C++ host.
+    Parses only (no GPU needed)."""
+
+    def __init__(self, paths, max_reads: int = 0, validate_every: int = 0):
+        self._L = load_library()
+        arr = (C.c_char_p * max(len(paths), 1))(*[os.fsencode(p) for p in paths])
+        h = C.c_void_p()
+        rc = self._L.shk_fastq_open(arr, len(paths), max_reads, validate_every, C.byref(h))
+        if rc != 0:
+            raise ShkError(rc, "shk_fastq_open failed")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.shk_fastq_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def next_batch(self, max_seqs: int = 1_000_000, max_bases: int = 64 << 20):
+        bases = np.empty(max_bases, dtype=np.uint8)
+        offsets = np.zeros(max_seqs + 1, dtype=np.uint64)
+        n = C.c_uint64(0)
+        rc = self._L.shk_fastq_next_batch(self._h, bases.ctypes.data, max_bases, offsets.ctypes.data,
+                                          max_seqs, C.byref(n))
+        if rc != 0:
+            raise ShkError(rc, (self._L.shk_fastq_error(self._h) or b"").decode("utf-8", "replace"))
+        n = int(n.value)
+        return bases[:int(offsets[n])].copy(), offsets[:n + 1].copy()
+
+    def stats(self) -> dict:
+        a, b, m, d = C.c_uint64(0), C.c_uint64(0), C.c_int(0), C.c_int(0)
+        self._L.shk_fastq_stats(self._h, C.byref(a), C.byref(b), C.byref(m), C.byref(d))
+        return {"n_reads_read": int(a.value), "n_bases_read": int(b.value),
+                "reached_max": bool(m.value), "done": bool(d.value)}
+
+
+def write_histo(path: str, histo: np.ndarray, k: int, histo_max: int, version: str = "3.1.0"):
+    h = np.ascontiguousarray(histo, dtype=np.uint64)
+    rc = load_library().shk_write_histo(os.fsencode(path), version.encode(), k, h.shape[0], histo_max,
+                                        h.ctypes.data)
+    if rc != 0:
+        raise ShkError(rc, "shk_write_histo failed")
+
+
+def write_final_histo(path: str, histo: np.ndarray, k: int, histo_max: int, version: str = "3.1.0"):
+    h = np.ascontiguousarray(histo, dtype=np.uint64)
+    rc = load_library().shk_write_final_histo(os.fsencode(path), version.encode(), k, h.shape[0],
+                                              histo_max, h.ctypes.data)
+    if rc != 0:
+        raise ShkError(rc, "shk_write_final_histo failed")
+
+
+def write_stats_yaml(path: str, **f):
+    st = _RunStats(sharkmer_version=f.get("sharkmer_version", "3.1.0").encode(),
+                   command=f.get("command", "").encode(), sample=f.get("sample", "").encode(),
+                   kmer_length=f["kmer_length"], chunks=f["chunks"], n_reads_read=f["n_reads_read"],
+                   n_bases_read=f["n_bases_read"], n_subreads_ingested=f["n_subreads_ingested"],
+                   n_bases_ingested=f["n_bases_ingested"], n_kmers=f["n_kmers"],
+                   n_multi_kmers=f.get("n_multi_kmers", 0), n_singleton_kmers=f.get("n_singleton_kmers", 0),
+                   peak_memory_bytes=f.get("peak_memory_bytes", 0),
+                   has_histogram=1 if f.get("has_histogram", f["chunks"] > 0) else 0)
+    rc = load_library().shk_write_stats_yaml(os.fsencode(path), C.byref(st))
+    if rc != 0:
+        raise ShkError(rc, "shk_write_stats_yaml failed")
+
+
+def validate_args(k: int, histo_max: int, sample):
+    """cli.rs:659-673 + 645-652; raises ShkError with the reference's message."""
+    L = load_library()
+    rc = L.shk_validate_args(k, histo_max, None if sample is None else sample.encode())
+    if rc != 0:
+        raise ShkError(rc, (L.shk_run_error() or b"").decode("utf-8", "replace"))
+
+
+def run_files(inputs, k: int, chunks: int, sample: str, outdir: str = "./", histo_max: int = 10000,
+              max_reads: int = 0, validate_every: int = 0, device: int = 0, capacity_hint: int = 0,
+              command: str = "", batch_reads: int = 0, batch_bases: int = 0) -> dict:
+    """main.rs:112-197 without sPCR: FASTQ files → counts → .histo/.final.histo/.stats.yaml."""
+    L = load_library()
+    arr = (C.c_char_p * max(len(inputs), 1))(*[os.fsencode(p) for p in inputs])
+    cfg = _RunConfig(inputs=arr, n_inputs=len(inputs), k=k, chunks=chunks, device=device,
+                     histo_max=histo_max, max_reads=max_reads, validate_every=validate_every,
+                     sample=None if sample is None else sample.encode(), outdir=os.fsencode(outdir),
+                     command=command.encode(), version=None, table_capacity_hint=capacity_hint,
+                     batch_reads=batch_reads, batch_bases=batch_bases)
+    st = _RunStats()
+    rc = L.shk_run_files(C.byref(cfg), C.byref(st))
+    if rc != 0:
+        raise ShkError(rc, (L.shk_run_error() or b"").decode("utf-8", "replace"))
+    return {f: int(getattr(st, f)) for f, t in _RunStats._fields_ if t in (C.c_uint32, C.c_uint64)}
