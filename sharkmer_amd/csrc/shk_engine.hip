@@ -570,7 +570,8 @@ int shk_reset(shk_ctx *c) {
   c->h_stats->bad = ~0ull;
   HIPC(c, hipMemcpyAsync(c->d_stats, c->h_stats, sizeof(DevStats), hipMemcpyHostToDevice, c->stream));
   HIPC(c, hipMemsetAsync(c->d_lane_bases, 0, sizeof(unsigned long long) * c->n_lanes, c->stream));
-  HIPC(c, hipStreamSynchronize(c->stream));
+  // no host sync: everything later is ordered behind these on the engine stream; h_stats is
+  // re-read (read_stats) before the host looks at it again
   std::fill(c->lane_reads.begin(), c->lane_reads.end(), 0);
   c->n_reads_read = c->n_bases_read = 0;
   c->n_inserted = 0;
