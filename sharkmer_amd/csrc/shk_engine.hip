@@ -21,6 +21,10 @@ using namespace shk;
 
 struct shk_ctx;
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub);
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 
 namespace {
 
@@ -68,7 +72,9 @@ struct shk_ctx {
   HistoTotals h_tot{};
   std::vector<uint64_t> h_hist;
   // scratch
-  DevBuf in_bases, in_offsets, startbits, tiles, spillA, spillB, misc, part, part2, part_meta;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_done[2] = {nullptr, nullptr};
+  DevBuf in_bases, in_offsets, in_bases2, in_offsets2, startbits, tiles, spillA, spillB, misc, part, part2, part_meta;
   // host counters
   std::vector<uint64_t> lane_reads;
   uint64_t n_reads_read = 0, n_bases_read = 0;
@@ -340,11 +346,6 @@ static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
   return c->tb.log_pages >= 8 && sub_kmers_ub >= c->tb.cap / 2;
 }
 
-static int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 constexpr int SC_NT = 512;  // threads of the partition count / sorted scatter workgroups
 
 static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp) {
@@ -549,6 +550,11 @@ void shk_destroy(shk_ctx *c) {
   if (c->d_tot) (void)hipFree(c->d_tot);
   c->in_bases.release();
   c->in_offsets.release();
+  c->in_bases2.release();
+  c->in_offsets2.release();
+  if (c->copy_done[0]) (void)hipEventDestroy(c->copy_done[0]);
+  if (c->copy_done[1]) (void)hipEventDestroy(c->copy_done[1]);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   c->startbits.release();
   c->tiles.release();
   c->spillA.release();
@@ -582,30 +588,75 @@ int shk_reset(shk_ctx *c) {
   return SHK_OK;
 }
 
+// Host buffers → device → count.  A large batch is streamed in slices of whole reads through two
+// device staging buffers: slice i+1 crosses PCIe on the copy stream while slice i is being
+// counted on the engine stream (BASELINE.json configs[2]: "streamed chunks with copy/compute
+// overlap").  Striping is unaffected: ingest_core advances the running read index per slice.
 static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
                        int64_t lane_fixed) {
   if (!c) return SHK_ERR_BAD_ARG;
   if (n_seqs && (!offsets)) return fail(c, SHK_ERR_BAD_ARG, "null offsets");
   HIPC(c, hipSetDevice(c->cfg.device));
   if (n_seqs == 0) return ingest_core(c, nullptr, nullptr, 0, 0, lane_fixed);
-  const uint64_t o0 = offsets[0];
-  const uint64_t n_bases = offsets[n_seqs] - o0;
-  if (n_bases && !bases) return fail(c, SHK_ERR_BAD_ARG, "null bases");
-  HIPC(c, c->in_bases.ensure(n_bases + 64));
-  HIPC(c, c->in_offsets.ensure((n_seqs + 1) * 8));
-  const uint64_t *offs = offsets;
-  std::vector<uint64_t> rebased;
-  if (o0 != 0) {  // device code indexes the staged copy from 0
-    rebased.resize(n_seqs + 1);
-    for (uint64_t i = 0; i <= n_seqs; ++i) rebased[i] = offsets[i] - o0;
-    offs = rebased.data();
+  const uint64_t n_bases_all = offsets[n_seqs] - offsets[0];
+  if (n_bases_all && !bases) return fail(c, SHK_ERR_BAD_ARG, "null bases");
+  const uint64_t slice_kb = (uint64_t)env_int("SHK_SLICE_KB", 256 << 10);  // test hook: tiny slices
+  const uint64_t slice_bases = slice_kb << 10;
+  // slice boundaries at read boundaries, ≈ slice_bases each
+  std::vector<uint64_t> cut{0};
+  while (cut.back() < n_seqs) {
+    uint64_t lo = cut.back(), hi = n_seqs;
+    const uint64_t limit = offsets[lo] + slice_bases;
+    if (offsets[n_seqs] > limit) {  // largest hi with offsets[hi] ≤ limit, at least one read
+      hi = (uint64_t)(std::upper_bound(offsets + lo, offsets + n_seqs + 1, limit) - offsets) - 1;
+      if (hi <= lo) hi = lo + 1;
+    }
+    cut.push_back(hi);
   }
-  if (n_bases)
-    HIPC(c, hipMemcpyAsync(c->in_bases.p, bases + o0, n_bases, hipMemcpyHostToDevice, c->stream));
-  HIPC(c, hipMemcpyAsync(c->in_offsets.p, offs, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  HIPC(c, hipStreamSynchronize(c->stream));  // `rebased` and caller buffers may go away
-  return ingest_core(c, (const uint8_t *)c->in_bases.p, (const uint64_t *)c->in_offsets.p, n_seqs,
-                     n_bases, lane_fixed);
+  const size_t n_slices = cut.size() - 1;
+  if (!c->copy_stream) HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->copy_done[0]) {
+    HIPC(c, hipEventCreateWithFlags(&c->copy_done[0], hipEventDisableTiming));
+    HIPC(c, hipEventCreateWithFlags(&c->copy_done[1], hipEventDisableTiming));
+  }
+  std::vector<uint64_t> rebased[2];
+  auto issue_copy = [&](size_t i) -> int {
+    const int bsel = (int)(i & 1);
+    const uint64_t r0 = cut[i], r1 = cut[i + 1];
+    const uint64_t o0 = offsets[r0], nb = offsets[r1] - o0, ns = r1 - r0;
+    DevBuf &db = bsel ? c->in_bases2 : c->in_bases;
+    DevBuf &dof = bsel ? c->in_offsets2 : c->in_offsets;
+    HIPC(c, db.ensure(nb + 64));
+    HIPC(c, dof.ensure((ns + 1) * 8));
+    rebased[bsel].resize(ns + 1);  // device code indexes the staged copy from 0
+    for (uint64_t j = 0; j <= ns; ++j) rebased[bsel][j] = offsets[r0 + j] - o0;
+    if (nb) HIPC(c, hipMemcpyAsync(db.p, bases + o0, nb, hipMemcpyHostToDevice, c->copy_stream));
+    HIPC(c, hipMemcpyAsync(dof.p, rebased[bsel].data(), (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
+    HIPC(c, hipEventRecord(c->copy_done[bsel], c->copy_stream));
+    return SHK_OK;
+  };
+  int rc = issue_copy(0);
+  if (rc != SHK_OK) return rc;
+  for (size_t i = 0; i < n_slices; ++i) {
+    const int bsel = (int)(i & 1);
+    // the other buffer is free: slice i-1 was counted synchronously.  Its copy now overlaps
+    // the counting of slice i.
+    HIPC(c, hipEventSynchronize(c->copy_done[bsel]));  // `rebased[bsel]` consumed; data resident
+    if (i + 1 < n_slices) {
+      rc = issue_copy(i + 1);
+      if (rc != SHK_OK) return rc;
+    }
+    const uint64_t r0 = cut[i], r1 = cut[i + 1];
+    DevBuf &db = bsel ? c->in_bases2 : c->in_bases;
+    DevBuf &dof = bsel ? c->in_offsets2 : c->in_offsets;
+    rc = ingest_core(c, (const uint8_t *)db.p, (const uint64_t *)dof.p, r1 - r0, offsets[r1] - offsets[r0],
+                     lane_fixed);
+    if (rc != SHK_OK) {
+      (void)hipStreamSynchronize(c->copy_stream);  // do not leave a copy reading `rebased` behind
+      return rc;
+    }
+  }
+  return SHK_OK;
 }
 
 int shk_ingest_batch(shk_ctx *c, uint32_t chunk_id, const uint8_t *bases, const uint64_t *offsets,

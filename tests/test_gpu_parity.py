@@ -295,3 +295,41 @@ def test_config2_full_size(orc, flags):
     col = got[0].astype(object)
     assert sum(int(f) * i for i, f in enumerate(col)) == 130 * n  # no count exceeds histo_max here
     assert int(got[0].sum()) == cnt["n_unique_kmers"]
+
+
+# ---- BASELINE.json config 3 semantics: host input streamed in slices, copy/compute overlap ------------
+
+@pytest.mark.parametrize("k,chunks", [(31, 1), (21, 4)])
+def test_streamed_slices_match_oracle(orc, monkeypatch, k, chunks):
+    """A large host batch crosses PCIe in slices of whole reads (double-buffered, the next slice
+    copying while the current one is counted); forcing 64 KiB slices exercises many slice
+    boundaries, including ones inside a 1000-read block."""
+    monkeypatch.setenv("SHK_SLICE_KB", "64")
+    rng = np.random.default_rng(99)
+    bases, offsets = ragged_reads(rng, 20_000, max_len=160)
+    check_against_oracle(orc, bases, offsets, k, chunks, 60, check_table=False)
+
+
+def test_config3_shape_k31_properties():
+    """k=31 at a size the oracle would take minutes for: size-independent properties only —
+    Σ freq·count = k-mer occurrences, Σ freq = distinct, chunk-count invariance of the final
+    column, error-free 150-bp reads ⇒ 120 k-mers per read."""
+    spec = sa.SynthSpec(genome_len=20_000_000)
+    n = 3_000_000
+    finals = []
+    for chunks in (1, 6):
+        with sa.KmerEngine(31, chunks, 2000, capacity_hint=20_000_000) as eng:
+            for part in range(3):  # three host batches, generated on the fly
+                b, o = sa.synth_reads(spec, part * (n // 3), n // 3)
+                eng.ingest_reads(b, o)
+            eng.finalize()
+            h = eng.histograms()
+            c = eng.counters()
+        assert c["n_kmers_ingested"] == 120 * n
+        last = h[-1].astype(object)
+        assert sum(int(f) * i for i, f in enumerate(last)) == 120 * n
+        assert int(h[-1].sum()) == c["n_unique_kmers"]
+        for j in range(1, chunks):  # cumulative columns only ever gain k-mers
+            assert int(h[j].sum()) >= int(h[j - 1].sum())
+        finals.append(h[-1])
+    assert np.array_equal(finals[0], finals[1])
