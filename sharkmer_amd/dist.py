@@ -67,6 +67,10 @@ class DistCounter:
         dist.all_to_all_single(rk, keys)
         for l in range(n_lanes):
             dist.all_to_all_single(rv[l], vals[l])
+        if rk.is_cuda:
+            # RCCL enqueues on torch's stream; the merge below runs on the engine's own HIP
+            # stream, so the received slices must have landed before it is launched
+            torch.cuda.synchronize()
         p0, p1 = self.rank * per, (self.rank + 1) * per
         for s in range(W):
             if s == self.rank:
