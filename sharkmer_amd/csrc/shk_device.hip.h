@@ -435,16 +435,15 @@ __device__ __forceinline__ int64_t find_slot(const uint64_t *keys, uint64_t base
   return -1;
 }
 
-// saturating add of an arbitrary delta (counting.rs:82-92 semantics) by CAS
-__device__ __forceinline__ void sat_add_cas(uint32_t *p, uint32_t delta) {
-  uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (;;) {
-    uint32_t nv = sat_add_u32(old, delta);
-    if (nv == old) return;
-    uint32_t prev = atomicCAS(p, old, nv);
-    if (prev == old) return;
-    old = prev;
-  }
+// Saturating add of an arbitrary delta (counting.rs:82-92 semantics) without a CAS loop (a CAS
+// loop livelocks for seconds when millions of records hit one k-mer, e.g. poly-A input): a
+// returning add, and if that add wrapped the slot (old > MAX - delta) a repair with
+// atomicMax(MAX).  Every wrapping add is followed by its own repair and an add that lands after
+// a repair wraps again and repairs again, so the last operation on a saturated slot leaves MAX.
+__device__ __forceinline__ void sat_add_atomic(uint32_t *p, uint32_t delta) {
+  if (!delta) return;
+  uint32_t old = atomicAdd(p, delta);
+  if (old > 0xFFFFFFFFu - delta) atomicMax(p, 0xFFFFFFFFu);
 }
 
 // ==========================================================================================
@@ -642,7 +641,7 @@ __global__ void __launch_bounds__(WG) k_insert(const uint64_t *__restrict__ kmer
       continue;
     }
     n_new += inserted;
-    sat_add_cas(tb.vals + (uint64_t)lane * tb.cap + (uint64_t)s, cnt);
+    sat_add_atomic(tb.vals + (uint64_t)lane * tb.cap + (uint64_t)s, cnt);
   }
   for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
   if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&stats->n_distinct, (unsigned long long)n_new);
@@ -838,7 +837,7 @@ __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t n_slots, uin
     n_new += inserted;
     for (uint32_t l = 0; l < tb.n_lanes; ++l) {
       uint32_t v = pvals[(uint64_t)l * lane_stride + i];
-      if (v) sat_add_cas(tb.vals + (uint64_t)l * tb.cap + (uint64_t)s, v);
+      if (v) sat_add_atomic(tb.vals + (uint64_t)l * tb.cap + (uint64_t)s, v);
     }
   }
   for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
@@ -911,12 +910,12 @@ __global__ void __launch_bounds__(WG) k_synth(SynthSpec sp, uint64_t first_read,
 // ##########################################################################################
 // Paged path: the table is a sequence of PAGE_SLOTS-slot pages, each an independent
 // open-addressing table that fits in LDS (64 KiB keys + 32 KiB counts).  One counting pass =
-//   K_SCATTER  a) k_part_count    extract k-mers, count them per page      (LDS histogram)
-//              b) k_part_scan1/2  exclusive scans → a private, contiguous output run for
-//                                 every (workgroup, page): no global atomics anywhere
-//              c) k_part_scatter  extract again, append each k-mer to its page's run
-//   K_PAGES    k_pages            one workgroup per page: page → LDS, stream the page's run
-//                                 through LDS atomics, page → HBM
+//   K_SCATTER  k_part_scatter_sorted  validate + extract k-mers tile by tile, counting-sort each
+//                                     tile by page in LDS, append every page's run to that page's
+//                                     region of part_buf (reserved with one returning atomic per
+//                                     (tile, page)) as aligned 16-B record pairs
+//   K_PAGES    k_pages                one workgroup per page: page → LDS, stream the page's
+//                                     region through LDS atomics, page → HBM
 // HBM traffic per k-mer occurrence: 8 B written + 8 B read, all of it streaming; the table
 // is read and written once per pass.  counting.rs:82-85 semantics, exact incl. saturation.
 // ##########################################################################################
@@ -925,120 +924,6 @@ namespace shk {
 constexpr int MAX_PARTS = 4096;   // pages addressable by the LDS partition counters
 constexpr int PG_WG = 1024;       // k_pages workgroup: 16 waves, one workgroup (96 KiB LDS) per CU
 constexpr uint32_t PAGE_FILL_CAP = PAGE_SLOTS - PAGE_SLOTS / 8;  // new keys spill beyond this
-
-template <int NT>
-__global__ void __launch_bounds__(NT) k_part_count(BatchRef b, uint32_t log_pages /* = log2(#partitions) */,
-                                                   uint32_t lane_filter,
-                                                   uint32_t *__restrict__ counts,
-                                                   DevStats *__restrict__ stats,
-                                                   unsigned long long *__restrict__ lane_bases) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
-  __shared__ uint32_t red[NT / 64];
-  const uint32_t P = 1u << log_pages;
-  uint8_t *lds = reinterpret_cast<uint8_t *>(sh);   // TILE_LDS bytes (multiple of 16)
-  uint32_t *cnt = sh + STAGE_BYTES / 4;             // P counters
-  for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
-  __syncthreads();
-  // This pass also is the validation pass (encoding.rs:353-356) and the non-N base count
-  // (chunk.rs:28): both ride on the staging loads.  An invalid byte found by ANY workgroup
-  // stops k_part_scatter / k_pages (they test stats->bad), so the table stays untouched.
-  uint32_t n_non_n = 0;
-  uint32_t *tot_p = cnt + P;  // per-partition totals over this workgroup's tiles
-  for (uint32_t i = threadIdx.x; i < P; i += NT) tot_p[i] = 0;
-  uint64_t t = blockIdx.x, t0, t1;
-  uint32_t lane;
-  bool have = next_tile(b, t, true, lane_filter, t0, t1, lane);
-  StageRegs<NT> pre;
-  if (have) stage_prefetch<NT>(b, t0, pre);
-  while (have) {
-    __syncthreads();
-    n_non_n += stage_tile<true, NT>(b, t0, t1, lds, stats, pre);
-    uint64_t tn = t + gridDim.x, n0, n1;
-    uint32_t nl;
-    const bool hn = next_tile(b, tn, true, lane_filter, n0, n1, nl);
-    if (hn) stage_prefetch<NT>(b, n0, pre);
-    __syncthreads();
-    walk_tile<NT>(lds, t0, t1, b.k, [&](uint64_t kmer) {
-      atomicAdd(&cnt[(uint32_t)page_of(hash64(kmer), log_pages)], 1u);
-    });
-    __syncthreads();
-    // every (tile, partition) run is padded to an even length (16-B aligned record pairs)
-    for (uint32_t i = threadIdx.x; i < P; i += NT) {
-      tot_p[i] += (cnt[i] + 1u) & ~1u;
-      cnt[i] = 0;
-    }
-    t = tn;
-    t0 = n0;
-    t1 = n1;
-    lane = nl;
-    have = hn;
-  }
-  __syncthreads();
-  uint32_t tot = wg_sum<NT>(n_non_n, red);
-  if (threadIdx.x == 0 && tot) atomicAdd(&lane_bases[lane_filter], (unsigned long long)tot);
-  uint32_t *out = counts + (uint64_t)blockIdx.x * P;
-  for (uint32_t i = threadIdx.x; i < P; i += NT) out[i] = tot_p[i];
-}
-
-// exclusive scan over workgroups, per page: offs[g][p] = Σ_{g'<g} counts[g'][p] (the start
-// of workgroup g inside page p's run); totals[p] = run length.  One workgroup per 64 pages;
-// its 16 waves each own a 1/16 slice of the workgroups: slice sums, then slice-local scans.
-constexpr int SC_WAVES = 16;
-__global__ void __launch_bounds__(64 * SC_WAVES) k_part_scan1(const uint32_t *__restrict__ counts,
-                                                              uint32_t *__restrict__ offs,
-                                                              uint32_t G, uint32_t P,
-                                                              unsigned long long *__restrict__ totals) {
-  __shared__ uint32_t part[SC_WAVES][64];
-  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t p = blockIdx.x * 64 + lane;
-  const uint32_t per = (G + SC_WAVES - 1) / SC_WAVES;
-  const uint32_t g0 = w * per, g1 = g0 + per < G ? g0 + per : G;
-  uint32_t s = 0;
-  if (p < P)
-    for (uint32_t g = g0; g < g1; ++g) s += counts[(uint64_t)g * P + p];
-  part[w][lane] = s;
-  __syncthreads();
-  if (p >= P) return;
-  uint32_t run = 0, tot = 0;
-  for (uint32_t i = 0; i < SC_WAVES; ++i) {
-    uint32_t v = part[i][lane];
-    if (i < w) run += v;
-    tot += v;
-  }
-  for (uint32_t g = g0; g < g1; ++g) {
-    uint32_t c = counts[(uint64_t)g * P + p];
-    offs[(uint64_t)g * P + p] = run;
-    run += c;
-  }
-  if (w == 0) totals[p] = tot;
-}
-
-// exclusive scan over pages: part_base[p] = Σ_{q<p} totals[q]; part_base[P] = total
-__global__ void __launch_bounds__(1024) k_part_scan2(const unsigned long long *__restrict__ totals,
-                                                     uint32_t P,
-                                                     unsigned long long *__restrict__ part_base) {
-  __shared__ unsigned long long sc[1024];
-  const uint32_t per = (P + 1023) / 1024;
-  const uint32_t lo = threadIdx.x * per;
-  unsigned long long s = 0;
-  for (uint32_t i = 0; i < per; ++i)
-    if (lo + i < P) s += totals[lo + i];
-  sc[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    unsigned long long v = threadIdx.x >= (unsigned)d ? sc[threadIdx.x - d] : 0;
-    __syncthreads();
-    sc[threadIdx.x] += v;
-    __syncthreads();
-  }
-  unsigned long long run = sc[threadIdx.x] - s;
-  for (uint32_t i = 0; i < per; ++i)
-    if (lo + i < P) {
-      part_base[lo + i] = run;
-      run += totals[lo + i];
-    }
-  if (threadIdx.x == 1023) part_base[P] = sc[1023];
-}
 
 // ------------------------------------------------------------------------------------------
 // k_part_scatter_sorted: the same job as k_part_scatter, but every tile is counting-sorted by
@@ -1057,7 +942,12 @@ __global__ void __launch_bounds__(1024) k_part_scan2(const unsigned long long *_
 #define SORTED_WAVES_PER_SIMD 4
 #endif
 constexpr int PACK_WORDS = TILE_LDS / 16 + 2;  // 16 bases per u32, MSB first, + 2 pad words
-constexpr int SORT_REGION = 2 * TILE_T > STAGE_BYTES ? 2 * TILE_T : STAGE_BYTES;
+// LDS bytes of the sorted-entry region: TILE_T entries + one possible pad per page (u16), and it
+// doubles as the staging area (code bytes + group masks) before the sort
+__host__ __device__ inline uint32_t sort_region_bytes(uint32_t P) {
+  uint32_t a = 2u * ((uint32_t)TILE_T + P), b = (uint32_t)STAGE_BYTES;
+  return ((a > b ? a : b) + 15u) & ~15u;
+}
 
 __device__ __forceinline__ uint32_t pack4(uint32_t w) {  // 4 code bytes → 8 bits, first base on top
   return ((w & 3u) << 6) | (((w >> 8) & 3u) << 4) | (((w >> 16) & 3u) << 2) | ((w >> 24) & 3u);
@@ -1076,19 +966,21 @@ __device__ __forceinline__ uint64_t kmer_at(const uint32_t *packed, int j, int k
 
 template <int NT>
 __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sorted(
-    BatchRef b, uint32_t log_parts, uint32_t lane_filter, const uint32_t *__restrict__ offs,
-    const unsigned long long *__restrict__ part_base, uint64_t *__restrict__ part_buf,
-    const DevStats *__restrict__ stats, unsigned long long *__restrict__ dbg) {
+    BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
+    uint32_t cap_p, uint64_t *__restrict__ part_buf, DevStats *__restrict__ stats,
+    unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[NT / 64];
+  __shared__ uint32_t red[NT / 64];
   constexpr int SPAN = TILE_T / NT;
   const uint32_t P = 1u << log_parts;
-  uint8_t *codes = reinterpret_cast<uint8_t *>(sh);                 // SORT_REGION bytes
-  uint16_t *sorted = reinterpret_cast<uint16_t *>(sh);              // aliases codes
-  uint32_t *packed = sh + SORT_REGION / 4;                          // PACK_WORDS
+  const uint32_t sort_bytes = sort_region_bytes(P);
+  uint8_t *codes = reinterpret_cast<uint8_t *>(sh);                 // STAGE_BYTES ≤ sort_bytes
+  uint16_t *sorted = reinterpret_cast<uint16_t *>(sh);              // TILE_T + P entries; aliases codes
+  uint32_t *packed = sh + sort_bytes / 4;                           // PACK_WORDS
   uint32_t *cnt = packed + PACK_WORDS;                              // P
   uint32_t *tstart = cnt + P;                                       // P
-  uint32_t *gcur = tstart + P;                                      // P
+  uint32_t *gbase = tstart + P;                                     // P: this tile's reservation per page
 #ifdef SHK_PHASE_TIMING
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = 0;
@@ -1101,9 +993,10 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
 #else
 #define STAMP(i)
 #endif
-  if (stats->bad != ~0ull) return;
-  const uint32_t *mine = offs + (uint64_t)blockIdx.x * P;
-  for (uint32_t i = threadIdx.x; i < P; i += NT) gcur[i] = (uint32_t)part_base[i] + mine[i];
+  // This kernel is also the validation pass (encoding.rs:353-356) and the non-N base count
+  // (chunk.rs:28): both ride on the staging loads.  An invalid byte found by ANY workgroup
+  // keeps k_pages from running (it tests stats->bad), so the table stays untouched.
+  uint32_t n_non_n = 0;
   const int k = b.k;
   const uint64_t mask = (1ull << (2 * k)) - 1;
   const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
@@ -1120,7 +1013,7 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     tprev = __builtin_readcyclecounter();
 #endif
     for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
-    stage_tile<false, NT>(b, t0, t1, codes, nullptr, pre);
+    n_non_n += stage_tile<true, NT>(b, t0, t1, codes, stats, pre);
     uint64_t tn = t + gridDim.x, n0, n1;
     uint32_t nl;
     const bool hn = next_tile(b, tn, true, lane_filter, n0, n1, nl);
@@ -1193,6 +1086,13 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
           run += (cnt[lo + i] + 1u) & ~1u;
         }
     }
+    // reserve this tile's (even-padded) run in every page's output region: one returning
+    // device-scope add per non-empty (tile, page); consecutive lanes hit consecutive cursors.
+    // The results are first needed by the write phase, a barrier and the place phase later.
+    for (uint32_t i = threadIdx.x; i < P; i += NT) {
+      const uint32_t c2 = (cnt[i] + 1u) & ~1u;
+      gbase[i] = c2 ? atomicAdd(&cursor[i], c2) : 0u;
+    }
     __syncthreads();  // codes are dead from here: `sorted` may overwrite them
     STAMP(3);
     // ---- place (the odd runs' padding slot gets the sentinel 0xFFFF) ---------------------------
@@ -1215,19 +1115,38 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
       const uint64_t km0 = kmer_at(packed, HALO + (int)e0, k);
       const uint64_t km1 = e1 == 0xFFFFu ? EMPTY : kmer_at(packed, HALO + (int)e1, k);
       const uint32_t pc = (uint32_t)page_of(hash64(km0), log_parts);
-      ulonglong2 rec;
-      rec.x = km0;
-      rec.y = km1;
-      *reinterpret_cast<ulonglong2 *>(part_buf + gcur[pc] + (2 * i - tstart[pc])) = rec;
+      const uint32_t at = gbase[pc] + (2 * i - tstart[pc]);  // record index inside page pc's region
+      if (at + 2 <= cap_p) {
+        ulonglong2 rec;
+        rec.x = km0;
+        rec.y = km1;
+        *reinterpret_cast<ulonglong2 *>(part_buf + (uint64_t)pc * cap_p + at) = rec;
+      } else {  // the page's region is full (skewed input): these records take the spill path
+        const unsigned long long j = atomicAdd(&stats->spill_count, km1 == EMPTY ? 1ull : 2ull);
+        if (j < sp.cap) {
+          sp.keys[j] = km0;
+          sp.lanes[j] = lane;
+          sp.counts[j] = 1u;
+        }
+        if (km1 != EMPTY && j + 1 < sp.cap) {
+          sp.keys[j + 1] = km1;
+          sp.lanes[j + 1] = lane;
+          sp.counts[j + 1] = 1u;
+        }
+      }
     }
     __syncthreads();
     STAMP(5);
-    for (uint32_t i = threadIdx.x; i < P; i += NT) gcur[i] += (cnt[i] + 1u) & ~1u;
     t = tn;
     t0 = n0;
     t1 = n1;
     lane = nl;
     have = hn;
+  }
+  __syncthreads();
+  {
+    uint32_t tot = wg_sum<NT>(n_non_n, red);
+    if (threadIdx.x == 0 && tot) atomicAdd(&lane_bases[lane_filter], (unsigned long long)tot);
   }
 #ifdef SHK_PHASE_TIMING
   if (dbg && threadIdx.x == 0)
@@ -1282,7 +1201,7 @@ __device__ __forceinline__ void page_insert(uint64_t *keys, uint32_t *vals, uint
 // siblings are dispatched together on one XCD (ids equal mod 8 — speed only): the run is then
 // fetched from HBM once and re-read from that XCD's L2.
 __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uint32_t coarse,
-                                                 const unsigned long long *__restrict__ part_base,
+                                                 const unsigned int *__restrict__ cursor, uint32_t cap_p,
                                                  const uint64_t *__restrict__ part_buf,
                                                  uint64_t *__restrict__ miss_buf,
                                                  DevStats *__restrict__ stats, SpillRef sp) {
@@ -1302,7 +1221,8 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uin
     }
   }
   const bool filter = coarse != 0;
-  const uint64_t r0 = part_base[part], r1 = part_base[part + 1];
+  const uint32_t filled = cursor[part] < cap_p ? cursor[part] : cap_p;  // beyond cap_p: spilled
+  const uint64_t r0 = (uint64_t)part * cap_p, r1 = r0 + filled;
   if (r1 == r0) return;  // nothing for this page: leave it untouched in HBM
   uint64_t *gk = tb.keys + ((uint64_t)page << PAGE_LOG);
   uint32_t *gv = tb.vals + (uint64_t)lane * tb.cap + ((uint64_t)page << PAGE_LOG);

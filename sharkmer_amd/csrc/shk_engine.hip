@@ -350,59 +350,41 @@ constexpr int SC_NT = 512;  // threads of the partition count / sorted scatter w
 
 static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp) {
   const uint32_t lp = c->tb.log_pages;
-  const uint32_t n_pages = 1u << lp;
-  // partitions = groups of 2^coarse sibling pages: fewer, longer output runs for the scatter
-  static const int max_log_parts = env_int("SHK_PART_LOG", 13);
-  static const uint32_t g_cap = (uint32_t)env_int("SHK_PART_G", 768);
-  const uint32_t log_parts = std::min<uint32_t>(lp, (uint32_t)max_log_parts);
-  const uint32_t coarse = lp - log_parts;
-  const uint32_t P = 1u << log_parts;
+  const uint32_t P = 1u << lp;  // one partition per page
+  static const uint32_t g_cap = (uint32_t)env_int("SHK_PART_G", 512);
   const uint32_t G = grid_for(b.tile_count, 1, g_cap);
-  const size_t counts_b = (size_t)G * P * 4, totals_b = (size_t)P * 8, base_b = (size_t)(P + 1) * 8;
-  HIPC(c, c->part_meta.ensure(2 * counts_b + totals_b + base_b + 64));
-  // every (tile, partition) run may carry one padding record
-  const uint64_t rec_ub = sub_kmers_ub + (uint64_t)b.tile_count * P + 2;
-  HIPC(c, c->part.ensure(rec_ub * 8));
-  HIPC(c, c->part2.ensure(rec_ub * 8));  // k_pages miss queues (same offsets as part)
-  uint8_t *m = (uint8_t *)c->part_meta.p;
-  uint32_t *counts = (uint32_t *)m;
-  uint32_t *offs = (uint32_t *)(m + counts_b);
-  unsigned long long *totals = (unsigned long long *)(m + 2 * counts_b);
-  unsigned long long *part_base = (unsigned long long *)(m + 2 * counts_b + totals_b);
+  // Every page owns a fixed region of part_buf, filled by per-tile reservations (one returning
+  // atomic per non-empty (tile, page)).  Capacity = mean load + 25 % + the worst-case padding
+  // (one record per tile) + slack; a page that still overflows (skewed input: one k-mer making
+  // up a large share of the batch) sends the excess through the spill list — exact either way.
+  uint64_t cap64 = sub_kmers_ub / P + sub_kmers_ub / P / 4 + b.tile_count + 1024;
+  cap64 = (cap64 + 1) & ~1ull;
+  if (cap64 > 0x7FFFFFF0ull) return fail(c, SHK_ERR_BAD_ARG, "sub-batch too large for the page regions");
+  const uint32_t cap_p = (uint32_t)cap64;
+  HIPC(c, c->part.ensure((uint64_t)P * cap_p * 8));
+  HIPC(c, c->part2.ensure((uint64_t)P * cap_p * 8));  // k_pages miss queues (same offsets as part)
+  HIPC(c, c->part_meta.ensure((size_t)P * 4 + 64));
+  unsigned int *cursor = (unsigned int *)c->part_meta.p;
   uint64_t *part_buf = (uint64_t *)c->part.p;
   unsigned long long *dbg = nullptr;
 #ifdef SHK_PHASE_TIMING
   HIPC(c, c->misc.ensure((size_t)G * 64));
   dbg = (unsigned long long *)c->misc.p;
 #endif
-  const size_t lds_count = STAGE_BYTES + (size_t)P * 8;
-  const size_t lds_sorted = SORT_REGION + (size_t)PACK_WORDS * 4 + (size_t)P * 12;
+  const size_t lds_sorted = (size_t)sort_region_bytes(P) + (size_t)PACK_WORDS * 4 + (size_t)P * 12;
   const bool multi = b.tiles != nullptr;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
   for (uint32_t lane = lane_lo; lane < lane_hi; ++lane) {
-    {
-      ScopedTimer t(c, SHK_K_PCOUNT);
-      hipLaunchKernelGGL(k_part_count<SC_NT>, dim3(G), dim3(SC_NT), lds_count, c->stream, b, log_parts,
-                         lane, counts, c->d_stats, c->d_lane_bases);
-    }
-    {
-      ScopedTimer t(c, SHK_K_PSCAN);
-      hipLaunchKernelGGL(k_part_scan1, dim3((P + 63) / 64), dim3(64 * SC_WAVES), 0, c->stream,
-                         (const uint32_t *)counts, offs, G, P, totals);
-      hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, c->stream,
-                         (const unsigned long long *)totals, P, part_base);
-    }
+    HIPC(c, hipMemsetAsync(cursor, 0, (size_t)P * 4, c->stream));
     {
       ScopedTimer t(c, SHK_K_SCATTER);
-      hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b,
-                         log_parts, lane, (const uint32_t *)offs,
-                         (const unsigned long long *)part_base, part_buf,
-                         (const DevStats *)c->d_stats, dbg);
+      hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b, lp,
+                         lane, cursor, cap_p, part_buf, c->d_stats, c->d_lane_bases, sp, dbg);
     }
     {
       ScopedTimer t(c, SHK_K_PAGES);
-      hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane, coarse,
-                         (const unsigned long long *)part_base, (const uint64_t *)part_buf,
+      hipLaunchKernelGGL(k_pages, dim3(P), dim3(PG_WG), 0, c->stream, c->tb, lane, 0u,
+                         (const unsigned int *)cursor, cap_p, (const uint64_t *)part_buf,
                          (uint64_t *)c->part2.p, c->d_stats, sp);
     }
 #ifdef SHK_PHASE_TIMING

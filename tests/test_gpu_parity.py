@@ -333,3 +333,34 @@ def test_config3_shape_k31_properties():
             assert int(h[j].sum()) >= int(h[j - 1].sum())
         finals.append(h[-1])
     assert np.array_equal(finals[0], finals[1])
+
+
+# ---- shapes that stress the paged path's LDS sort and page regions -------------------------------------
+
+@pytest.mark.parametrize("flags", FLAGSETS)
+def test_long_reads_fill_whole_tiles(orc, flags):
+    """Few very long reads: almost every position of a 16 Ki-base tile ends a k-mer, so the
+    tile's sorted-entry region (entries + one pad per page) is used to the full."""
+    rng = np.random.default_rng(5)
+    n, L = 24, 40_000
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n * L)].copy()
+    offsets = np.arange(n + 1, dtype=np.uint64) * L
+    check_against_oracle(orc, bases, offsets, 21, 2, 30, flags=flags, check_table=False)
+
+
+@pytest.mark.parametrize("flags", FLAGSETS)
+def test_skewed_low_complexity_input(orc, flags):
+    """One k-mer (poly-A) makes up most of the batch: its page's region of the scatter buffer
+    overflows and the excess must arrive through the spill path, exactly."""
+    rng = np.random.default_rng(6)
+    n = 30_000
+    seqs = []
+    for i in range(n):
+        if rng.random() < 0.9:
+            seqs.append(b"A" * 150)
+        else:
+            seqs.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=150)].tobytes())
+    bases, offsets = pack(seqs)
+    cnt = check_against_oracle(orc, bases, offsets, 21, 3, 100, flags=flags)
+    if flags == sa.FLAG_FORCE_PAGED:
+        assert cnt["n_spilled"] > 0
