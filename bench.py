@@ -130,7 +130,6 @@ def main():
         lanes = max(args.chunks, 1)
         # per-kernel algorithmic bytes of ONE launch (what the kernel must move by design):
         alg = {
-            "pcount": n_bases * 1,                       # ASCII bases read once
             "scatter": n_bases * 1 + n_kmers * 8,        # bases read + one 8-B record per k-mer written
             "pages": n_kmers * 8 + cap * 12 * 2,         # records read + every page (8-B key, 4-B count) in and out
             "histo": cap * (8 + 4 * lanes),              # one table scan per histogram emit
@@ -144,7 +143,7 @@ def main():
                 per_kernel[name] = {"avg_launch_ms": round(avg, 4), "launches_per_step": launches / args.steps,
                                     "alg_bytes_per_launch": int(alg[name]),
                                     "achieved_GBps": round(alg[name] / (avg * 1e-3) / 1e9, 1)}
-        hot = [k_ for k_ in ("direct", "scatter", "pages", "pcount") if k_ in per_kernel]
+        hot = [k_ for k_ in ("direct", "scatter", "pages") if k_ in per_kernel]
         dom = max(hot, key=lambda k_: per_kernel[k_]["avg_launch_ms"] * per_kernel[k_]["launches_per_step"]) if hot else None
         roof = None
         if dom:

@@ -21,7 +21,7 @@ os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats, f"profiles/{rnd}_kernel_stats.csv")
 
-NAMES = {"k_part_scatter_sorted<512>": "scatter", "k_pages": "pages", "k_part_count<512>": "pcount",
+NAMES = {"k_part_scatter_sorted<512>": "scatter", "k_pages": "pages",
          "k_histo": "histo", "k_direct": "direct", "k_scan": "scan", "k_mark_starts": "mark"}
 
 
