@@ -1308,7 +1308,9 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uin
           mq[atomicAdd(&n_miss, 1u)] = kq;  // kq != EMPTY here: an EMPTY record always "hits"
         }                                   // an empty slot or probes on; filtered in the drain
       }
-      if ((quad % DRAIN_EVERY) == DRAIN_EVERY - 1 || quad + 1 == n_quads) {
+      // drain after every step at first (an empty page misses on every first occurrence, and
+      // on its repeats until it is inserted), then every DRAIN_EVERY steps
+      if (quad < 2 * DRAIN_EVERY || (quad % DRAIN_EVERY) == DRAIN_EVERY - 1 || quad + 1 == n_quads) {
         __syncthreads();
         const uint32_t nm = n_miss;
         if (nm) {
