@@ -921,7 +921,7 @@ __global__ void __launch_bounds__(WG) k_synth(SynthSpec sp, uint64_t first_read,
 // ##########################################################################################
 namespace shk {
 
-constexpr int MAX_PARTS = 4096;   // pages addressable by the LDS partition counters
+constexpr int MAX_PARTS = 4096;   // partitions one LDS sort fans out to; more pages ⇒ two levels
 constexpr int PG_WG = 1024;       // k_pages workgroup: 16 waves, one workgroup (96 KiB LDS) per CU
 constexpr uint32_t PAGE_FILL_CAP = PAGE_SLOTS - PAGE_SLOTS / 8;  // new keys spill beyond this
 
@@ -1152,6 +1152,135 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
   if (dbg && threadIdx.x == 0)
     for (int i = 0; i < 8; ++i) dbg[(uint64_t)blockIdx.x * 8 + i] = ph[i];
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// k_part_rescatter: second level of the partition for tables with more pages than one LDS sort
+// can fan out to (> MAX_PARTS).  Level 1 (k_part_scatter_sorted with log_parts < log_pages) has
+// grouped the records by SUPER-PAGE (2^log_sub consecutive pages); this kernel takes one
+// 16 Ki-record tile of one super-page's region, counting-sorts it by page inside the super-page
+// in LDS, reserves each page's share of the final page regions with one returning atomic per
+// (tile, page) and writes the records there as aligned pairs — the same machine as level 1 with
+// "re-read the record from the LDS copy of the tile" in place of "re-read the k-mer from the
+// packed bases" (the fan-out is small here, so 4 Ki-record tiles already give long runs).
+// Costs one more 8-B read + 8-B write per k-mer occurrence.
+// ------------------------------------------------------------------------------------------
+constexpr int RS_NT = 256;
+constexpr int RS_TILE = 4096;              // records per tile: they stay in LDS (32 KiB) for the write-out
+constexpr int RS_SPAN = RS_TILE / RS_NT;   // 16 records per thread
+__global__ void __launch_bounds__(RS_NT) k_part_rescatter(
+    const uint64_t *__restrict__ src_buf, const unsigned int *__restrict__ src_cursor, uint32_t src_cap,
+    uint32_t tiles_per_region, uint32_t log_pages, uint32_t log_sub, unsigned int *__restrict__ dst_cursor,
+    uint32_t dst_cap, uint64_t *__restrict__ dst_buf, uint32_t lane, DevStats *__restrict__ stats,
+    SpillRef sp) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+  __shared__ uint32_t wsum[RS_NT / 64];
+  if (stats->bad != ~0ull) return;
+  const uint32_t S = 1u << log_sub;  // pages per super-page
+  const uint32_t region = blockIdx.x / tiles_per_region, tile = blockIdx.x % tiles_per_region;
+  const uint32_t filled = src_cursor[region] < src_cap ? src_cursor[region] : src_cap;
+  const uint32_t r0 = tile * RS_TILE;
+  if (r0 >= filled) return;
+  const uint32_t n = filled - r0 < (uint32_t)RS_TILE ? filled - r0 : (uint32_t)RS_TILE;  // even
+  const uint64_t *src = src_buf + (uint64_t)region * src_cap + r0;
+  uint64_t *recs = reinterpret_cast<uint64_t *>(sh);                       // RS_TILE records
+  uint16_t *sorted = reinterpret_cast<uint16_t *>(sh + 2 * RS_TILE);       // RS_TILE + S entries
+  uint32_t *cnt = sh + 2 * RS_TILE + (((uint32_t)RS_TILE + S) * 2 + 15) / 16 * 4;  // S
+  uint32_t *tstart = cnt + S;                                              // S
+  uint32_t *gbase = tstart + S;                                            // S
+  for (uint32_t i = threadIdx.x; i < S; i += RS_NT) cnt[i] = 0;
+  __syncthreads();
+  // ---- rank: (page-in-super-page, rank) per record, in registers -------------------------------
+  uint32_t pr[RS_SPAN];
+  const uint32_t sub_mask = S - 1;
+#pragma unroll
+  for (int q = 0; q < RS_SPAN / 2; ++q) {
+    const uint32_t i = (uint32_t)(q * RS_NT + threadIdx.x) * 2;  // record pair, coalesced 16-B loads
+    uint32_t va = 0xFFFFFFFFu, vb = 0xFFFFFFFFu;
+    if (i < n) {
+      const ulonglong2 rec = *reinterpret_cast<const ulonglong2 *>(src + i);
+      *reinterpret_cast<ulonglong2 *>(recs + i) = rec;
+      if (rec.x != EMPTY) {
+        const uint32_t sub = (uint32_t)page_of(hash64(rec.x), log_pages) & sub_mask;
+        va = (sub << 16) | atomicAdd(&cnt[sub], 1u);
+      }
+      if (rec.y != EMPTY) {
+        const uint32_t sub = (uint32_t)page_of(hash64(rec.y), log_pages) & sub_mask;
+        vb = (sub << 16) | atomicAdd(&cnt[sub], 1u);
+      }
+    }
+    pr[2 * q] = va;
+    pr[2 * q + 1] = vb;
+  }
+  __syncthreads();
+  // ---- exclusive scan of the even-padded counts; reservation in the final page regions ---------
+  {
+    const uint32_t per = S / RS_NT ? S / RS_NT : 1;
+    uint32_t lo = threadIdx.x * per, sacc = 0;
+    if (lo < S)
+      for (uint32_t i = 0; i < per; ++i) sacc += (cnt[lo + i] + 1u) & ~1u;
+    uint32_t inc = sacc;
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(inc, d, 64);
+      if ((int)(threadIdx.x & 63) >= d) inc += o;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+    uint32_t run = woff + inc - sacc;
+    if (lo < S)
+      for (uint32_t i = 0; i < per; ++i) {
+        tstart[lo + i] = run;
+        run += (cnt[lo + i] + 1u) & ~1u;
+      }
+  }
+  for (uint32_t i = threadIdx.x; i < S; i += RS_NT) {
+    const uint32_t c2 = (cnt[i] + 1u) & ~1u;
+    gbase[i] = c2 ? atomicAdd(&dst_cursor[((uint64_t)region << log_sub) + i], c2) : 0u;
+  }
+  __syncthreads();
+  // ---- place: entry = record index inside the tile (0xFFFF = pad) ------------------------------------
+#pragma unroll
+  for (int q = 0; q < RS_SPAN / 2; ++q) {
+    const uint32_t i = (uint32_t)(q * RS_NT + threadIdx.x) * 2;
+    const uint32_t va = pr[2 * q], vb = pr[2 * q + 1];
+    if (va != 0xFFFFFFFFu) sorted[tstart[va >> 16] + (va & 0xFFFFu)] = (uint16_t)i;
+    if (vb != 0xFFFFFFFFu) sorted[tstart[vb >> 16] + (vb & 0xFFFFu)] = (uint16_t)(i + 1);
+  }
+  for (uint32_t i = threadIdx.x; i < S; i += RS_NT)
+    if (cnt[i] & 1u) sorted[tstart[i] + cnt[i]] = 0xFFFFu;
+  __syncthreads();
+  // ---- write: pairs of records, re-read from the LDS copy of the tile ---------------------------
+  const uint32_t n_pairs = (tstart[S - 1] + ((cnt[S - 1] + 1u) & ~1u)) >> 1;
+  const uint32_t *sorted2 = reinterpret_cast<const uint32_t *>(sorted);
+  for (uint32_t i = threadIdx.x; i < n_pairs; i += RS_NT) {
+    const uint32_t ee = sorted2[i];
+    const uint32_t ea = ee & 0xFFFFu, eb = ee >> 16;
+    const uint64_t km0 = recs[ea];
+    const uint64_t km1 = eb == 0xFFFFu ? EMPTY : recs[eb];
+    const uint32_t sub = (uint32_t)page_of(hash64(km0), log_pages) & sub_mask;
+    const uint32_t at = gbase[sub] + (2 * i - tstart[sub]);
+    const uint64_t page = ((uint64_t)region << log_sub) + sub;
+    if (at + 2 <= dst_cap) {
+      ulonglong2 rec;
+      rec.x = km0;
+      rec.y = km1;
+      *reinterpret_cast<ulonglong2 *>(dst_buf + page * dst_cap + at) = rec;
+    } else {
+      const unsigned long long j = atomicAdd(&stats->spill_count, km1 == EMPTY ? 1ull : 2ull);
+      if (j < sp.cap) {
+        sp.keys[j] = km0;
+        sp.lanes[j] = lane;
+        sp.counts[j] = 1u;
+      }
+      if (km1 != EMPTY && j + 1 < sp.cap) {
+        sp.keys[j + 1] = km1;
+        sp.lanes[j + 1] = lane;
+        sp.counts[j + 1] = 1u;
+      }
+    }
+  }
 }
 
 __device__ __forceinline__ void page_insert(uint64_t *keys, uint32_t *vals, uint32_t *occ,

@@ -74,7 +74,7 @@ struct shk_ctx {
   // scratch
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_done[2] = {nullptr, nullptr};
-  DevBuf in_bases, in_offsets, in_bases2, in_offsets2, startbits, tiles, spillA, spillB, misc, part, part2, part_meta;
+  DevBuf in_bases, in_offsets, in_bases2, in_offsets2, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
   // host counters
   std::vector<uint64_t> lane_reads;
   uint64_t n_reads_read = 0, n_bases_read = 0;
@@ -340,7 +340,8 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
 // rounds stay few; it pays when the batch is at least comparable to the table, because every
 // touched page is read and written once per pass.
 static bool paged_feasible(const shk_ctx *c) {
-  return (1ull << c->tb.log_pages) <= (uint64_t)MAX_PARTS && c->n_lanes <= 16;
+  // one level up to MAX_PARTS pages, two levels (super-pages of ≤ MAX_PARTS pages) beyond
+  return c->tb.log_pages <= 20 && c->n_lanes <= 16;
 }
 static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
   return c->tb.log_pages >= 8 && sub_kmers_ub >= c->tb.cap / 2;
@@ -348,43 +349,68 @@ static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
 
 constexpr int SC_NT = 512;  // threads of the partition count / sorted scatter workgroups
 
+static uint32_t region_cap(uint64_t n_records_ub, uint64_t n_regions, uint64_t pads) {
+  // mean load + 25 % + worst-case padding + slack, even
+  uint64_t cap = n_records_ub / n_regions + n_records_ub / n_regions / 4 + pads + 1024;
+  return (uint32_t)std::min<uint64_t>((cap + 1) & ~1ull, 0x7FFFFFF0ull);
+}
+
 static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp) {
   const uint32_t lp = c->tb.log_pages;
-  const uint32_t P = 1u << lp;  // one partition per page
-  static const uint32_t g_cap = (uint32_t)env_int("SHK_PART_G", 512);
+  const uint32_t n_pages = 1u << lp;
+  const uint32_t g_cap = (uint32_t)env_int("SHK_PART_G", 512);
+  const uint32_t lvl1_log = (uint32_t)env_int("SHK_LEVEL1_LOG", 10);           // test hooks: force the
+  const uint32_t two_level_min = (uint32_t)env_int("SHK_TWO_LEVEL_MIN_PAGES", MAX_PARTS);  // two-level path
   const uint32_t G = grid_for(b.tile_count, 1, g_cap);
-  // Every page owns a fixed region of part_buf, filled by per-tile reservations (one returning
-  // atomic per non-empty (tile, page)).  Capacity = mean load + 25 % + the worst-case padding
-  // (one record per tile) + slack; a page that still overflows (skewed input: one k-mer making
-  // up a large share of the batch) sends the excess through the spill list — exact either way.
-  uint64_t cap64 = sub_kmers_ub / P + sub_kmers_ub / P / 4 + b.tile_count + 1024;
-  cap64 = (cap64 + 1) & ~1ull;
-  if (cap64 > 0x7FFFFFF0ull) return fail(c, SHK_ERR_BAD_ARG, "sub-batch too large for the page regions");
-  const uint32_t cap_p = (uint32_t)cap64;
-  HIPC(c, c->part.ensure((uint64_t)P * cap_p * 8));
-  HIPC(c, c->part2.ensure((uint64_t)P * cap_p * 8));  // k_pages miss queues (same offsets as part)
-  HIPC(c, c->part_meta.ensure((size_t)P * 4 + 64));
-  unsigned int *cursor = (unsigned int *)c->part_meta.p;
-  uint64_t *part_buf = (uint64_t *)c->part.p;
+  // One level: one partition per page.  More than MAX_PARTS pages: level 1 groups the records
+  // by super-page (2^log_sub consecutive pages), level 2 (k_part_rescatter) by page.
+  const bool two_level = n_pages > std::min<uint32_t>(two_level_min, (uint32_t)MAX_PARTS);
+  const uint32_t log_p1 = two_level ? std::min(lvl1_log, lp) : lp;
+  const uint32_t log_sub = lp - log_p1;
+  if (two_level && (1u << log_sub) > (uint32_t)MAX_PARTS)
+    return fail(c, SHK_ERR_BAD_ARG, "table too large for the two-level partition");
+  const uint32_t P1 = 1u << log_p1;
+  // Every region is filled by per-tile reservations (one returning atomic per non-empty
+  // (tile, region)); a region that still overflows (skewed input: one k-mer making up a large
+  // share of the batch) sends the excess through the spill list — exact either way.
+  const uint32_t cap1 = region_cap(sub_kmers_ub, P1, b.tile_count);
+  const uint32_t tiles_per_region = (cap1 + RS_TILE - 1) / RS_TILE;
+  const uint32_t cap_pg = two_level ? region_cap(sub_kmers_ub, n_pages, tiles_per_region) : cap1;
+  DevBuf &buf_pg = two_level ? c->part3 : c->part;  // what k_pages reads
+  HIPC(c, c->part.ensure((uint64_t)P1 * cap1 * 8));
+  if (two_level) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * 8));
+  HIPC(c, c->part2.ensure((uint64_t)n_pages * cap_pg * 8));  // k_pages miss queues (same offsets)
+  HIPC(c, c->part_meta.ensure(((size_t)P1 + n_pages) * 4 + 64));
+  unsigned int *cursor1 = (unsigned int *)c->part_meta.p;
+  unsigned int *cursor_pg = two_level ? cursor1 + P1 : cursor1;
   unsigned long long *dbg = nullptr;
 #ifdef SHK_PHASE_TIMING
   HIPC(c, c->misc.ensure((size_t)G * 64));
   dbg = (unsigned long long *)c->misc.p;
 #endif
-  const size_t lds_sorted = (size_t)sort_region_bytes(P) + (size_t)PACK_WORDS * 4 + (size_t)P * 12;
+  const size_t lds_sorted = (size_t)sort_region_bytes(P1) + (size_t)PACK_WORDS * 4 + (size_t)P1 * 12;
+  const uint32_t S = 1u << log_sub;
+  const size_t lds_rs = (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12;
   const bool multi = b.tiles != nullptr;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
   for (uint32_t lane = lane_lo; lane < lane_hi; ++lane) {
-    HIPC(c, hipMemsetAsync(cursor, 0, (size_t)P * 4, c->stream));
+    HIPC(c, hipMemsetAsync(cursor1, 0, ((size_t)P1 + (two_level ? n_pages : 0)) * 4, c->stream));
     {
       ScopedTimer t(c, SHK_K_SCATTER);
-      hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b, lp,
-                         lane, cursor, cap_p, part_buf, c->d_stats, c->d_lane_bases, sp, dbg);
+      hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b,
+                         log_p1, lane, cursor1, cap1, (uint64_t *)c->part.p, c->d_stats, c->d_lane_bases,
+                         sp, dbg);
+    }
+    if (two_level) {
+      ScopedTimer t(c, SHK_K_PSCAN);  // timer slot reused: the level-2 re-scatter
+      hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
+                         (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
+                         log_sub, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp);
     }
     {
       ScopedTimer t(c, SHK_K_PAGES);
-      hipLaunchKernelGGL(k_pages, dim3(P), dim3(PG_WG), 0, c->stream, c->tb, lane, 0u,
-                         (const unsigned int *)cursor, cap_p, (const uint64_t *)part_buf,
+      hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane, 0u,
+                         (const unsigned int *)cursor_pg, cap_pg, (const uint64_t *)buf_pg.p,
                          (uint64_t *)c->part2.p, c->d_stats, sp);
     }
 #ifdef SHK_PHASE_TIMING
@@ -544,6 +570,7 @@ void shk_destroy(shk_ctx *c) {
   c->misc.release();
   c->part.release();
   c->part2.release();
+  c->part3.release();
   c->part_meta.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -364,3 +364,40 @@ def test_skewed_low_complexity_input(orc, flags):
     cnt = check_against_oracle(orc, bases, offsets, 21, 3, 100, flags=flags)
     if flags == sa.FLAG_FORCE_PAGED:
         assert cnt["n_spilled"] > 0
+
+
+# ---- two-level partition (tables with more pages than one LDS sort fans out to) -------------------------
+
+@pytest.mark.parametrize("k,chunks,lvl1", [(21, 1, 2), (31, 3, 3), (13, 2, 0)])
+def test_two_level_partition_small(orc, monkeypatch, k, chunks, lvl1):
+    """Force the super-page + re-scatter path on a small table: 8+ pages, level 1 fans out to
+    2^lvl1 super-pages, level 2 to the pages inside each."""
+    monkeypatch.setenv("SHK_TWO_LEVEL_MIN_PAGES", "4")
+    monkeypatch.setenv("SHK_LEVEL1_LOG", str(lvl1))
+    spec = sa.SynthSpec(genome_len=150_000, sub_per_64k=328, n_per_64k=66)
+    bases, offsets = sa.synth_reads(spec, 0, 60_000)
+    cnt = check_against_oracle(orc, bases, offsets, k, chunks, 200, flags=sa.FLAG_FORCE_PAGED,
+                               hint=400_000, check_table=False)
+    assert cnt["table_capacity"] >= 8 * 8192
+
+
+def test_two_level_partition_large_table():
+    """A table past MAX_PARTS pages (64 M distinct-k-mer hint ⇒ 16 Ki pages) takes the two-level
+    path by itself; properties at a size the oracle is too slow for."""
+    spec = sa.SynthSpec(genome_len=30_000_000)
+    n = 3_400_000  # two batches of 1.7 M reads: each fits one counting launch (≤ 2^28 bases)
+    with sa.KmerEngine(21, 1, 1000, capacity_hint=64_000_000, flags=sa.FLAG_TIMING) as eng:
+        for part in range(2):
+            b, o = sa.synth_reads(spec, part * (n // 2), n // 2)
+            eng.ingest_reads(b, o)
+        eng.finalize()
+        h = eng.histograms()
+        c = eng.counters()
+        t = eng.timings()
+    assert "pages" in t and "direct" not in t and "pscan" in t  # pscan slot = the level-2 re-scatter
+    assert c["n_kmers_ingested"] == 130 * n
+    col = h[0].astype(object)
+    assert sum(int(f) * i for i, f in enumerate(col)) == 130 * n
+    assert int(h[0].sum()) == c["n_unique_kmers"] and c["n_spilled"] == 0
+    # 17x coverage of a 30 Mb genome: nearly every genomic 21-mer seen at least once
+    assert 0.99 * 30_000_000 < c["n_unique_kmers"] <= 30_000_000
