@@ -922,7 +922,7 @@ __global__ void __launch_bounds__(WG) k_synth(SynthSpec sp, uint64_t first_read,
 namespace shk {
 
 constexpr int MAX_PARTS = 4096;   // partitions one LDS sort fans out to; more pages ⇒ two levels
-constexpr int PG_WG = 1024;       // k_pages workgroup: 16 waves, one workgroup (96 KiB LDS) per CU
+constexpr int PG_WG = 512;        // k_pages workgroup: 8 waves; two workgroups (80 KiB LDS each) per CU
 constexpr uint32_t PAGE_FILL_CAP = PAGE_SLOTS - PAGE_SLOTS / 8;  // new keys spill beyond this
 
 // ------------------------------------------------------------------------------------------
@@ -1283,197 +1283,184 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
   }
 }
 
-__device__ __forceinline__ void page_insert(uint64_t *keys, uint32_t *vals, uint32_t *occ,
-                                            uint64_t key, uint32_t log_pages, bool slow,
-                                            uint32_t lane, DevStats *stats, const SpillRef &sp,
-                                            uint32_t &n_new, uint32_t page, bool filter) {
-  if (key == EMPTY) return;  // padding record of an odd (tile, partition) run
-  const uint32_t h = hash64(key);
-  if (filter && (uint32_t)page_of(h, log_pages) != page) return;  // a sibling page's k-mer
-  uint32_t s = slot_of(h, log_pages);
-  for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
-    uint64_t cur = keys[s];
-    if (cur == EMPTY) {
-      if (__hip_atomic_load(occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= PAGE_FILL_CAP)
-        break;  // page (nearly) full → spill
-      uint64_t prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)EMPTY,
-                                (unsigned long long)key);
-      if (prev == EMPTY) {
-        atomicAdd(occ, 1u);
-        n_new++;
-        cur = key;
-      } else {
-        cur = prev;
-      }
-    }
-    if (cur == key) {
-      if (!slow) {
-        atomicAdd(&vals[s], 1u);  // cannot wrap: checked against the run length at page load
-      } else {
-        uint32_t old = atomicAdd(&vals[s], 1u);
-        if (old == 0xFFFFFFFFu) atomicMax(&vals[s], 0xFFFFFFFFu);
-      }
-      return;
-    }
-    s = (s + 1) & (PAGE_SLOTS - 1);
-  }
-  unsigned long long i = atomicAdd(&stats->spill_count, 1ull);
-  if (i < sp.cap) {
-    sp.keys[i] = key;
-    sp.lanes[i] = lane;
-    sp.counts[i] = 1u;
-  }
+// In LDS a page is 8192 keys (64 KiB) + 8192 sixteen-bit DELTAS of this pass (16 KiB, two per
+// word) = 80 KiB, so two page workgroups share a CU.  The deltas are folded into the page's
+// 32-bit counts in HBM when the workgroup leaves (saturating, counting.rs:82-85) — and earlier
+// for any slot whose delta reaches 2^15, which is checked at every miss-queue drain: between two
+// checks a slot gains at most DRAIN_EVERY·4·PG_WG = 8192 < 2^15, so a delta never wraps.
+__device__ __forceinline__ void delta_add(uint32_t *dl, uint32_t slot) {
+  atomicAdd(&dl[slot >> 1], 1u << (16 * (slot & 1)));
 }
 
-// coarse > 0: a partition run holds the k-mers of 2^coarse sibling pages; each sibling's
-// workgroup streams the whole run and keeps its own.  Block ids are laid out so that the
-// siblings are dispatched together on one XCD (ids equal mod 8 — speed only): the run is then
-// fetched from HBM once and re-read from that XCD's L2.
-__global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane, uint32_t coarse,
+// Workgroup reduction through a few words of scratch LDS (sum), result to every thread.
+__device__ __forceinline__ uint32_t pg_wg_sum(uint32_t v, uint32_t *scratch) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t s = 0;
+  for (int w = 0; w < PG_WG / 64; ++w) s += scratch[w];
+  __syncthreads();
+  return s;
+}
+
+// LDS budget: 64 KiB keys + 16 KiB deltas = exactly half a CU's 160 KiB, so there is no room
+// for even one shared counter: occupancy and new-key counts are reduced through the (then
+// idle) delta words, and every wave keeps its own miss queue (a slice of the page's miss_buf
+// region) with the fill level in a wave-uniform register — ballot/popcount, no atomics.
+constexpr uint32_t MISS_SLACK = 4096;  // extra records per page region of miss_buf (8 slices)
+__global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
                                                  const unsigned int *__restrict__ cursor, uint32_t cap_p,
                                                  const uint64_t *__restrict__ part_buf,
                                                  uint64_t *__restrict__ miss_buf,
                                                  DevStats *__restrict__ stats, SpillRef sp) {
   __shared__ __attribute__((aligned(16))) uint64_t keys[PAGE_SLOTS];
-  __shared__ __attribute__((aligned(16))) uint32_t vals[PAGE_SLOTS];
-  __shared__ uint32_t occ, vmax, nnew, n_miss;
+  __shared__ __attribute__((aligned(16))) uint32_t dl[PAGE_SLOTS / 2];
   if (stats->bad != ~0ull) return;
-  uint32_t page = blockIdx.x, part = blockIdx.x;
-  if (coarse) {
-    const uint32_t sib = 1u << coarse, grp = 8u * sib;
-    if ((gridDim.x % grp) == 0) {
-      const uint32_t r = blockIdx.x & 7, sub = (blockIdx.x >> 3) & (sib - 1), base = blockIdx.x / grp;
-      part = base * 8 + r;
-      page = (part << coarse) | sub;
-    } else {
-      part = page >> coarse;
-    }
-  }
-  const bool filter = coarse != 0;
-  const uint32_t filled = cursor[part] < cap_p ? cursor[part] : cap_p;  // beyond cap_p: spilled
-  const uint64_t r0 = (uint64_t)part * cap_p, r1 = r0 + filled;
-  if (r1 == r0) return;  // nothing for this page: leave it untouched in HBM
+  const uint32_t page = blockIdx.x;
+  const uint32_t filled = cursor[page] < cap_p ? cursor[page] : cap_p;  // beyond cap_p: spilled
+  if (filled == 0) return;  // nothing for this page: leave it untouched in HBM
   uint64_t *gk = tb.keys + ((uint64_t)page << PAGE_LOG);
   uint32_t *gv = tb.vals + (uint64_t)lane * tb.cap + ((uint64_t)page << PAGE_LOG);
-  if (threadIdx.x == 0) {
-    occ = 0;
-    vmax = 0;
-    nnew = 0;
-    n_miss = 0;
-  }
-  __syncthreads();
-  // page → LDS (16-B vectors), counting occupied slots and the largest count on the way
-  uint32_t my_occ = 0, my_max = 0;
+  // page keys → LDS (16-B vectors), counting occupied slots on the way
+  uint32_t my_occ = 0;
   for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 2; i += PG_WG) {
     ulonglong2 v = reinterpret_cast<const ulonglong2 *>(gk)[i];
     reinterpret_cast<ulonglong2 *>(keys)[i] = v;
     my_occ += (v.x != EMPTY) + (v.y != EMPTY);
   }
-  for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 4; i += PG_WG) {
-    uint4 v = reinterpret_cast<const uint4 *>(gv)[i];
-    reinterpret_cast<uint4 *>(vals)[i] = v;
-    uint32_t m = v.x > v.y ? v.x : v.y;
-    uint32_t n = v.z > v.w ? v.z : v.w;
-    m = m > n ? m : n;
-    my_max = my_max > m ? my_max : m;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    my_occ += __shfl_down(my_occ, off, 64);
-    uint32_t o = __shfl_down(my_max, off, 64);
-    my_max = my_max > o ? my_max : o;
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&occ, my_occ);
-    atomicMax(&vmax, my_max);
-  }
+  const uint32_t occ0 = pg_wg_sum(my_occ, dl);
+  // every wave may add its share of what is left below the fill cap; beyond it new keys spill
+  const uint32_t room = occ0 < PAGE_FILL_CAP ? (PAGE_FILL_CAP - occ0) / (PG_WG / 64) : 0u;
+  for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 2; i += PG_WG) dl[i] = 0;
   __syncthreads();
-  const uint64_t n = r1 - r0;
-  // the plain add cannot wrap if max + run length stays below 2^32
-  const bool slow = (uint64_t)vmax + n > 0xFFFFFFFFull;
-  const uint64_t *src = part_buf + r0;
-  uint32_t n_new = 0;
-  uint64_t i = threadIdx.x;
-  if (!slow && !filter) {
-    // Fast path: four k-mers per thread per step.  The four global loads, then the four 32-B
-    // home buckets (two ds_read_b128 each), are in flight together; a k-mer whose key sits in
-    // its home bucket (≈99 % at load ≤ 1/2) costs one non-returning LDS add.  The others (first
-    // occurrences, displaced keys) are only QUEUED here — the run's slice of miss_buf — and
-    // handled densely by the general probe afterwards: a divergent in-line slow path would be
-    // executed by nearly every wave for one or two lanes each.
-    uint64_t *mq = miss_buf + r0;
-    // runs are sequences of aligned record PAIRS (padding = EMPTY): one 16-B load per lane
-    // fetches two records; two such loads per step
-    const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(src);
-    const uint32_t n_quads = (uint32_t)(n / (4 * PG_WG));  // steps of four records per thread
-    constexpr uint32_t DRAIN_EVERY = 4;                     // steps between miss-queue drains
-    ulonglong2 nxt[2];
-    if (n_quads) {
-      nxt[0] = src2[threadIdx.x];
-      nxt[1] = src2[threadIdx.x + PG_WG];
-    }
-    for (uint32_t quad = 0; quad < n_quads; ++quad) {
-      uint64_t kk[4] = {nxt[0].x, nxt[0].y, nxt[1].x, nxt[1].y};
-      uint32_t ss[4];
-      ulonglong2 ba[4], bb[4];
-      if (quad + 1 < n_quads) {  // next step's loads are in flight while this one is processed
-        const uint64_t ib = (uint64_t)(quad + 1) * 2 * PG_WG + threadIdx.x;
-        nxt[0] = src2[ib];
-        nxt[1] = src2[ib + PG_WG];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ss[q] = slot_of(hash64(kk[q]), tb.log_pages);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        ba[q] = *reinterpret_cast<const ulonglong2 *>(&keys[ss[q]]);
-        bb[q] = *reinterpret_cast<const ulonglong2 *>(&keys[ss[q] + 2]);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint64_t kq = kk[q];
-        int hit = ba[q].x == kq ? 0 : ba[q].y == kq ? 1 : bb[q].x == kq ? 2 : bb[q].y == kq ? 3 : -1;
-        if (hit >= 0) {
-          if (kq != EMPTY) atomicAdd(&vals[ss[q] + hit], 1u);  // EMPTY = padding record
+  const uint64_t n = filled;
+  const uint64_t *src = part_buf + (uint64_t)page * cap_p;
+  const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+  const uint32_t slice = (uint32_t)(n / (PG_WG / 64)) + MISS_SLACK / (PG_WG / 64);
+  uint64_t *mq = miss_buf + (uint64_t)page * (cap_p + MISS_SLACK) + (uint64_t)wave * slice;
+  uint32_t n_miss = 0;  // wave-uniform
+  uint32_t n_new = 0;   // per thread
+  // The fill cap is soft: whether this wave may still insert new keys is decided once per
+  // drain from its running total, so a wave can overshoot its share by one drain's misses; a
+  // page that fills up completely still ends in the spill path (bounded probe).
+  bool may_insert = room > 0;
+  auto update_may_insert = [&]() {
+    uint32_t w = n_new;
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
+    may_insert = w < room;
+  };
+  // general probe of one record into the LDS page: find the key or insert it, add one
+  auto insert = [&](uint64_t key) {
+    if (key == EMPTY) return;  // padding record of an odd (tile, page) run
+    uint32_t sl = slot_of(hash64(key), tb.log_pages);
+    for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
+      uint64_t cur = keys[sl];
+      if (cur == EMPTY) {
+        if (!may_insert) break;  // this wave's share of the page is used up → spill
+        uint64_t prev = atomicCAS((unsigned long long *)&keys[sl], (unsigned long long)EMPTY,
+                                  (unsigned long long)key);
+        if (prev == EMPTY) {
+          n_new++;
+          cur = key;
         } else {
-          mq[atomicAdd(&n_miss, 1u)] = kq;  // kq != EMPTY here: an EMPTY record always "hits"
-        }                                   // an empty slot or probes on; filtered in the drain
-      }
-      // drain after every step at first (an empty page misses on every first occurrence, and
-      // on its repeats until it is inserted), then every DRAIN_EVERY steps
-      if (quad < 2 * DRAIN_EVERY || (quad % DRAIN_EVERY) == DRAIN_EVERY - 1 || quad + 1 == n_quads) {
-        __syncthreads();
-        const uint32_t nm = n_miss;
-        if (nm) {
-          for (uint32_t j = threadIdx.x; j < nm; j += PG_WG) {
-            const uint64_t kq = mq[j];
-            if (kq != EMPTY)
-              page_insert(keys, vals, &occ, kq, tb.log_pages, false, lane, stats, sp, n_new, page, false);
-          }
-          __syncthreads();
-          if (threadIdx.x == 0) n_miss = 0;
-          __syncthreads();
+          cur = prev;
         }
       }
+      if (cur == key) {
+        delta_add(dl, sl);
+        return;
+      }
+      sl = (sl + 1) & (PAGE_SLOTS - 1);
     }
-    i = (uint64_t)n_quads * 4 * PG_WG + threadIdx.x;
+    unsigned long long i = atomicAdd(&stats->spill_count, 1ull);
+    if (i < sp.cap) {
+      sp.keys[i] = key;
+      sp.lanes[i] = lane;
+      sp.counts[i] = 1u;
+    }
+  };
+  // Four records per thread per step.  The global loads of the NEXT step, then the four 32-B
+  // home buckets (two ds_read_b128 each), are in flight together; a record whose key sits in
+  // its home bucket (≈99 % at load ≤ 1/2) costs one non-returning LDS add.  The others (first
+  // occurrences, displaced keys) are only QUEUED here and handled densely by the general probe
+  // afterwards: a divergent in-line slow path would be executed by nearly every wave for one or
+  // two lanes each.  Regions are sequences of aligned record PAIRS (padding = EMPTY): one 16-B
+  // load per lane fetches two records; two such loads per step.
+  const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(src);
+  const uint32_t n_quads = (uint32_t)(n / (4 * PG_WG));  // steps of four records per thread
+  constexpr uint32_t DRAIN_EVERY = 4;                     // steps between miss-queue drains
+  static_assert(DRAIN_EVERY * 4 * PG_WG < 0x8000, "a 16-bit delta must not wrap between checks");
+  ulonglong2 nxt[2];
+  if (n_quads) {
+    nxt[0] = src2[threadIdx.x];
+    nxt[1] = src2[threadIdx.x + PG_WG];
   }
-  for (; i + 3 * PG_WG < n; i += 4 * PG_WG) {  // four independent loads in flight per thread
-    uint64_t k0 = src[i], k1 = src[i + PG_WG], k2 = src[i + 2 * PG_WG], k3 = src[i + 3 * PG_WG];
-    page_insert(keys, vals, &occ, k0, tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
-    page_insert(keys, vals, &occ, k1, tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
-    page_insert(keys, vals, &occ, k2, tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
-    page_insert(keys, vals, &occ, k3, tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
+  for (uint32_t quad = 0; quad < n_quads; ++quad) {
+    uint64_t kk[4] = {nxt[0].x, nxt[0].y, nxt[1].x, nxt[1].y};
+    uint32_t ss[4];
+    ulonglong2 ba[4], bb[4];
+    if (quad + 1 < n_quads) {  // next step's loads are in flight while this one is processed
+      const uint64_t ib = (uint64_t)(quad + 1) * 2 * PG_WG + threadIdx.x;
+      nxt[0] = src2[ib];
+      nxt[1] = src2[ib + PG_WG];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ss[q] = slot_of(hash64(kk[q]), tb.log_pages);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ba[q] = *reinterpret_cast<const ulonglong2 *>(&keys[ss[q]]);
+      bb[q] = *reinterpret_cast<const ulonglong2 *>(&keys[ss[q] + 2]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint64_t kq = kk[q];
+      int hit = ba[q].x == kq ? 0 : ba[q].y == kq ? 1 : bb[q].x == kq ? 2 : bb[q].y == kq ? 3 : -1;
+      if (hit >= 0 && kq != EMPTY) delta_add(dl, ss[q] + hit);  // EMPTY = padding ("hits" a free slot)
+      const unsigned long long mm = __ballot(hit < 0);
+      if (hit < 0) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = kq;
+      n_miss += (uint32_t)__popcll(mm);
+    }
+    // drain after every step at first (an empty page misses on every first occurrence, and
+    // on its repeats until it is inserted), then every DRAIN_EVERY steps
+    if (quad < 2 * DRAIN_EVERY || (quad % DRAIN_EVERY) == DRAIN_EVERY - 1 || quad + 1 == n_quads) {
+      for (uint32_t j = lane_id; j < n_miss; j += 64) insert(mq[j]);  // this wave's own queue
+      n_miss = 0;
+      update_may_insert();
+      __syncthreads();
+      // deltas >= 2^15 go to the 32-bit counts in HBM now (a slot gains < 2^15 between checks)
+      for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 2; j += PG_WG) {
+        const uint32_t w = dl[j];
+        if (w & 0x80008000u) {
+          if (w & 0x8000u) gv[2 * j] = sat_add_u32(gv[2 * j], w & 0xFFFFu);
+          if (w & 0x80000000u) gv[2 * j + 1] = sat_add_u32(gv[2 * j + 1], w >> 16);
+          dl[j] = (w & 0x8000u ? 0u : (w & 0xFFFFu)) | (w & 0x80000000u ? 0u : (w & 0xFFFF0000u));
+        }
+      }
+      __syncthreads();
+    }
   }
-  for (; i < n; i += PG_WG)
-    page_insert(keys, vals, &occ, src[i], tb.log_pages, slow, lane, stats, sp, n_new, page, filter);
-  for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
-  if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&nnew, n_new);
+  // tail (< 4*PG_WG records): straight through the general probe
+  for (uint64_t i = (uint64_t)n_quads * 4 * PG_WG + threadIdx.x; i < n; i += PG_WG) insert(src[i]);
   __syncthreads();
-  // LDS → page
-  for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 2; j += PG_WG)
-    reinterpret_cast<ulonglong2 *>(gk)[j] = reinterpret_cast<const ulonglong2 *>(keys)[j];
-  for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG)
-    reinterpret_cast<uint4 *>(gv)[j] = reinterpret_cast<const uint4 *>(vals)[j];
-  if (threadIdx.x == 0 && nnew) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
+  // LDS → page: counts += deltas (saturating), four slots per lane; then the keys if any is new
+  for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG) {
+    const uint2 d = reinterpret_cast<const uint2 *>(dl)[j];
+    if (d.x | d.y) {
+      uint4 v = reinterpret_cast<const uint4 *>(gv)[j];
+      v.x = sat_add_u32(v.x, d.x & 0xFFFFu);
+      v.y = sat_add_u32(v.y, d.x >> 16);
+      v.z = sat_add_u32(v.z, d.y & 0xFFFFu);
+      v.w = sat_add_u32(v.w, d.y >> 16);
+      reinterpret_cast<uint4 *>(gv)[j] = v;
+    }
+  }
+  __syncthreads();
+  const uint32_t nnew = pg_wg_sum(n_new, dl);
+  if (nnew) {
+    for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 2; j += PG_WG)
+      reinterpret_cast<ulonglong2 *>(gk)[j] = reinterpret_cast<const ulonglong2 *>(keys)[j];
+    if (threadIdx.x == 0) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
+  }
 }
 
 }  // namespace shk

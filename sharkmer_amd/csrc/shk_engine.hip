@@ -379,7 +379,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   DevBuf &buf_pg = two_level ? c->part3 : c->part;  // what k_pages reads
   HIPC(c, c->part.ensure((uint64_t)P1 * cap1 * 8));
   if (two_level) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * 8));
-  HIPC(c, c->part2.ensure((uint64_t)n_pages * cap_pg * 8));  // k_pages miss queues (same offsets)
+  HIPC(c, c->part2.ensure((uint64_t)n_pages * ((uint64_t)cap_pg + MISS_SLACK) * 8));  // k_pages miss queues
   HIPC(c, c->part_meta.ensure(((size_t)P1 + n_pages) * 4 + 64));
   unsigned int *cursor1 = (unsigned int *)c->part_meta.p;
   unsigned int *cursor_pg = two_level ? cursor1 + P1 : cursor1;
@@ -409,7 +409,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     }
     {
       ScopedTimer t(c, SHK_K_PAGES);
-      hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane, 0u,
+      hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
                          (const unsigned int *)cursor_pg, cap_pg, (const uint64_t *)buf_pg.p,
                          (uint64_t *)c->part2.p, c->d_stats, sp);
     }
