@@ -21,6 +21,7 @@ using namespace shk;
 
 struct shk_ctx;
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub);
+static int settle(shk_ctx *c);
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -82,6 +83,8 @@ struct shk_ctx {
   uint64_t own_p0 = 0, own_p1 = 0;  // owned page range for finalize (0,0 = all)
   bool own_set = false;
   bool finalized = false, poisoned = false;
+  bool unsettled = false;  // a counting launch whose outcome the host has not looked at yet
+  uint64_t unsettled_spill_cap = 0;
   int poison_code = 0;
   std::string err;
   // timing
@@ -264,6 +267,10 @@ constexpr uint64_t MAX_SUB_BASES = 1ull << 28;  // bases per counting launch (bo
 int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_seqs,
                 uint64_t n_bases, int64_t lane_fixed) {
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  {
+    int rc0 = settle(c);  // the previous launch's spill list / scratch must be done with
+    if (rc0 != SHK_OK) return rc0;
+  }
   c->finalized = false;
   const uint64_t g0 = c->n_reads_read;
   const uint32_t NL = c->n_lanes;
@@ -322,6 +329,10 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     uint64_t sub_kmers_ub = tn * TILE_T;
     b.tile_first = ta;
     b.tile_count = tn;
+    if (ta) {
+      int rcs = settle(c);
+      if (rcs != SHK_OK) return rcs;
+    }
     // capacity heuristic when no hint was given: assume ≥ 4× coverage; the spill path keeps
     // the result exact whatever the truth is
     int rc = ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : sub_kmers_ub / 4);
@@ -451,8 +462,16 @@ static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub) {
     hipLaunchKernelGGL(k_direct, dim3(grid_for(b.tile_count, 1, 256 * 8)), dim3(WG), 0, c->stream, b,
                        c->tb, c->d_stats, sp);
   }
-  int rc = read_stats(c);
-  if (rc != SHK_OK) return rc;
+  // Nothing is waited for here: the host looks at the launch's outcome (invalid byte, spilled
+  // records, load factor) in settle(), at the latest before the next launch or at finalize.
+  c->unsettled = true;
+  c->unsettled_spill_cap = sub_kmers_ub;
+  return SHK_OK;
+}
+
+// Outcome of the last counting launch, h_stats already read back and synchronised.
+static int settle_checked(shk_ctx *c) {
+  c->unsettled = false;
   if (c->h_stats->bad != ~0ull) {
     // identical text to encoding.rs:353-356
     c->poisoned = true;
@@ -460,7 +479,7 @@ static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub) {
     return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%c' in sequence. Only ACGTN allowed.",
                 (char)(c->h_stats->bad & 0xFF));
   }
-  rc = drain_spill(c, sub_kmers_ub);
+  int rc = drain_spill(c, c->unsettled_spill_cap);
   if (rc != SHK_OK) return rc;
   // keep the load factor ≤ 1/2 for the next launch
   if (c->h_stats->n_distinct * 2 > c->tb.cap) {
@@ -468,6 +487,13 @@ static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub) {
     if (rc != SHK_OK) return rc;
   }
   return SHK_OK;
+}
+
+static int settle(shk_ctx *c) {
+  if (!c->unsettled) return SHK_OK;
+  int rc = read_stats(c);
+  if (rc != SHK_OK) return rc;
+  return settle_checked(c);
 }
 
 // =============================================================================================
@@ -592,6 +618,7 @@ int shk_reset(shk_ctx *c) {
   c->n_inserted = 0;
   c->own_set = false;
   c->finalized = c->poisoned = false;
+  c->unsettled = false;  // the memsets above are ordered behind any launch still in flight
   c->poison_code = 0;
   c->err.clear();
   return SHK_OK;
@@ -651,6 +678,13 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     // the other buffer is free: slice i-1 was counted synchronously.  Its copy now overlaps
     // the counting of slice i.
     HIPC(c, hipEventSynchronize(c->copy_done[bsel]));  // `rebased[bsel]` consumed; data resident
+    // slice i-1 (launched without a host sync) read the buffer slice i+1 is about to overwrite
+    rc = settle(c);
+    if (rc != SHK_OK) {
+      (void)hipStreamSynchronize(c->copy_stream);
+      return rc;
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
     if (i + 1 < n_slices) {
       rc = issue_copy(i + 1);
       if (rc != SHK_OK) return rc;
@@ -665,7 +699,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
       return rc;
     }
   }
-  return SHK_OK;
+  return settle(c);  // host-buffer ingest reports its errors before returning
 }
 
 int shk_ingest_batch(shk_ctx *c, uint32_t chunk_id, const uint8_t *bases, const uint64_t *offsets,
@@ -697,6 +731,10 @@ int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, cons
                       uint64_t n) {
   if (!c) return SHK_ERR_BAD_ARG;
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
   if (chunk_id >= c->n_lanes) return fail(c, SHK_ERR_BAD_ARG, "chunk_id out of range");
   if (n == 0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -731,7 +769,7 @@ int shk_sync(shk_ctx *c) {
   HIPC(c, hipSetDevice(c->cfg.device));
   HIPC(c, hipStreamSynchronize(c->stream));
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
-  return SHK_OK;
+  return settle(c);
 }
 
 int shk_finalize(shk_ctx *c) {
@@ -766,7 +804,19 @@ int shk_finalize(shk_ctx *c) {
   HIPC(c, hipMemcpyAsync(c->h_hist.data(), c->d_hist, hist_n * sizeof(uint64_t), hipMemcpyDeviceToHost,
                          c->stream));
   HIPC(c, hipMemcpyAsync(&c->h_tot, c->d_tot, sizeof(HistoTotals), hipMemcpyDeviceToHost, c->stream));
+  // One host sync serves both the last counting launch and the scan: the scan was queued
+  // optimistically; if that launch turns out to have spilled records (or hit an invalid byte)
+  // it is settled now and the scan repeated over the repaired table.
+  const bool was_unsettled = c->unsettled;
+  if (was_unsettled)
+    HIPC(c, hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats), hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));
+  if (was_unsettled) {
+    const bool redo = c->h_stats->bad != ~0ull || c->h_stats->spill_count > 0;
+    int rcs = settle_checked(c);
+    if (rcs != SHK_OK) return rcs;
+    if (redo) return shk_finalize(c);
+  }
   if (!c->own_set) {
     // io.rs:1042-1047 (and :1150-1155 for chunks==0)
     if (c->h_tot.n_hashed != c->h_tot.n_lane_sum)
@@ -800,6 +850,10 @@ int shk_histograms(shk_ctx *c, uint64_t *out) {
 int shk_get_counters(shk_ctx *c, shk_counters *o) {
   if (!c || !o) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
   memset(o, 0, sizeof *o);
   for (auto v : c->lane_reads) o->n_reads_ingested += v;
   o->n_bases_read = c->n_bases_read;
@@ -842,6 +896,10 @@ int shk_reset_timings(shk_ctx *c) {
 int shk_export_table(shk_ctx *c, uint64_t *kmers, uint32_t *counts, uint64_t cap, uint64_t *n_out) {
   if (!c || !n_out) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
   HIPC(c, c->misc.ensure(cap * 12 + 16));
   uint8_t *p = (uint8_t *)c->misc.p;
   unsigned long long *dn = (unsigned long long *)p;
@@ -872,6 +930,10 @@ int shk_lookup(shk_ctx *c, const uint64_t *kmers, uint32_t *counts, uint64_t n, 
   if (!c) return SHK_ERR_BAD_ARG;
   if (n == 0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
   HIPC(c, c->misc.ensure(n * 12));
   uint64_t *dk = (uint64_t *)c->misc.p;
   uint32_t *dc = (uint32_t *)((uint8_t *)c->misc.p + n * 8);
@@ -888,6 +950,11 @@ int shk_lookup(shk_ctx *c, const uint64_t *kmers, uint32_t *counts, uint64_t n, 
 
 int shk_table_geometry(shk_ctx *c, uint64_t *n_pages, uint32_t *page_slots, uint32_t *n_lanes) {
   if (!c) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);  // a pending spill may still grow the table
+    if (rcs != SHK_OK) return rcs;
+  }
   if (n_pages) *n_pages = 1ull << c->tb.log_pages;
   if (page_slots) *page_slots = PAGE_SLOTS;
   if (n_lanes) *n_lanes = c->n_lanes;
@@ -897,6 +964,10 @@ int shk_table_geometry(shk_ctx *c, uint64_t *n_pages, uint32_t *page_slots, uint
 int shk_table_reserve_pages(shk_ctx *c, uint64_t n_pages) {
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
   uint32_t lp = 0;
   while ((1ull << lp) < n_pages) lp++;
   c->finalized = false;
@@ -906,6 +977,10 @@ int shk_table_reserve_pages(shk_ctx *c, uint64_t n_pages) {
 int shk_table_device_ptrs(shk_ctx *c, void **d_keys, void **d_vals) {
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
   HIPC(c, hipStreamSynchronize(c->stream));
   if (d_keys) *d_keys = c->tb.keys;
   if (d_vals) *d_vals = c->tb.vals;
@@ -917,6 +992,10 @@ int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, co
   if (!c) return SHK_ERR_BAD_ARG;
   if (p1 <= p0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
   c->finalized = false;
   const uint64_t n_slots = (p1 - p0) << PAGE_LOG;
   // worst case every peer key is new here
