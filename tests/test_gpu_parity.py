@@ -401,3 +401,29 @@ def test_two_level_partition_large_table():
     assert int(h[0].sum()) == c["n_unique_kmers"] and c["n_spilled"] == 0
     # 17x coverage of a 30 Mb genome: nearly every genomic 21-mer seen at least once
     assert 0.99 * 30_000_000 < c["n_unique_kmers"] <= 30_000_000
+
+
+# ---- parameter extremes ------------------------------------------------------------------------------
+
+def test_many_chunks_take_the_direct_path(orc):
+    """More chunk lanes than the paged path handles (16): the atomics path with per-tile lanes."""
+    spec = sa.SynthSpec(genome_len=20_000, sub_per_64k=328, n_per_64k=66)
+    bases, offsets = sa.synth_reads(spec, 0, 45_500)
+    check_against_oracle(orc, bases, offsets, 21, 40, 300, check_table=False)
+
+
+@pytest.mark.parametrize("histo_max", [1, 1_000_000])
+def test_histo_max_extremes(orc, histo_max):
+    """cli.rs:668-673: 0 < histo_max ≤ 1_000_000; counts above fold into the last bin."""
+    spec = sa.SynthSpec(genome_len=1_000, sub_per_64k=100)
+    bases, offsets = sa.synth_reads(spec, 0, 20_000)
+    check_against_oracle(orc, bases, offsets, 15, 2, histo_max, check_table=False)
+
+
+@pytest.mark.parametrize("k", [2, 16, 20, 30])
+def test_even_k_is_accepted_by_the_library(orc, k):
+    """"k odd" is the CLI's rule (cli.rs:667); the kmer module takes any 0 < k < 32
+    (encoding.rs:333), palindromic k-mers included (fwd == rev)."""
+    rng = np.random.default_rng(k)
+    bases, offsets = ragged_reads(rng, 6_000, max_len=120)
+    check_against_oracle(orc, bases, offsets, k, 2, 40)
