@@ -183,6 +183,14 @@ int shk_export_table(shk_ctx *ctx, uint64_t *kmers, uint32_t *counts, uint64_t c
 int shk_lookup(shk_ctx *ctx, const uint64_t *kmers, uint32_t *counts, uint64_t n,
                int canonical);
 
+/* find_oligos_in_kmers (src/pcr/primers.rs:163-226), sPCR's primer seed scan over the merged
+ * table: oligos[] are 2-bit encoded values of oligo_len bases (1 ≤ oligo_len < k).  A k-mer
+ * with merged count ≥ min_count whose FIRST oligo_len bases equal an oligo is reported as is;
+ * one whose LAST oligo_len bases equal an oligo's reverse complement is reported
+ * reverse-complemented (primers.rs:212-223).  Same output convention as shk_export_table. */
+int shk_find_oligos(shk_ctx *ctx, const uint64_t *oligos, uint32_t n_oligos, uint32_t oligo_len,
+                    uint32_t min_count, uint64_t *kmers, uint32_t *counts, uint64_t cap, uint64_t *n_out);
+
 /* ---- multi-GPU hooks (device pointers; exchanged by the caller over RCCL) ---- */
 
 /* Table geometry needed to shard by owner: n_pages (power of two),

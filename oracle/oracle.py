@@ -126,6 +126,8 @@ def lib():
     L.orc_counts_remove_low.restype = None
     L.orc_counts_export.argtypes = [C.c_void_p, u64p, u32p]
     L.orc_counts_export.restype = C.c_size_t
+    L.orc_find_oligos.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.c_uint32, u64p, u32p]
+    L.orc_find_oligos.restype = C.c_size_t
 
     L.orc_histo_new.argtypes = [C.c_uint64]
     L.orc_histo_new.restype = C.c_void_p
@@ -322,6 +324,19 @@ class KmerCounts:
 
     def remove_low_count_kmers(self, min_count):
         lib().orc_counts_remove_low(self._p, min_count)
+
+    def find_oligos(self, oligos, oligo_len: int, min_count: int = 1):
+        """find_oligos_in_kmers (pcr/primers.rs:163-226) → (kmers, counts) sorted by k-mer."""
+        oligos = np.ascontiguousarray(np.atleast_1d(oligos), dtype=np.uint64)
+        n = len(self)
+        keys = np.empty(max(n, 1), dtype=np.uint64)
+        cnts = np.empty(max(n, 1), dtype=np.uint32)
+        m = lib().orc_find_oligos(self._p, oligos.ctypes.data_as(C.POINTER(C.c_uint64)), len(oligos),
+                                  oligo_len, min_count, keys.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                  cnts.ctypes.data_as(C.POINTER(C.c_uint32)))
+        keys, cnts = keys[:m], cnts[:m]
+        o = np.argsort(keys, kind="stable")
+        return keys[o], cnts[o]
 
     def export(self):
         """iter(): (keys u64[n], counts u32[n]) sorted by key for comparison."""

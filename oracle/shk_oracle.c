@@ -1024,3 +1024,34 @@ int orc_run_write_stats_yaml(const orc_run *r, const char *path, const char *ver
   fclose(f);
   return ORC_OK;
 }
+
+/* find_oligos_in_kmers, src/pcr/primers.rs:163-226 — the consumer-side scan of the merged
+ * table.  oligos: 2-bit values of oligo_len bases.  Writes the matching
+ * (k-mer, count) pairs (reverse-complemented for the rc orientation, :219-222); returns n. */
+size_t orc_find_oligos(const orc_counts *c, const uint64_t *oligos, size_t n_oligos, int oligo_len,
+                       uint32_t min_count, uint64_t *out_kmers, uint32_t *out_counts) {
+  const int k = c->k;
+  uint64_t mask = 0;
+  for (int i = 0; i < 2 * oligo_len; i++) mask = (mask << 1) | 1; /* :195-198 */
+  mask <<= 2 * k - 2 * oligo_len;
+  const uint64_t rc_mask = (1ull << (2 * oligo_len)) - 1; /* :203 */
+  size_t n = 0;
+  for (size_t i = 0; i < c->kmers.cap; i++) {
+    uint64_t kmer = c->kmers.keys[i];
+    if (kmer == MAP_EMPTY) continue;
+    uint32_t count = c->kmers.vals[i];
+    if (count < min_count) continue; /* :213 */
+    int hit = 0;
+    for (size_t j = 0; j < n_oligos && !hit; j++)
+      if ((oligos[j] << (2 * (k - oligo_len))) == (kmer & mask)) hit = 1; /* :214 */
+    if (!hit)
+      for (size_t j = 0; j < n_oligos && !hit; j++)
+        if (orc_revcomp_kmer(oligos[j], oligo_len) == (kmer & rc_mask)) hit = 2; /* :216 */
+    if (hit) {
+      out_kmers[n] = hit == 1 ? kmer : orc_revcomp_kmer(kmer, k);
+      out_counts[n] = count;
+      n++;
+    }
+  }
+  return n;
+}

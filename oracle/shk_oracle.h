@@ -84,6 +84,10 @@ void orc_counts_remove_low(orc_counts *c, uint32_t min_count); /* :234-237 */
 /* iter(), :239-241: export all (kmer,count) pairs; arrays sized n_unique */
 size_t orc_counts_export(const orc_counts *c, uint64_t *keys, uint32_t *counts);
 
+/* find_oligos_in_kmers, src/pcr/primers.rs:163-226; outputs sized n_unique */
+size_t orc_find_oligos(const orc_counts *c, const uint64_t *oligos, size_t n_oligos, int oligo_len,
+                       uint32_t min_count, uint64_t *out_kmers, uint32_t *out_counts);
+
 /* ---- histogram.rs: Histogram ----------------------------------------- */
 
 typedef struct orc_histo orc_histo;

@@ -804,6 +804,58 @@ __global__ void __launch_bounds__(WG) k_export(TableRef tb, uint64_t slot0, uint
 }
 
 // ==========================================================================================
+// K_OLIGO: the primer seed scan of sPCR, find_oligos_in_kmers (src/pcr/primers.rs:163-226): one
+// bandwidth-bound pass over the merged table.  A k-mer with count ≥ min_count is reported as
+// is when its first oligo_len bases equal one of the oligos, or reverse-complemented when its
+// LAST oligo_len bases equal the reverse complement of one (primers.rs:212-223).  The two
+// sorted oligo sets sit in LDS; membership = binary search.
+// ==========================================================================================
+__device__ __forceinline__ bool in_sorted(const uint64_t *a, uint32_t n, uint64_t x) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo < n && a[lo] == x;
+}
+
+__global__ void __launch_bounds__(WG) k_find_oligos(TableRef tb, uint64_t slot0, uint64_t slot1, int k,
+                                                    int oligo_len, uint32_t min_count,
+                                                    const uint64_t *__restrict__ fwd_set /* shifted, sorted */,
+                                                    const uint64_t *__restrict__ rc_set /* sorted */,
+                                                    uint32_t n_oligos, uint64_t *__restrict__ out_kmers,
+                                                    uint32_t *__restrict__ out_counts, uint64_t cap,
+                                                    unsigned long long *__restrict__ n_out) {
+  extern __shared__ uint64_t sets[];  // fwd then rc
+  for (uint32_t i = threadIdx.x; i < n_oligos; i += WG) {
+    sets[i] = fwd_set[i];
+    sets[n_oligos + i] = rc_set[i];
+  }
+  __syncthreads();
+  const uint64_t mask = ((1ull << (2 * oligo_len)) - 1) << (2 * (k - oligo_len));
+  const uint64_t rc_mask = (1ull << (2 * oligo_len)) - 1;
+  for (uint64_t s = slot0 + (uint64_t)blockIdx.x * WG + threadIdx.x; s < slot1;
+       s += (uint64_t)gridDim.x * WG) {
+    const uint64_t key = tb.keys[s];
+    if (key == EMPTY) continue;
+    uint32_t cum = 0;
+    for (uint32_t l = 0; l < tb.n_lanes; ++l) cum = sat_add_u32(cum, tb.vals[(uint64_t)l * tb.cap + s]);
+    if (cum < min_count) continue;
+    uint64_t hit = EMPTY;
+    if (in_sorted(sets, n_oligos, key & mask)) hit = key;
+    else if (in_sorted(sets + n_oligos, n_oligos, key & rc_mask)) hit = revcomp(key, k);
+    if (hit != EMPTY) {
+      unsigned long long i = atomicAdd(n_out, 1ull);
+      if (i < cap) {
+        out_kmers[i] = hit;
+        out_counts[i] = cum;
+      }
+    }
+  }
+}
+
+// ==========================================================================================
 // K_MERGE: KmerCounts::extend across devices (counting.rs:157-166): fold a peer's page range
 // (same geometry) into this table, lane by lane, saturating.
 // ==========================================================================================

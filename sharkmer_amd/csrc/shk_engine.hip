@@ -948,6 +948,66 @@ int shk_lookup(shk_ctx *c, const uint64_t *kmers, uint32_t *counts, uint64_t n, 
   return SHK_OK;
 }
 
+int shk_find_oligos(shk_ctx *c, const uint64_t *oligos, uint32_t n_oligos, uint32_t oligo_len,
+                    uint32_t min_count, uint64_t *kmers, uint32_t *counts, uint64_t cap, uint64_t *n_out) {
+  if (!c || !n_out) return SHK_ERR_BAD_ARG;
+  const uint32_t k = c->cfg.k;
+  // the reference asserts these (primers.rs:169-186)
+  if (n_oligos == 0 || !oligos) return fail(c, SHK_ERR_BAD_ARG, "find_oligos_in_kmers called with no oligos");
+  if (!(oligo_len > 0 && oligo_len < k))
+    return fail(c, SHK_ERR_BAD_ARG, "oligo length %u out of range for k=%u (must be 1..k-1); trim must be < k",
+                oligo_len, k);
+  if (n_oligos > 3000) return fail(c, SHK_ERR_BAD_ARG, "too many oligos (%u > 3000)", n_oligos);
+  HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
+  auto rc_of = [](uint64_t x, int len) {  // reverse complement of a len-base value (host side)
+    uint64_t r = 0;
+    for (int i = 0; i < len; ++i) {
+      r = (r << 2) | (3 - (x & 3));
+      x >>= 2;
+    }
+    return r;
+  };
+  std::vector<uint64_t> fwd(n_oligos), rc(n_oligos);
+  for (uint32_t i = 0; i < n_oligos; ++i) {
+    fwd[i] = oligos[i] << (2 * (k - oligo_len));  // primers.rs:189-192
+    rc[i] = rc_of(oligos[i], (int)oligo_len);      // primers.rs:206-209
+  }
+  std::sort(fwd.begin(), fwd.end());
+  std::sort(rc.begin(), rc.end());
+  HIPC(c, c->misc.ensure((size_t)n_oligos * 16 + cap * 12 + 64));
+  uint8_t *p = (uint8_t *)c->misc.p;
+  unsigned long long *dn = (unsigned long long *)p;
+  uint64_t *dsets = (uint64_t *)(p + 16);
+  uint64_t *dk = dsets + 2 * (size_t)n_oligos;
+  uint32_t *dc = (uint32_t *)(dk + cap);
+  HIPC(c, hipMemsetAsync(dn, 0, 8, c->stream));
+  HIPC(c, hipMemcpyAsync(dsets, fwd.data(), (size_t)n_oligos * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(dsets + n_oligos, rc.data(), (size_t)n_oligos * 8, hipMemcpyHostToDevice, c->stream));
+  uint64_t s0 = 0, s1 = c->tb.cap;
+  if (c->own_set) {
+    s0 = c->own_p0 << PAGE_LOG;
+    s1 = c->own_p1 << PAGE_LOG;
+  }
+  {
+    ScopedTimer t(c, SHK_K_LOOKUP);
+    hipLaunchKernelGGL(k_find_oligos, dim3(grid_for(s1 - s0, WG * 8, 2048)), dim3(WG), (size_t)n_oligos * 16,
+                       c->stream, c->tb, s0, s1, (int)k, (int)oligo_len, min_count, (const uint64_t *)dsets,
+                       (const uint64_t *)(dsets + n_oligos), n_oligos, dk, dc, cap, dn);
+  }
+  unsigned long long n = 0;
+  HIPC(c, hipMemcpyAsync(&n, dn, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));  // also keeps fwd/rc alive until their copies ran
+  *n_out = n;
+  uint64_t m = std::min<uint64_t>(n, cap);
+  if (m && kmers) HIPC(c, hipMemcpy(kmers, dk, m * 8, hipMemcpyDeviceToHost));
+  if (m && counts) HIPC(c, hipMemcpy(counts, dc, m * 4, hipMemcpyDeviceToHost));
+  return SHK_OK;
+}
+
 int shk_table_geometry(shk_ctx *c, uint64_t *n_pages, uint32_t *page_slots, uint32_t *n_lanes) {
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));

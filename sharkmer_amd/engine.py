@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "shk_abi_version", "shk_create", "shk_destroy", "shk_reset", "shk_last_error", "shk_ingest_batch",
     "shk_ingest_reads", "shk_set_read_index", "shk_ingest_reads_device", "shk_insert_counts", "shk_sync", "shk_finalize",
     "shk_histograms", "shk_get_counters", "shk_get_timings", "shk_reset_timings",
-    "shk_export_table", "shk_lookup", "shk_table_geometry", "shk_table_reserve_pages",
+    "shk_export_table", "shk_lookup", "shk_find_oligos", "shk_table_geometry", "shk_table_reserve_pages",
     "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
     "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_synth_reads_device",
     "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_stats",
@@ -156,6 +156,7 @@ def load_library():
     L.shk_reset_timings.argtypes = [vp]
     L.shk_export_table.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.shk_lookup.argtypes = [vp, vp, vp, u64, C.c_int]
+    L.shk_find_oligos.argtypes = [vp, vp, u32, u32, u32, vp, vp, u64, C.POINTER(u64)]
     L.shk_table_geometry.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
     L.shk_table_reserve_pages.argtypes = [vp, u64]
     L.shk_table_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -328,6 +329,21 @@ class KmerEngine:
         self._check(self._L.shk_lookup(self._h, kmers.ctypes.data, out.ctypes.data, len(kmers),
                                        1 if canonical else 0))
         return out
+
+    def find_oligos(self, oligos, oligo_len: int, min_count: int = 1):
+        """find_oligos_in_kmers (pcr/primers.rs:163-226): (kmers, counts) sorted by k-mer."""
+        oligos = np.ascontiguousarray(np.atleast_1d(oligos), dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._check(self._L.shk_find_oligos(self._h, oligos.ctypes.data, len(oligos), oligo_len, min_count,
+                                            None, None, 0, C.byref(n)))
+        cap = int(n.value)
+        keys = np.zeros(cap, dtype=np.uint64)
+        cnts = np.zeros(cap, dtype=np.uint32)
+        if cap:
+            self._check(self._L.shk_find_oligos(self._h, oligos.ctypes.data, len(oligos), oligo_len,
+                                                min_count, keys.ctypes.data, cnts.ctypes.data, cap, C.byref(n)))
+        o = np.argsort(keys, kind="stable")
+        return keys[o], cnts[o]
 
     # -- multi-GPU hooks ---------------------------------------------------------------
     def table_geometry(self):

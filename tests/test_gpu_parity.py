@@ -427,3 +427,52 @@ def test_even_k_is_accepted_by_the_library(orc, k):
     rng = np.random.default_rng(k)
     bases, offsets = ragged_reads(rng, 6_000, max_len=120)
     check_against_oracle(orc, bases, offsets, k, 2, 40)
+
+
+# ---- the merged table's read API as sPCR uses it -------------------------------------
+
+@pytest.mark.parametrize("oligo_len,min_count", [(8, 1), (12, 2), (20, 3)])
+def test_find_oligos_in_kmers(orc, oligo_len, min_count):
+    """pcr/primers.rs:163-226: start-of-k-mer matches as is, reverse-orientation matches
+    reverse-complemented, count threshold applied."""
+    spec = sa.SynthSpec(genome_len=30_000, sub_per_64k=200)
+    bases, offsets = sa.synth_reads(spec, 0, 12_000)
+    k = 21
+    ref = orc.run_batch(bases, offsets, k, 2, 100)
+    merged = ref.merged()
+    keys, _ = merged.export()
+    rng = np.random.default_rng(oligo_len)
+    # oligos: prefixes of some table k-mers (forward hits), suffix-revcomps of others (rc hits), noise
+    pick = rng.choice(len(keys), size=40, replace=False)
+    oligos = [int(keys[i]) >> (2 * (k - oligo_len)) for i in pick[:20]]
+    oligos += [orc.revcomp_kmer(int(keys[i]) & ((1 << (2 * oligo_len)) - 1), oligo_len) for i in pick[20:]]
+    oligos += [int(x) for x in rng.integers(0, 1 << (2 * oligo_len), size=10)]
+    want_k, want_c = merged.find_oligos(oligos, oligo_len, min_count)
+    with sa.KmerEngine(k, 2, 100) as eng:
+        eng.ingest_reads(bases, offsets)
+        eng.finalize()
+        got_k, got_c = eng.find_oligos(oligos, oligo_len, min_count)
+        with pytest.raises(sa.ShkError):
+            eng.find_oligos(oligos, k, 1)  # oligo_len must be < k (primers.rs:181-186)
+    assert len(want_k) > 0
+    assert np.array_equal(got_k, want_k) and np.array_equal(got_c, want_c)
+
+
+@pytest.mark.parametrize("seq,k,oligo,min_count,expected", [
+    ("ACGTACGT", 5, "ACG", 1, None), ("AAAAAAAAAA", 5, "GGG", 1, []), ("AACCCAACC", 5, "AAC", 2, []),
+    ("TTTTTTT", 5, "AAA", 1, ["AAAAA"]), ("ACGTACGT", 5, "ACGT", 1, None)])
+def test_find_oligos_reference_cases(orc, seq, k, oligo, min_count, expected):
+    """The reference's own cases, pcr/primers.rs:603-695, through the C ABI."""
+    kc = orc.KmerCounts(k)
+    kc.ingest_seq(seq)
+    want_k, want_c = kc.find_oligos([orc.seq_to_kmer(oligo)], len(oligo), min_count)
+    bases = np.frombuffer(seq.encode(), dtype=np.uint8)
+    with sa.KmerEngine(k, 1, 100) as eng:
+        eng.ingest_reads(bases, np.array([0, len(seq)], dtype=np.uint64))
+        eng.finalize()
+        got_k, got_c = eng.find_oligos([orc.seq_to_kmer(oligo)], len(oligo), min_count)
+    assert np.array_equal(got_k, want_k) and np.array_equal(got_c, want_c)
+    if expected is not None:
+        assert [orc.kmer_to_seq(int(x), k) for x in got_k] == expected
+    else:
+        assert len(got_k) > 0

@@ -242,3 +242,30 @@ def test_get_canonical(orc):
     cgt = orc.seq_to_kmer("CGT")
     assert kc.get_canonical(acg) == 1 and kc.get_canonical(cgt) == 1
     assert kc.get_canonical_count(cgt) == 1 and kc.get_canonical(orc.seq_to_kmer("AAA")) is None
+
+
+# ---- pcr/primers.rs:593-695: find_oligos_in_kmers (the consumer-side scan of the merged table) ------------
+
+_OLIGO_KATS = [
+    # (sequence, k, oligo, min_count, expected k-mer strings or None for "non-empty")
+    ("ACGTACGT", 5, "ACG", 1, None),          # test_find_oligos_exact_match_forward
+    ("AAAAAAAAAA", 5, "GGG", 1, []),          # test_find_oligos_no_match
+    ("AACCCAACC", 5, "AAC", 2, []),           # test_find_oligos_min_count_filter
+    ("TTTTTTT", 5, "AAA", 1, ["AAAAA"]),      # test_find_oligos_rc_match
+    ("ACGTACGT", 5, "ACGT", 1, None),         # test_find_oligos_oligo_equals_k_minus_1
+]
+
+
+@pytest.mark.parametrize("seq,k,oligo,min_count,expected", _OLIGO_KATS)
+def test_find_oligos_in_kmers(orc, seq, k, oligo, min_count, expected):
+    kc = orc.KmerCounts(k)
+    kc.ingest_seq(seq)
+    kmers, counts = kc.find_oligos([orc.seq_to_kmer(oligo)], len(oligo), min_count)
+    got = [orc.kmer_to_seq(int(x), k) for x in kmers]
+    if expected is None:
+        assert got
+        assert all(s.startswith(oligo) for s in got)   # reported in the oligo's orientation
+    else:
+        assert got == expected
+    for x, c in zip(kmers, counts):
+        assert kc.get_canonical_count(int(x)) == int(c) >= min_count
