@@ -14,6 +14,7 @@
 //   histogram    src/kmer/counting.rs:171-202 + src/kmer/histogram.rs:51-85,125-134
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace shk {
@@ -36,12 +37,14 @@ struct TileDesc {
 };
 
 struct DevStats {
+  unsigned long long bad;          // min over (position<<8 | byte) of invalid bytes; ~0 = none
+  unsigned long long bad_pad;      // (bad, bad_pad) = the control block's first 16-B word: reset fills it with ~0
   unsigned long long n_distinct;   // keys inserted so far (all launches)
   unsigned long long spill_count;  // entries in the spill list (this launch)
-  unsigned long long bad;          // min over (position<<8 | byte) of invalid bytes; ~0 = none
   unsigned long long n_tiles;      // written by k_build_tiles
-  unsigned long long scratch[4];
+  unsigned long long scratch[3];
 };
+static_assert(sizeof(DevStats) == 64 && offsetof(DevStats, bad) == 0, "control block layout");
 
 struct TableRef {
   uint64_t *keys;
@@ -447,12 +450,45 @@ __device__ __forceinline__ void sat_add_atomic(uint32_t *p, uint32_t delta) {
 }
 
 // ==========================================================================================
+// K_FILL: up to four buffers set to a 64-bit pattern in ONE launch (table reset: keys = EMPTY,
+// counts = 0, control block = initial state).  Every segment is 16-B aligned and a multiple of
+// 16 B long; the segments are walked as one concatenated range of 16-B words.
+// ==========================================================================================
+struct FillSegs {
+  void *ptr[4];
+  uint64_t n16[4];  // length in 16-B words
+  uint64_t val[4];  // 64-bit pattern
+};
+__global__ void __launch_bounds__(WG) k_fill(FillSegs f) {
+  const uint64_t total = f.n16[0] + f.n16[1] + f.n16[2] + f.n16[3];
+  for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < total; i += (uint64_t)gridDim.x * WG) {
+    uint64_t j = i;
+    int sgm = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (sgm == q && j >= f.n16[q]) {
+        j -= f.n16[q];
+        sgm = q + 1;
+      }
+    ulonglong2 v;
+    v.x = v.y = f.val[sgm];
+    reinterpret_cast<ulonglong2 *>(f.ptr[sgm])[j] = v;
+  }
+}
+
+// ==========================================================================================
 // K_MARK: read-start bitmap.  One thread per read.
 // ==========================================================================================
+// It also clears the small per-launch state of the counting pass that follows it on the stream
+// (partition cursors, spill counter), which saves two fill launches per batch.
 __global__ void __launch_bounds__(WG) k_mark_starts(const uint64_t *__restrict__ offsets,
                                                     uint64_t n_seqs, uint64_t n_bases,
-                                                    uint32_t *__restrict__ startbits) {
+                                                    uint32_t *__restrict__ startbits,
+                                                    unsigned int *__restrict__ zero_u32, uint32_t n_zero,
+                                                    unsigned long long *__restrict__ zero_u64) {
   uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  for (uint64_t j = i; j < n_zero; j += (uint64_t)gridDim.x * WG) zero_u32[j] = 0;
+  if (i == 0 && zero_u64) *zero_u64 = 0;
   if (i >= n_seqs) return;
   uint64_t o = offsets[i], e = offsets[i + 1];
   if (e > o && o < n_bases) atomicOr(&startbits[o >> 5], 1u << (o & 31));
@@ -993,7 +1029,8 @@ constexpr uint32_t PAGE_FILL_CAP = PAGE_SLOTS - PAGE_SLOTS / 8;  // new keys spi
 #ifndef SORTED_WAVES_PER_SIMD
 #define SORTED_WAVES_PER_SIMD 4
 #endif
-constexpr int PACK_WORDS = TILE_LDS / 16 + 2;  // 16 bases per u32, MSB first, + 2 pad words
+constexpr int PACK_WORDS = TILE_GROUPS + 2;  // 16 bases per u32, MSB first, + 2 pad words
+static_assert(TILE_T <= (1 << 14) && TILE_LDS % 16 == 0, "sorted entries: 14-bit position + strand bit");
 // LDS bytes of the sorted-entry region: TILE_T entries + one possible pad per page (u16), and it
 // doubles as the staging area (code bytes + group masks) before the sort
 __host__ __device__ inline uint32_t sort_region_bytes(uint32_t P) {
@@ -1005,15 +1042,26 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w) {  // 4 code bytes → 8 b
   return ((w & 3u) << 6) | (((w >> 8) & 3u) << 4) | (((w >> 16) & 3u) << 2) | ((w >> 24) & 3u);
 }
 
-// canonical k-mer whose LAST base sits at LDS position j (halo included) of the packed tile
-__device__ __forceinline__ uint64_t kmer_at(const uint32_t *packed, int j, int k) {
-  const int s = 2 * (j - k + 1);
+// reverse the order of the sixteen 2-bit fields of x
+__device__ __forceinline__ uint32_t rev2(uint32_t x) {
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  return __builtin_bswap32(x);
+}
+// the k-base window that starts at base index q of an MSB-first packed stream
+__device__ __forceinline__ uint64_t window_at(const uint32_t *stream, int q, int k) {
+  const int s = 2 * q;
   const int wi = s >> 5, off = s & 31;
-  uint64_t x = ((uint64_t)packed[wi] << 32) | packed[wi + 1];
-  if (off) x = (x << off) | ((uint64_t)packed[wi + 2] >> (32 - off));
-  uint64_t fwd = x >> (64 - 2 * k);
-  uint64_t rev = revcomp(fwd, k);
-  return fwd < rev ? fwd : rev;
+  uint64_t x = ((uint64_t)stream[wi] << 32) | stream[wi + 1];
+  if (off) x = (x << off) | ((uint64_t)stream[wi + 2] >> (32 - off));
+  return x >> (64 - 2 * k);
+}
+// Canonical k-mer whose LAST base sits at LDS position j (halo included).  The walk has already
+// decided the strand: rc = 1 ⇔ the reverse complement is the smaller one, and that is a plain
+// window of the mirrored complement stream (base j of the tile is its base TILE_LDS-1-j).
+__device__ __forceinline__ uint64_t kmer_at(const uint32_t *packed, const uint32_t *rcpacked, int j,
+                                            uint32_t rc, int k) {
+  return window_at(rc ? rcpacked : packed, rc ? TILE_LDS - 1 - j : j - k + 1, k);  // one window read, no branch
 }
 
 template <int NT>
@@ -1030,7 +1078,8 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
   uint8_t *codes = reinterpret_cast<uint8_t *>(sh);                 // STAGE_BYTES ≤ sort_bytes
   uint16_t *sorted = reinterpret_cast<uint16_t *>(sh);              // TILE_T + P entries; aliases codes
   uint32_t *packed = sh + sort_bytes / 4;                           // PACK_WORDS
-  uint32_t *cnt = packed + PACK_WORDS;                              // P
+  uint32_t *rcpacked = packed + PACK_WORDS;                         // PACK_WORDS: mirrored complement
+  uint32_t *cnt = rcpacked + PACK_WORDS;                            // P
   uint32_t *tstart = cnt + P;                                       // P
   uint32_t *gbase = tstart + P;                                     // P: this tile's reservation per page
 #ifdef SHK_PHASE_TIMING
@@ -1076,9 +1125,12 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     // for a k-mer that the walk did not emit)
     for (int m = threadIdx.x; m < PACK_WORDS; m += NT) {
       uint32_t v = 0;
-      if (m < TILE_LDS / 16) {
+      if (m < TILE_GROUPS) {
         uint4 c4 = *reinterpret_cast<const uint4 *>(codes + m * 16);
         v = (pack4(c4.x) << 24) | (pack4(c4.y) << 16) | (pack4(c4.z) << 8) | pack4(c4.w);
+        rcpacked[TILE_GROUPS - 1 - m] = rev2(~v);
+      } else {
+        rcpacked[m] = 0;  // the two pad words behind either stream
       }
       packed[m] = v;
     }
@@ -1108,8 +1160,11 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
           roll_step(x, c & 3u, mask_lo, mask_hi);
           uint32_t v = 0xFFFFFFFFu;
           if ((c & 4u) && jemit + q * 8 + r < jend) {
-            uint32_t pc = (uint32_t)page_of(hash64(roll_canonical(x, k)), log_parts);
-            v = (pc << 16) | atomicAdd(&cnt[pc], 1u);
+            const uint64_t fwd = ((uint64_t)x.f_hi << 32) | x.f_lo;
+            const uint64_t rev = (((uint64_t)x.r_hi << 32) | x.r_lo) >> (64 - 2 * k);
+            const bool rc = rev < fwd;
+            const uint32_t pc = (uint32_t)page_of(hash64(rc ? rev : fwd), log_parts);
+            v = (pc << 16) | (rc ? 0x8000u : 0u) | atomicAdd(&cnt[pc], 1u);  // rank < 2^14
           }
           pr[q * 8 + r] = v;
         }
@@ -1151,7 +1206,8 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
 #pragma unroll
     for (int i = 0; i < SPAN; ++i) {
       uint32_t v = pr[i];
-      if (v != 0xFFFFFFFFu) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = (uint16_t)(threadIdx.x * SPAN + i);
+      if (v != 0xFFFFFFFFu)  // entry = end position | strand << 14
+        sorted[tstart[v >> 16] + (v & 0x7FFFu)] = (uint16_t)((threadIdx.x * SPAN + i) | ((v & 0x8000u) >> 1));
     }
     for (uint32_t i = threadIdx.x; i < P; i += NT)
       if (cnt[i] & 1u) sorted[tstart[i] + cnt[i]] = 0xFFFFu;
@@ -1164,8 +1220,9 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     for (uint32_t i = threadIdx.x; i < n_pairs; i += NT) {
       const uint32_t ee = sorted2[i];
       const uint32_t e0 = ee & 0xFFFFu, e1 = ee >> 16;
-      const uint64_t km0 = kmer_at(packed, HALO + (int)e0, k);
-      const uint64_t km1 = e1 == 0xFFFFu ? EMPTY : kmer_at(packed, HALO + (int)e1, k);
+      const uint64_t km0 = kmer_at(packed, rcpacked, HALO + (int)(e0 & 0x3FFFu), e0 >> 14, k);
+      const uint64_t km1 =
+          e1 == 0xFFFFu ? EMPTY : kmer_at(packed, rcpacked, HALO + (int)(e1 & 0x3FFFu), e1 >> 14, k);
       const uint32_t pc = (uint32_t)page_of(hash64(km0), log_parts);
       const uint32_t at = gbase[pc] + (2 * i - tstart[pc]);  // record index inside page pc's region
       if (at + 2 <= cap_p) {

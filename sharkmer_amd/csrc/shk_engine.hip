@@ -20,7 +20,8 @@
 using namespace shk;
 
 struct shk_ctx;
-static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub);
+static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed);
+static int prepare_cursors(shk_ctx *c, uint32_t *n_words);
 static int settle(shk_ctx *c);
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
@@ -65,13 +66,19 @@ struct shk_ctx {
   // table
   TableRef tb{};
   // device state
+  // Control block: every small piece of device state in ONE allocation, mirrored in pinned host
+  // memory with the same layout, so that a reset is one fill launch and the end of a run one copy:
+  //   [DevStats][HistoTotals][lane_bases × n_lanes][pad to 16 B][hist × chunks·(histo_max+2)]
+  uint8_t *d_ctl = nullptr, *h_ctl = nullptr;
+  size_t ctl_bytes = 0, ctl_hist_off = 0;
   DevStats *d_stats = nullptr;
-  DevStats *h_stats = nullptr;  // pinned mirror
-  unsigned long long *d_lane_bases = nullptr;
+  DevStats *h_stats = nullptr;
+  unsigned long long *d_lane_bases = nullptr, *h_lane_bases = nullptr;
   unsigned long long *d_hist = nullptr;
   HistoTotals *d_tot = nullptr;
-  HistoTotals h_tot{};
-  std::vector<uint64_t> h_hist;
+  HistoTotals *h_totp = nullptr;
+  HistoTotals h_tot{};         // the totals of the last finalize
+  const uint64_t *h_hist = nullptr;  // → the mirror's histogram
   // scratch
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_done[2] = {nullptr, nullptr};
@@ -165,6 +172,28 @@ inline uint32_t grid_for(uint64_t n_items, uint32_t per_block, uint32_t cap_bloc
   return (uint32_t)g;
 }
 
+// One launch: table t ← empty (keys = EMPTY, counts = 0) and, with `ctl`, the control block ←
+// initial state.
+int fill_state(shk_ctx *c, const TableRef &t, bool ctl) {
+  FillSegs f{};
+  f.ptr[0] = t.keys;
+  f.n16[0] = t.cap * sizeof(uint64_t) / 16;
+  f.val[0] = ~0ull;
+  f.ptr[1] = t.vals;
+  f.n16[1] = t.cap * sizeof(uint32_t) * t.n_lanes / 16;
+  if (ctl) {  // all zero, except the first 16-B word = DevStats.bad = ~0 ("no invalid byte")
+    f.ptr[2] = c->d_ctl;
+    f.n16[2] = 1;
+    f.val[2] = ~0ull;
+    f.ptr[3] = c->d_ctl + 16;
+    f.n16[3] = c->ctl_bytes / 16 - 1;
+  }
+  const uint64_t total = f.n16[0] + f.n16[1] + f.n16[2] + f.n16[3];
+  hipLaunchKernelGGL(k_fill, dim3(grid_for(total, WG * 4, 4096)), dim3(WG), 0, c->stream, f);
+  HIPC(c, hipGetLastError());
+  return SHK_OK;
+}
+
 int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out) {
   TableRef t{};
   t.log_pages = log_pages;
@@ -177,10 +206,8 @@ int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out) {
     return fail(c, SHK_ERR_NOMEM, "out of device memory allocating %llu-slot table (%u lanes)",
                 (unsigned long long)t.cap, t.n_lanes);
   }
-  HIPC(c, hipMemsetAsync(t.keys, 0xFF, t.cap * sizeof(uint64_t), c->stream));
-  HIPC(c, hipMemsetAsync(t.vals, 0, t.cap * sizeof(uint32_t) * t.n_lanes, c->stream));
   *out = t;
-  return SHK_OK;
+  return fill_state(c, t, false);
 }
 
 int read_stats(shk_ctx *c) {
@@ -302,10 +329,26 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     n_tiles_ub += n_blocks;
     HIPC(c, c->tiles.ensure(n_tiles_ub * sizeof(TileDesc)));
   }
+  // The table geometry of the first counting launch is fixed here, so that k_mark_starts can
+  // clear that launch's partition cursors and the spill counter on its way (capacity heuristic
+  // when no hint was given: assume ≥ 4× coverage; the spill path keeps the result exact whatever
+  // the truth is).
+  const uint64_t tiles_per_sub = MAX_SUB_BASES / TILE_T;
+  {
+    const uint64_t first_kmers_ub = std::min(tiles_per_sub, n_tiles_ub) * TILE_T;
+    int rc = ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : first_kmers_ub / 4);
+    if (rc != SHK_OK) return rc;
+  }
+  uint32_t n_cursor_words = 0;
+  {
+    int rc = prepare_cursors(c, &n_cursor_words);
+    if (rc != SHK_OK) return rc;
+  }
   {
     ScopedTimer t(c, SHK_K_MARK);
     hipLaunchKernelGGL(k_mark_starts, dim3((uint32_t)((n_seqs + WG - 1) / WG)), dim3(WG), 0,
-                       c->stream, d_offsets, n_seqs, n_bases, (uint32_t *)c->startbits.p);
+                       c->stream, d_offsets, n_seqs, n_bases, (uint32_t *)c->startbits.p,
+                       (unsigned int *)c->part_meta.p, n_cursor_words, &c->d_stats->spill_count);
     if (multi)
       hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(TB_WG), 0, c->stream, d_offsets, n_seqs, g0,
                          NL, n_blocks, (TileDesc *)c->tiles.p, c->d_stats);
@@ -323,7 +366,6 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   b.k = (int)c->cfg.k;
 
   // 3. count, in sub-ranges of tiles
-  const uint64_t tiles_per_sub = MAX_SUB_BASES / TILE_T;
   for (uint64_t ta = 0; ta < n_tiles_ub; ta += tiles_per_sub) {
     uint64_t tn = std::min(tiles_per_sub, n_tiles_ub - ta);
     uint64_t sub_kmers_ub = tn * TILE_T;
@@ -333,11 +375,9 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
       int rcs = settle(c);
       if (rcs != SHK_OK) return rcs;
     }
-    // capacity heuristic when no hint was given: assume ≥ 4× coverage; the spill path keeps
-    // the result exact whatever the truth is
-    int rc = ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : sub_kmers_ub / 4);
+    int rc = ta ? ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : sub_kmers_ub / 4) : SHK_OK;
     if (rc != SHK_OK) return rc;
-    rc = count_tiles(c, b, sub_kmers_ub);
+    rc = count_tiles(c, b, sub_kmers_ub, /*prezeroed=*/ta == 0);
     if (rc != SHK_OK) return rc;
   }
   return SHK_OK;
@@ -366,21 +406,43 @@ static uint32_t region_cap(uint64_t n_records_ub, uint64_t n_regions, uint64_t p
   return (uint32_t)std::min<uint64_t>((cap + 1) & ~1ull, 0x7FFFFFF0ull);
 }
 
-static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp) {
-  const uint32_t lp = c->tb.log_pages;
-  const uint32_t n_pages = 1u << lp;
+// Partition geometry of a paged counting pass over the current table.
+// One level: one partition per page.  More than MAX_PARTS pages: level 1 groups the records by
+// super-page (2^log_sub consecutive pages), level 2 (k_part_rescatter) by page.
+struct PartGeom {
+  uint32_t lp, n_pages, log_p1, log_sub, P1;
+  bool two_level;
+  uint32_t cursor_words() const { return P1 + (two_level ? n_pages : 0); }
+};
+static PartGeom part_geom(const shk_ctx *c) {
+  PartGeom g{};
+  g.lp = c->tb.log_pages;
+  g.n_pages = 1u << g.lp;
+  const uint32_t lvl1_log = (uint32_t)env_int("SHK_LEVEL1_LOG", 10);                      // test hooks: force
+  const uint32_t two_level_min = (uint32_t)env_int("SHK_TWO_LEVEL_MIN_PAGES", MAX_PARTS);  // the two-level path
+  g.two_level = g.n_pages > std::min<uint32_t>(two_level_min, (uint32_t)MAX_PARTS);
+  g.log_p1 = g.two_level ? std::min(lvl1_log, g.lp) : g.lp;
+  g.log_sub = g.lp - g.log_p1;
+  g.P1 = 1u << g.log_p1;
+  return g;
+}
+
+// Room for the partition cursors of the next paged pass; *n_words = how many k_mark_starts clears.
+static int prepare_cursors(shk_ctx *c, uint32_t *n_words) {
+  const PartGeom g = part_geom(c);
+  HIPC(c, c->part_meta.ensure(((size_t)g.P1 + g.n_pages) * 4 + 64));  // same size as paged_count asks for
+  *n_words = g.cursor_words();
+  return SHK_OK;
+}
+
+static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed) {
+  const PartGeom pg = part_geom(c);
+  const uint32_t lp = pg.lp, n_pages = pg.n_pages, log_p1 = pg.log_p1, log_sub = pg.log_sub, P1 = pg.P1;
+  const bool two_level = pg.two_level;
   const uint32_t g_cap = (uint32_t)env_int("SHK_PART_G", 512);
-  const uint32_t lvl1_log = (uint32_t)env_int("SHK_LEVEL1_LOG", 10);           // test hooks: force the
-  const uint32_t two_level_min = (uint32_t)env_int("SHK_TWO_LEVEL_MIN_PAGES", MAX_PARTS);  // two-level path
   const uint32_t G = grid_for(b.tile_count, 1, g_cap);
-  // One level: one partition per page.  More than MAX_PARTS pages: level 1 groups the records
-  // by super-page (2^log_sub consecutive pages), level 2 (k_part_rescatter) by page.
-  const bool two_level = n_pages > std::min<uint32_t>(two_level_min, (uint32_t)MAX_PARTS);
-  const uint32_t log_p1 = two_level ? std::min(lvl1_log, lp) : lp;
-  const uint32_t log_sub = lp - log_p1;
   if (two_level && (1u << log_sub) > (uint32_t)MAX_PARTS)
     return fail(c, SHK_ERR_BAD_ARG, "table too large for the two-level partition");
-  const uint32_t P1 = 1u << log_p1;
   // Every region is filled by per-tile reservations (one returning atomic per non-empty
   // (tile, region)); a region that still overflows (skewed input: one k-mer making up a large
   // share of the batch) sends the excess through the spill list — exact either way.
@@ -399,13 +461,14 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   HIPC(c, c->misc.ensure((size_t)G * 64));
   dbg = (unsigned long long *)c->misc.p;
 #endif
-  const size_t lds_sorted = (size_t)sort_region_bytes(P1) + (size_t)PACK_WORDS * 4 + (size_t)P1 * 12;
+  const size_t lds_sorted = (size_t)sort_region_bytes(P1) + (size_t)PACK_WORDS * 8 + (size_t)P1 * 12;
   const uint32_t S = 1u << log_sub;
   const size_t lds_rs = (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12;
   const bool multi = b.tiles != nullptr;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
   for (uint32_t lane = lane_lo; lane < lane_hi; ++lane) {
-    HIPC(c, hipMemsetAsync(cursor1, 0, ((size_t)P1 + (two_level ? n_pages : 0)) * 4, c->stream));
+    if (!(prezeroed && lane == lane_lo))  // the first pass's cursors were cleared by k_mark_starts
+      HIPC(c, hipMemsetAsync(cursor1, 0, (size_t)pg.cursor_words() * 4, c->stream));
     {
       ScopedTimer t(c, SHK_K_SCATTER);
       hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b,
@@ -443,14 +506,15 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   return SHK_OK;
 }
 
-static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub) {
+static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed) {
   HIPC(c, c->spillA.ensure(sub_kmers_ub * 16));
   SpillRef sp = spill_ref(c->spillA, sub_kmers_ub);
-  HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  if (!prezeroed)
+    HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
   bool use_paged = paged_feasible(c) && !(c->cfg.flags & SHK_FLAG_FORCE_DIRECT) &&
                    ((c->cfg.flags & SHK_FLAG_FORCE_PAGED) || paged_pays(c, sub_kmers_ub));
   if (use_paged) {
-    int rc = paged_count(c, b, sub_kmers_ub, sp);
+    int rc = paged_count(c, b, sub_kmers_ub, sp, prezeroed);
     if (rc != SHK_OK) return rc;
   } else {
     {  // validate + count bases first (encoding.rs:353-356, 374-376); k_direct tests stats->bad
@@ -549,19 +613,27 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
     }                                                                                        \
   } while (0)
   HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPB(hipMalloc((void **)&c->d_stats, sizeof(DevStats)));
-  HIPB(hipHostMalloc((void **)&c->h_stats, sizeof(DevStats), hipHostMallocDefault));
-  memset(c->h_stats, 0, sizeof(DevStats));
-  c->h_stats->bad = ~0ull;
-  HIPB(hipMemcpyAsync(c->d_stats, c->h_stats, sizeof(DevStats), hipMemcpyHostToDevice, c->stream));
-  HIPB(hipMalloc((void **)&c->d_lane_bases, sizeof(unsigned long long) * c->n_lanes));
-  HIPB(hipMemsetAsync(c->d_lane_bases, 0, sizeof(unsigned long long) * c->n_lanes, c->stream));
   const size_t hist_n = (size_t)std::max<uint32_t>(cfg->chunks, 1) * (cfg->histo_max + 2);
-  HIPB(hipMalloc((void **)&c->d_hist, hist_n * sizeof(unsigned long long)));
-  HIPB(hipMalloc((void **)&c->d_tot, sizeof(HistoTotals)));
-  c->h_hist.assign(hist_n, 0);
+  {
+    size_t off = sizeof(DevStats) + sizeof(HistoTotals) + sizeof(unsigned long long) * c->n_lanes;
+    c->ctl_hist_off = (off + 15) & ~(size_t)15;
+    c->ctl_bytes = (c->ctl_hist_off + hist_n * sizeof(unsigned long long) + 15) & ~(size_t)15;
+  }
+  HIPB(hipMalloc((void **)&c->d_ctl, c->ctl_bytes));
+  HIPB(hipHostMalloc((void **)&c->h_ctl, c->ctl_bytes, hipHostMallocDefault));
+  memset(c->h_ctl, 0, c->ctl_bytes);
+  c->d_stats = (DevStats *)c->d_ctl;
+  c->h_stats = (DevStats *)c->h_ctl;
+  c->d_tot = (HistoTotals *)(c->d_ctl + sizeof(DevStats));
+  c->h_totp = (HistoTotals *)(c->h_ctl + sizeof(DevStats));
+  c->d_lane_bases = (unsigned long long *)(c->d_ctl + sizeof(DevStats) + sizeof(HistoTotals));
+  c->h_lane_bases = (unsigned long long *)(c->h_ctl + sizeof(DevStats) + sizeof(HistoTotals));
+  c->d_hist = (unsigned long long *)(c->d_ctl + c->ctl_hist_off);
+  c->h_hist = (const uint64_t *)(c->h_ctl + c->ctl_hist_off);
+  c->h_stats->bad = ~0ull;
   uint64_t want = cfg->table_capacity_hint ? cfg->table_capacity_hint * 2 : (1ull << 20);
   int rc = alloc_table(c, log_pages_for(want), &c->tb);
+  if (rc == SHK_OK) rc = fill_state(c, c->tb, true);
   if (rc != SHK_OK) return bail(rc);
   HIPB(hipStreamSynchronize(c->stream));
 #undef HIPB
@@ -577,11 +649,8 @@ void shk_destroy(shk_ctx *c) {
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->tb.keys) (void)hipFree(c->tb.keys);
   if (c->tb.vals) (void)hipFree(c->tb.vals);
-  if (c->d_stats) (void)hipFree(c->d_stats);
-  if (c->h_stats) (void)hipHostFree(c->h_stats);
-  if (c->d_lane_bases) (void)hipFree(c->d_lane_bases);
-  if (c->d_hist) (void)hipFree(c->d_hist);
-  if (c->d_tot) (void)hipFree(c->d_tot);
+  if (c->d_ctl) (void)hipFree(c->d_ctl);
+  if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   c->in_bases.release();
   c->in_offsets.release();
   c->in_bases2.release();
@@ -605,12 +674,12 @@ void shk_destroy(shk_ctx *c) {
 int shk_reset(shk_ctx *c) {
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
-  HIPC(c, hipMemsetAsync(c->tb.keys, 0xFF, c->tb.cap * sizeof(uint64_t), c->stream));
-  HIPC(c, hipMemsetAsync(c->tb.vals, 0, c->tb.cap * sizeof(uint32_t) * c->n_lanes, c->stream));
+  {
+    int rc = fill_state(c, c->tb, true);  // table + control block (stats, totals, histogram) in one launch
+    if (rc != SHK_OK) return rc;
+  }
   memset(c->h_stats, 0, sizeof(DevStats));
   c->h_stats->bad = ~0ull;
-  HIPC(c, hipMemcpyAsync(c->d_stats, c->h_stats, sizeof(DevStats), hipMemcpyHostToDevice, c->stream));
-  HIPC(c, hipMemsetAsync(c->d_lane_bases, 0, sizeof(unsigned long long) * c->n_lanes, c->stream));
   // no host sync: everything later is ordered behind these on the engine stream; h_stats is
   // re-read (read_stats) before the host looks at it again
   std::fill(c->lane_reads.begin(), c->lane_reads.end(), 0);
@@ -784,9 +853,7 @@ int shk_finalize(shk_ctx *c) {
                 "No reads were ingested. Check that input files contain valid FASTQ records.");
   const uint32_t n_cols = c->cfg.chunks;
   const uint64_t hlen = c->cfg.histo_max + 2;
-  const size_t hist_n = (size_t)std::max<uint32_t>(n_cols, 1) * hlen;
-  HIPC(c, hipMemsetAsync(c->d_hist, 0, hist_n * sizeof(unsigned long long), c->stream));
-  HIPC(c, hipMemsetAsync(c->d_tot, 0, sizeof(HistoTotals), c->stream));
+  // d_hist and d_tot are zero here: they are zeroed by reset and again right after every read-back
   uint64_t s0 = 0, s1 = c->tb.cap;
   if (c->own_set) {
     s0 = c->own_p0 << PAGE_LOG;
@@ -801,16 +868,22 @@ int shk_finalize(shk_ctx *c) {
                        (size_t)lds_bins * n_cols * 4, c->stream, c->tb, s0, s1, c->cfg.histo_max,
                        n_cols, lds_bins, c->d_hist, c->d_tot);
   }
-  HIPC(c, hipMemcpyAsync(c->h_hist.data(), c->d_hist, hist_n * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                         c->stream));
-  HIPC(c, hipMemcpyAsync(&c->h_tot, c->d_tot, sizeof(HistoTotals), hipMemcpyDeviceToHost, c->stream));
-  // One host sync serves both the last counting launch and the scan: the scan was queued
-  // optimistically; if that launch turns out to have spilled records (or hit an invalid byte)
-  // it is settled now and the scan repeated over the repaired table.
+  // One copy brings back the whole control block (launch outcome, totals, non-N base counts,
+  // histogram), and one host sync serves both the last counting launch and the scan: the scan
+  // was queued optimistically; if that launch turns out to have spilled records (or hit an
+  // invalid byte) it is settled now and the scan repeated over the repaired table.
   const bool was_unsettled = c->unsettled;
-  if (was_unsettled)
-    HIPC(c, hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats), hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipMemcpyAsync(c->h_ctl, c->d_ctl, c->ctl_bytes, hipMemcpyDeviceToHost, c->stream));
+  {  // histogram + totals back to zero for the next scan; nobody waits for this
+    FillSegs f{};
+    f.ptr[0] = c->d_tot;
+    f.n16[0] = sizeof(HistoTotals) / 16;
+    f.ptr[1] = c->d_hist;
+    f.n16[1] = (c->ctl_bytes - c->ctl_hist_off) / 16;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(f.n16[0] + f.n16[1], WG * 4, 1024)), dim3(WG), 0, c->stream, f);
+  }
   HIPC(c, hipStreamSynchronize(c->stream));
+  c->h_tot = *c->h_totp;
   if (was_unsettled) {
     const bool redo = c->h_stats->bad != ~0ull || c->h_stats->spill_count > 0;
     int rcs = settle_checked(c);
@@ -825,7 +898,7 @@ int shk_finalize(shk_ctx *c) {
                   (unsigned long long)c->h_tot.n_hashed, (unsigned long long)c->h_tot.n_lane_sum);
     if (n_cols > 0) {
       // io.rs:1114-1132: histogram totals of the last column vs the table
-      const uint64_t *last = c->h_hist.data() + (size_t)(n_cols - 1) * hlen;
+      const uint64_t *last = c->h_hist + (size_t)(n_cols - 1) * hlen;
       uint64_t nu = 0;
       for (uint64_t i = 1; i < hlen; ++i) nu += last[i];
       if (nu != c->h_tot.n_unique)
@@ -843,7 +916,7 @@ int shk_histograms(shk_ctx *c, uint64_t *out) {
   if (!c->finalized) return fail(c, SHK_ERR_STATE, "shk_histograms before shk_finalize");
   if (c->cfg.chunks == 0) return SHK_OK;
   if (!out) return fail(c, SHK_ERR_BAD_ARG, "null output");
-  memcpy(out, c->h_hist.data(), (size_t)c->cfg.chunks * (c->cfg.histo_max + 2) * sizeof(uint64_t));
+  memcpy(out, c->h_hist, (size_t)c->cfg.chunks * (c->cfg.histo_max + 2) * sizeof(uint64_t));
   return SHK_OK;
 }
 
@@ -857,11 +930,12 @@ int shk_get_counters(shk_ctx *c, shk_counters *o) {
   memset(o, 0, sizeof *o);
   for (auto v : c->lane_reads) o->n_reads_ingested += v;
   o->n_bases_read = c->n_bases_read;
-  std::vector<unsigned long long> lb(c->n_lanes);
-  HIPC(c, hipMemcpyAsync(lb.data(), c->d_lane_bases, sizeof(unsigned long long) * c->n_lanes,
-                         hipMemcpyDeviceToHost, c->stream));
-  HIPC(c, hipStreamSynchronize(c->stream));
-  for (auto v : lb) o->n_bases_ingested += v;
+  if (!c->finalized) {  // (finalize has just brought the whole control block back)
+    HIPC(c, hipMemcpyAsync(c->h_lane_bases, c->d_lane_bases, sizeof(unsigned long long) * c->n_lanes,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+  }
+  for (uint32_t l = 0; l < c->n_lanes; ++l) o->n_bases_ingested += c->h_lane_bases[l];
   if (c->finalized) {
     o->n_kmers_ingested = c->h_tot.n_lane_sum;
     o->n_unique_kmers = c->h_tot.n_unique;
