@@ -709,7 +709,10 @@ __global__ void __launch_bounds__(WG) k_grow(TableRef oldt, TableRef newt) {
 // non-negative lane counts equal the clamped prefix sum, so column j is the histogram of
 // min(Σ_{c≤j} lane_c, u32::MAX); counts > histo_max fold into bin histo_max+1
 // (histogram.rs:125-134); zero prefix sums (k-mer not seen yet) are not counted.
-// Low bins are privatised in LDS (u32), the rest go straight to global u64 atomics.
+// Low bins are privatised in LDS (u32), the rest go straight to global u64 atomics.  The grid is
+// ≤ 256 workgroups of 1024 threads: enough loads in flight to stream the table, and few enough
+// workgroups that the final flush (every workgroup adds its non-zero bins to the same few cache
+// lines of `hist`) stays short — measured: 1024 × 256-thread workgroups spend 25 µs in that flush.
 // ==========================================================================================
 struct HistoTotals {
   unsigned long long n_unique;       // occupied slots
@@ -718,21 +721,23 @@ struct HistoTotals {
   unsigned long long any_saturated;
 };
 
-__global__ void __launch_bounds__(WG) k_histo(TableRef tb, uint64_t slot0, uint64_t slot1,
+constexpr int HISTO_WG = 1024;  // few, large workgroups: the flush of a workgroup's bins is what contends
+__global__ void __launch_bounds__(HISTO_WG) k_histo(TableRef tb, uint64_t slot0, uint64_t slot1,
                                               uint64_t histo_max, uint32_t n_cols,
                                               uint32_t lds_bins,
                                               unsigned long long *__restrict__ hist,
                                               HistoTotals *__restrict__ tot) {
   extern __shared__ uint32_t lh[];  // n_cols * lds_bins
+  __shared__ unsigned long long wtot[HISTO_WG / 64][4];
   const uint32_t n_l = n_cols * lds_bins;
-  for (uint32_t i = threadIdx.x; i < n_l; i += WG) lh[i] = 0;
+  for (uint32_t i = threadIdx.x; i < n_l; i += HISTO_WG) lh[i] = 0;
   __syncthreads();
   const uint64_t hlen = histo_max + 2;
   unsigned long long n_unique = 0, n_hashed = 0, n_lane = 0, sat = 0;
   // four consecutive slots per thread per step: keys as 2×16 B, each lane's counts as 16 B,
   // all loads issued before any is consumed (slot0/slot1 are multiples of PAGE_SLOTS)
-  for (uint64_t s = slot0 + ((uint64_t)blockIdx.x * WG + threadIdx.x) * 4; s < slot1;
-       s += (uint64_t)gridDim.x * WG * 4) {
+  for (uint64_t s = slot0 + ((uint64_t)blockIdx.x * HISTO_WG + threadIdx.x) * 4; s < slot1;
+       s += (uint64_t)gridDim.x * HISTO_WG * 4) {
     ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(tb.keys + s);
     ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(tb.keys + s + 2);
     uint32_t cum[4] = {0, 0, 0, 0};
@@ -764,14 +769,16 @@ __global__ void __launch_bounds__(WG) k_histo(TableRef tb, uint64_t slot0, uint6
     }
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n_l; i += WG) {
+  for (uint32_t i = threadIdx.x; i < n_l; i += HISTO_WG) {
     uint32_t v = lh[i];
     if (v) {
       uint32_t l = i / lds_bins, bin = i % lds_bins;
       if ((uint64_t)bin < hlen) atomicAdd(&hist[(uint64_t)l * hlen + bin], (unsigned long long)v);
     }
   }
-  // totals: wave reduce then atomics
+  // totals: wave reduce, then one workgroup reduce, then ONE set of atomics per workgroup —
+  // same-line atomics retire one after the other (≈2 ns each on MI355X), so their number, not
+  // their payload, is what costs
   for (int off = 32; off > 0; off >>= 1) {
     n_unique += __shfl_down(n_unique, off, 64);
     n_hashed += __shfl_down(n_hashed, off, 64);
@@ -779,10 +786,22 @@ __global__ void __launch_bounds__(WG) k_histo(TableRef tb, uint64_t slot0, uint6
     sat |= __shfl_down(sat, off, 64);
   }
   if ((threadIdx.x & 63) == 0) {
-    if (n_unique) atomicAdd(&tot->n_unique, n_unique);
-    if (n_hashed) atomicAdd(&tot->n_hashed, n_hashed);
-    if (n_lane) atomicAdd(&tot->n_lane_sum, n_lane);
-    if (sat) atomicOr(&tot->any_saturated, 1ull);
+    unsigned long long *w = wtot[threadIdx.x >> 6];
+    w[0] = n_unique;
+    w[1] = n_hashed;
+    w[2] = n_lane;
+    w[3] = sat;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    unsigned long long v = 0;
+    for (int w = 0; w < HISTO_WG / 64; ++w) v = threadIdx.x == 3 ? (v | wtot[w][3]) : v + wtot[w][threadIdx.x];
+    if (v) {
+      if (threadIdx.x == 0) atomicAdd(&tot->n_unique, v);
+      if (threadIdx.x == 1) atomicAdd(&tot->n_hashed, v);
+      if (threadIdx.x == 2) atomicAdd(&tot->n_lane_sum, v);
+      if (threadIdx.x == 3) atomicOr(&tot->any_saturated, 1ull);
+    }
   }
 }
 

@@ -864,7 +864,7 @@ int shk_finalize(shk_ctx *c) {
   if (n_cols && (uint64_t)lds_bins * n_cols * 4 > 65536) lds_bins = 65536 / 4 / n_cols;
   {
     ScopedTimer t(c, SHK_K_HISTO);
-    hipLaunchKernelGGL(k_histo, dim3(grid_for(s1 - s0, WG * 16, 256)), dim3(WG),
+    hipLaunchKernelGGL(k_histo, dim3(grid_for(s1 - s0, HISTO_WG * 16, 256)), dim3(HISTO_WG),
                        (size_t)lds_bins * n_cols * 4, c->stream, c->tb, s0, s1, c->cfg.histo_max,
                        n_cols, lds_bins, c->d_hist, c->d_tot);
   }

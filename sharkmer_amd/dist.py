@@ -87,15 +87,16 @@ class DistCounter:
         self.eng.finalize()
         h = self.eng.histograms()
         c = self.eng.counters()
-        ht = self._dev(torch.from_numpy(h.astype(np.int64)))
-        if ht.numel():
-            dist.all_reduce(ht, op=dist.ReduceOp.SUM)
         names = ["n_reads_ingested", "n_bases_read", "n_bases_ingested", "n_kmers_ingested",
                  "n_unique_kmers", "n_hashed_kmers", "any_saturated"]
-        tot = self._dev(torch.tensor([c[k] for k in names], dtype=torch.int64))
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        self.totals = {k: int(v) for k, v in zip(names, tot.cpu().tolist())}
-        hist = ht.cpu().numpy().astype(np.uint64)
+        # one all_reduce for the histogram and the scalar totals together (both are sums)
+        packed = np.concatenate([np.array([c[k] for k in names], dtype=np.int64),
+                                 h.astype(np.int64).reshape(-1)])
+        pt = self._dev(torch.from_numpy(packed))
+        dist.all_reduce(pt, op=dist.ReduceOp.SUM)
+        red = pt.cpu().numpy()
+        self.totals = {k: int(v) for k, v in zip(names, red[:len(names)])}
+        hist = red[len(names):].astype(np.uint64).reshape(h.shape)
         if hist.shape[0] > 0:
             self.totals["n_singleton_kmers"] = int(hist[-1, 1])
             # io.rs:1042-1047 / 1120-1132 on the merged whole
