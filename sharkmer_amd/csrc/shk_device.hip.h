@@ -141,12 +141,21 @@ __device__ __forceinline__ bool next_tile(const BatchRef &b, uint64_t &t, bool u
 
 // ASCII → 2-bit base for 4 bytes at once: A,C,G,T → 0..3 via ((c>>1)^(c>>2))&3 ('N' → 0);
 // *nmask4 gets one bit per byte that is 'N'.
-__device__ __forceinline__ uint32_t codes4(uint32_t w, uint32_t *nmask4) {
+__device__ __forceinline__ uint32_t codes4(uint32_t w, uint32_t *nmask4, uint32_t *nbytes = nullptr) {
   uint32_t c = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
   uint32_t t = w ^ 0x4E4E4E4Eu;  // zero byte ⇔ 'N'
   uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 per 'N' byte
   *nmask4 = (z * 0x00204081u) >> 28;  // gather the four byte-MSBs, byte order kept
+  if (nbytes) *nbytes = z;
   return c;
+}
+// Bytes of w that are none of A,C,G,T,N, given w's codes c and its 'N' bytes z (from codes4):
+// a byte is one of ACGT exactly when it equals the letter its own 2-bit code stands for, and that
+// letter comes out of a 4-entry byte table in one v_perm_b32 (the codes are the selectors).
+// Non-zero result ⇔ some byte is invalid (encoding.rs:341-356).
+__device__ __forceinline__ uint32_t invalid_bytes4(uint32_t w, uint32_t c, uint32_t z) {
+  const uint32_t letter = __builtin_amdgcn_perm(0u, 0x54474341u /* T G C A */, c);
+  return (w ^ letter) & ~((z >> 7) * 0xFFu);
 }
 
 // Is byte c one of A,C,G,T,N?  (A=0x41 C=0x43 G=0x47 N=0x4E T=0x54 → bits 1,3,7,14,20 of
@@ -244,11 +253,10 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
           uint32_t bad = 0, nn = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            uint32_t en = eq_bytes(w[q], 0x4E4E4E4Eu);
-            uint32_t ok = en | eq_bytes(w[q], 0x41414141u) | eq_bytes(w[q], 0x43434343u) |
-                          eq_bytes(w[q], 0x47474747u) | eq_bytes(w[q], 0x54545454u);
-            bad |= ~ok & 0x80808080u;
-            nn += __builtin_popcount(en);
+            uint32_t n4, z;
+            const uint32_t c = codes4(w[q], &n4, &z);  // (the conversion below recomputes it: CSE)
+            bad |= invalid_bytes4(w[q], c, z);
+            nn += __builtin_popcount(z);
           }
           n_non_n += 16 - nn;
           if (bad) {
@@ -1214,10 +1222,17 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     }
     // reserve this tile's (even-padded) run in every page's output region: one returning
     // device-scope add per non-empty (tile, page); consecutive lanes hit consecutive cursors.
-    // The results are first needed by the write phase, a barrier and the place phase later.
-    for (uint32_t i = threadIdx.x; i < P; i += NT) {
-      const uint32_t c2 = (cnt[i] + 1u) & ~1u;
-      gbase[i] = c2 ? atomicAdd(&cursor[i], c2) : 0u;
+    // The results are first needed by the write phase, a barrier and the place phase later, so
+    // they are parked in registers and only stored to LDS (where the wait for them sits) then.
+    uint32_t gres[MAX_PARTS / NT];  // stay in registers until the place phase is over
+#pragma unroll
+    for (int r = 0; r < MAX_PARTS / NT; ++r) {
+      const uint32_t i = threadIdx.x + r * NT;
+      gres[r] = 0;
+      if (i < P) {
+        const uint32_t c2 = (cnt[i] + 1u) & ~1u;
+        if (c2) gres[r] = atomicAdd(&cursor[i], c2);
+      }
     }
     __syncthreads();  // codes are dead from here: `sorted` may overwrite them
     STAMP(3);
@@ -1230,6 +1245,9 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     }
     for (uint32_t i = threadIdx.x; i < P; i += NT)
       if (cnt[i] & 1u) sorted[tstart[i] + cnt[i]] = 0xFFFFu;
+#pragma unroll
+    for (int r = 0; r < MAX_PARTS / NT; ++r)  // the reservations have had the place phase to come back
+      if (threadIdx.x + r * NT < P) gbase[threadIdx.x + r * NT] = gres[r];
     __syncthreads();
     STAMP(4);
     // ---- write: one PAIR of records per lane per store (16 B, aligned: runs start on even
