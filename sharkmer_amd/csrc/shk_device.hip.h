@@ -52,6 +52,8 @@ struct TableRef {
   uint64_t cap;      // n_pages * PAGE_SLOTS
   uint32_t log_pages;
   uint32_t n_lanes;
+  uint32_t key_bits;  // 2k
+  uint32_t pad_;
 };
 
 struct BatchRef {
@@ -81,17 +83,30 @@ struct SpillRef {
 // tools/hash_eval.py: page occupancy and slot collisions match a Poisson process on random,
 // AT-rich, tandem-repeat and sequential keys (without the finaliser sequential keys collide).
 constexpr uint32_t MAX_LOG_PAGES = 19;  // log_pages + PAGE_LOG ≤ 32 hash bits
-__device__ __forceinline__ uint32_t hash64(uint64_t key) {
-  const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-  const uint32_t c0 = lo & 0xFFFFFFu;
-  const uint32_t c1 = __builtin_amdgcn_alignbit(hi, lo, 24) & 0xFFFFFFu;
-  const uint32_t c2 = hi >> 16;
-  uint32_t h = __umul24(c0, 0x9E3779B1u & 0xFFFFFFu) + __umul24(c1, 0x85EBCA77u & 0xFFFFFFu) +
-               __umul24(c2, 0xC2B2AE3Du & 0xFFFFFFu);
-  h ^= h >> 15;
-  h *= 0x2C1B3C6Du;
-  h ^= h >> 12;
-  return h;
+// mix_key: a BIJECTION of the 2k-bit key space (multiply by an odd constant mod 2^2k, fold the
+// upper half down, multiply again: every step is invertible), so the position of a key in the
+// table — page = top log_pages bits, home bucket = next 11 bits — together with the remaining
+// low bits identifies the key.  The 4-byte-record path of the paged counter ships only those
+// low bits and rebuilds a key with unmix_key when it has to.
+constexpr uint64_t MIX_M1 = 0x9E3779B97F4A7C15ull, MIX_M2 = 0xD6E8FEB86659FD93ull;
+constexpr uint64_t MIX_M1_INV = 0xF1DE83E19937733Dull, MIX_M2_INV = 0xCFEE444D8B59A89Bull;  // mod 2^64
+__host__ __device__ __forceinline__ uint64_t mix_key(uint64_t x, uint32_t bits) {
+  const uint64_t mask = ~0ull >> (64 - bits);
+  x = (x * MIX_M1) & mask;
+  x ^= x >> ((bits + 1) >> 1);
+  return (x * MIX_M2) & mask;
+}
+__host__ __device__ __forceinline__ uint64_t unmix_key(uint64_t y, uint32_t bits) {
+  const uint64_t mask = ~0ull >> (64 - bits);
+  y = (y * MIX_M2_INV) & mask;
+  y ^= y >> ((bits + 1) >> 1);  // the fold is its own inverse: the shift is at least half the width
+  return (y * MIX_M1_INV) & mask;
+}
+// the 32 hash bits the table geometry is read from: the top of the mixed key
+__device__ __forceinline__ uint32_t hash64(uint64_t key, uint32_t bits) {
+  uint64_t x = (key * MIX_M1) & (~0ull >> (64 - bits));
+  x ^= x >> ((bits + 1) >> 1);
+  return (uint32_t)(((x * MIX_M2) << (64 - bits)) >> 32);
 }
 __device__ __forceinline__ uint64_t page_of(uint32_t h, uint32_t log_pages) {
   return log_pages ? (uint64_t)(h >> (32 - log_pages)) : 0ull;
@@ -140,22 +155,23 @@ __device__ __forceinline__ bool next_tile(const BatchRef &b, uint64_t &t, bool u
 }
 
 // ASCII → 2-bit base for 4 bytes at once: A,C,G,T → 0..3 via ((c>>1)^(c>>2))&3 ('N' → 0);
-// *nmask4 gets one bit per byte that is 'N'.
-__device__ __forceinline__ uint32_t codes4(uint32_t w, uint32_t *nmask4, uint32_t *nbytes = nullptr) {
-  uint32_t c = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
-  uint32_t t = w ^ 0x4E4E4E4Eu;  // zero byte ⇔ 'N'
-  uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 per 'N' byte
-  *nmask4 = (z * 0x00204081u) >> 28;  // gather the four byte-MSBs, byte order kept
-  if (nbytes) *nbytes = z;
-  return c;
+// *nbytes gets 0x80 in every byte that is 'N' — for VALID input: among A,C,G,T,N only N has
+// bit 3 set.  (Input with any other byte is rejected as a whole, encoding.rs:353-356: nothing
+// derived from it is ever used.)
+__device__ __forceinline__ uint32_t codes4(uint32_t w, uint32_t *nbytes) {
+  *nbytes = (w << 4) & 0x80808080u;
+  return ((w >> 1) ^ (w >> 2)) & 0x03030303u;
 }
-// Bytes of w that are none of A,C,G,T,N, given w's codes c and its 'N' bytes z (from codes4):
-// a byte is one of ACGT exactly when it equals the letter its own 2-bit code stands for, and that
-// letter comes out of a 4-entry byte table in one v_perm_b32 (the codes are the selectors).
-// Non-zero result ⇔ some byte is invalid (encoding.rs:341-356).
-__device__ __forceinline__ uint32_t invalid_bytes4(uint32_t w, uint32_t c, uint32_t z) {
-  const uint32_t letter = __builtin_amdgcn_perm(0u, 0x54474341u /* T G C A */, c);
-  return (w ^ letter) & ~((z >> 7) * 0xFFu);
+// the four byte-MSBs of z gathered into bits 0-3, byte order kept
+__device__ __forceinline__ uint32_t msb_gather4(uint32_t z) { return (z * 0x00204081u) >> 28; }
+// Bytes of w that are none of A,C,G,T,N (non-zero result ⇔ some byte is invalid,
+// encoding.rs:341-356), given w's codes c: a byte is valid exactly when it equals the letter
+// that its own (bit 3, 2-bit code) stands for, and that letter comes out of an 8-entry byte table
+// in one v_perm_b32 — selectors 0-3 → A C G T, 4 → N (bit 3 set, code 0), 5-7 → 0x00, which no
+// byte with bit 3 set equals.
+__device__ __forceinline__ uint32_t invalid_bytes4(uint32_t w, uint32_t c) {
+  const uint32_t sel = c | ((w >> 1) & 0x04040404u);
+  return w ^ __builtin_amdgcn_perm(0x0000004Eu /* . . . N */, 0x54474341u /* T G C A */, sel);
 }
 
 // Is byte c one of A,C,G,T,N?  (A=0x41 C=0x43 G=0x47 N=0x4E T=0x54 → bits 1,3,7,14,20 of
@@ -163,10 +179,22 @@ __device__ __forceinline__ uint32_t invalid_bytes4(uint32_t w, uint32_t c, uint3
 __device__ __forceinline__ bool byte_is_acgtn(uint32_t c) {
   return (c >> 5) == 2 && ((0x0010408Au >> (c & 31)) & 1u);
 }
-// 0x80 in every byte of w that equals the byte replicated in x4
-__device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t x4) {
-  uint32_t t = w ^ x4;
-  return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+// 2-bit packed copies of a staged tile (16 bases per u32, first base on top): PACK_WORDS words
+// each — the forward stream, and the mirrored complement stream in which base j of the tile is
+// base TILE_LDS-1-j, so that the reverse complement of a window is a window again.
+constexpr int PACK_WORDS = TILE_GROUPS + 2;  // + 2 pad words (a window read touches 3 words)
+static_assert(TILE_T <= (1 << 14) && TILE_LDS % 16 == 0, "sorted entries: 14-bit position + strand bit");
+__device__ __forceinline__ uint32_t pack4(uint32_t c) {  // 4 code bytes (0..3 each) → 8 bits, first base on top
+  return (c * 0x40100401u) >> 24;                        // the four 2-bit fields land in bits 31..24, no carries
+}
+__device__ __forceinline__ uint32_t pack16(uint4 c4) {
+  return (pack4(c4.x) << 24) | (pack4(c4.y) << 16) | (pack4(c4.z) << 8) | pack4(c4.w);
+}
+// reverse the order of the sixteen 2-bit fields of x
+__device__ __forceinline__ uint32_t rev2(uint32_t x) {
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  return __builtin_bswap32(x);
 }
 
 // Stage positions [t0-HALO, t0+TILE_T) of the batch into LDS as one code byte per base:
@@ -228,10 +256,11 @@ __device__ __forceinline__ void stage_prefetch(const BatchRef &b, uint64_t t0, S
   }
 }
 
-template <bool VALIDATE, int NT = WG>
+template <bool VALIDATE, int NT = WG, bool PACK = false>
 __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, uint64_t t1,
                                                uint8_t *lds, DevStats *stats,
-                                               const StageRegs<NT> &pre) {
+                                               const StageRegs<NT> &pre, uint32_t *packed = nullptr,
+                                               uint32_t *rcpacked = nullptr) {
   uint32_t *gmask = reinterpret_cast<uint32_t *>(lds + TILE_LDS);  // nmask16 | smask16<<16
   const int64_t p0 = (int64_t)t0 - HALO;
   uint32_t n_non_n = 0;
@@ -253,9 +282,9 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
           uint32_t bad = 0, nn = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            uint32_t n4, z;
-            const uint32_t c = codes4(w[q], &n4, &z);  // (the conversion below recomputes it: CSE)
-            bad |= invalid_bytes4(w[q], c, z);
+            uint32_t z;
+            const uint32_t c = codes4(w[q], &z);  // (the conversion below recomputes it: CSE)
+            bad |= invalid_bytes4(w[q], c);
             nn += __builtin_popcount(z);
           }
           n_non_n += 16 - nn;
@@ -278,9 +307,9 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        uint32_t n4;
-        w[q] = codes4(w[q], &n4);
-        nmask |= n4 << (4 * q);
+        uint32_t z;
+        w[q] = codes4(w[q], &z);
+        nmask |= msb_gather4(z) << (4 * q);
       }
     } else {
       uint4 e = stage_edge_group(b.bases, b.n_bases, p, t0, t1, VALIDATE, stats);
@@ -312,8 +341,23 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
   }                                     // iterations costs > 100 VGPRs
   __syncthreads();
   // "k-mer ends here" bits: position j is bad if an N lies in [j-k+1, j] or a read starts in
-  // [j-k+2, j].  48 mask bits (this group and the two before it) are smeared upwards.
+  // [j-k+2, j].  48 mask bits (this group and the two before it) are smeared upwards.  Positions
+  // at or beyond t1 (a tile that ends at a 1000-read block boundary) never get the bit, so the
+  // walks need no end-of-tile test.  PACK: the 2-bit packed streams are written on the way.
   const int k = b.k;
+  const int n_lds = (int)(t1 - t0) + HALO;  // LDS positions below this may end a k-mer
+  if (PACK) {
+    for (int m = threadIdx.x; m < 2 + 2; m += NT) {  // halo groups 0,1 and the streams' pad words
+      if (m < 2) {
+        const uint32_t v = pack16(*reinterpret_cast<const uint4 *>(lds + m * 16));
+        packed[m] = v;
+        rcpacked[TILE_GROUPS - 1 - m] = rev2(~v);
+      } else {
+        packed[TILE_GROUPS + m - 2] = 0;
+        rcpacked[TILE_GROUPS + m - 2] = 0;
+      }
+    }
+  }
   for (int m = 2 + threadIdx.x; m < TILE_GROUPS; m += NT) {
     const uint32_t g0 = gmask[m - 2], g1 = gmask[m - 1], g2 = gmask[m];
     uint64_t N = (uint64_t)(g0 & 0xFFFFu) | ((uint64_t)(g1 & 0xFFFFu) << 16) |
@@ -336,15 +380,24 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
       S = 0;
     }
     uint32_t ok = ~(uint32_t)((N | S) >> 32) & 0xFFFFu;  // m ≥ 2: ≥ 32 ≥ k-1 bases of history
-    if (ok) {
+    const int lim = n_lds - m * 16;                       // positions of this group below t1
+    if (lim < 16) ok = lim > 0 ? ok & ((1u << lim) - 1u) : 0u;
+    if (PACK || ok) {
       uint4 c4 = *reinterpret_cast<const uint4 *>(lds + m * 16);
-      uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint32_t fq = (ok >> (4 * q)) & 0xF;
-        cw[q] |= ((fq & 1) << 2) | ((fq & 2) << 9) | ((fq & 4) << 16) | ((fq & 8) << 23);
+      if (PACK) {
+        const uint32_t v = pack16(c4);
+        packed[m] = v;
+        rcpacked[TILE_GROUPS - 1 - m] = rev2(~v);
       }
-      *reinterpret_cast<uint4 *>(lds + m * 16) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+      if (ok) {
+        uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t fq = (ok >> (4 * q)) & 0xF;
+          cw[q] |= ((fq & 1) << 2) | ((fq & 2) << 9) | ((fq & 4) << 16) | ((fq & 8) << 23);
+        }
+        *reinterpret_cast<uint4 *>(lds + m * 16) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+      }
     }
   }
   return n_non_n;
@@ -608,7 +661,7 @@ __global__ void __launch_bounds__(WG) k_scan(BatchRef b, DevStats *__restrict__ 
 __device__ __forceinline__ void count_one(const TableRef &tb, uint64_t key, uint32_t lane,
                                           DevStats *stats, const SpillRef &sp,
                                           uint32_t &n_new) {
-  uint32_t h = hash64(key);
+  uint32_t h = hash64(key, tb.key_bits);
   uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
   bool inserted = false;
   int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
@@ -671,7 +724,7 @@ __global__ void __launch_bounds__(WG) k_insert(const uint64_t *__restrict__ kmer
     uint64_t key = kmers[i];
     uint32_t lane = lanes ? lanes[i] : lane0;
     uint32_t cnt = counts ? counts[i] : 1u;
-    uint32_t h = hash64(key);
+    uint32_t h = hash64(key, tb.key_bits);
     uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
     bool inserted = false;
     int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
@@ -700,7 +753,7 @@ __global__ void __launch_bounds__(WG) k_grow(TableRef oldt, TableRef newt) {
        i += (uint64_t)gridDim.x * WG) {
     uint64_t key = oldt.keys[i];
     if (key == EMPTY) continue;
-    uint32_t h = hash64(key);
+    uint32_t h = hash64(key, newt.key_bits);
     uint64_t base = page_of(h, newt.log_pages) << PAGE_LOG;
     bool inserted = false;
     int64_t s = find_or_insert(newt.keys, base, slot_of(h, newt.log_pages), key, inserted);
@@ -826,7 +879,7 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t kmer, int k) {
 }
 
 __device__ __forceinline__ uint32_t merged_count(const TableRef &tb, uint64_t key) {
-  uint32_t h = hash64(key);
+  uint32_t h = hash64(key, tb.key_bits);
   uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
   int64_t s = find_slot(tb.keys, base, slot_of(h, tb.log_pages), key);
   if (s < 0) return 0;
@@ -931,7 +984,7 @@ __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t n_slots, uin
        i += (uint64_t)gridDim.x * WG) {
     uint64_t key = pkeys[i];
     if (key == EMPTY) continue;
-    uint32_t h = hash64(key);
+    uint32_t h = hash64(key, tb.key_bits);
     uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
     bool inserted = false;
     int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
@@ -1056,8 +1109,6 @@ constexpr uint32_t PAGE_FILL_CAP = PAGE_SLOTS - PAGE_SLOTS / 8;  // new keys spi
 #ifndef SORTED_WAVES_PER_SIMD
 #define SORTED_WAVES_PER_SIMD 4
 #endif
-constexpr int PACK_WORDS = TILE_GROUPS + 2;  // 16 bases per u32, MSB first, + 2 pad words
-static_assert(TILE_T <= (1 << 14) && TILE_LDS % 16 == 0, "sorted entries: 14-bit position + strand bit");
 // LDS bytes of the sorted-entry region: TILE_T entries + one possible pad per page (u16), and it
 // doubles as the staging area (code bytes + group masks) before the sort
 __host__ __device__ inline uint32_t sort_region_bytes(uint32_t P) {
@@ -1065,16 +1116,6 @@ __host__ __device__ inline uint32_t sort_region_bytes(uint32_t P) {
   return ((a > b ? a : b) + 15u) & ~15u;
 }
 
-__device__ __forceinline__ uint32_t pack4(uint32_t w) {  // 4 code bytes → 8 bits, first base on top
-  return ((w & 3u) << 6) | (((w >> 8) & 3u) << 4) | (((w >> 16) & 3u) << 2) | ((w >> 24) & 3u);
-}
-
-// reverse the order of the sixteen 2-bit fields of x
-__device__ __forceinline__ uint32_t rev2(uint32_t x) {
-  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
-  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
-  return __builtin_bswap32(x);
-}
 // the k-base window that starts at base index q of an MSB-first packed stream
 __device__ __forceinline__ uint64_t window_at(const uint32_t *stream, int q, int k) {
   const int s = 2 * q;
@@ -1141,26 +1182,13 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     tprev = __builtin_readcyclecounter();
 #endif
     for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
-    n_non_n += stage_tile<true, NT>(b, t0, t1, codes, stats, pre);
+    n_non_n += stage_tile<true, NT, true>(b, t0, t1, codes, stats, pre, packed, rcpacked);
     uint64_t tn = t + gridDim.x, n0, n1;
     uint32_t nl;
     const bool hn = next_tile(b, tn, true, lane_filter, n0, n1, nl);
     if (hn) stage_prefetch<NT>(b, n0, pre);  // in flight during the rest of this tile
     __syncthreads();
     STAMP(0);
-    // 2-bit packed copy of the staged tile (N / out-of-range bases pack as 0; never read back
-    // for a k-mer that the walk did not emit)
-    for (int m = threadIdx.x; m < PACK_WORDS; m += NT) {
-      uint32_t v = 0;
-      if (m < TILE_GROUPS) {
-        uint4 c4 = *reinterpret_cast<const uint4 *>(codes + m * 16);
-        v = (pack4(c4.x) << 24) | (pack4(c4.y) << 16) | (pack4(c4.z) << 8) | pack4(c4.w);
-        rcpacked[TILE_GROUPS - 1 - m] = rev2(~v);
-      } else {
-        rcpacked[m] = 0;  // the two pad words behind either stream
-      }
-      packed[m] = v;
-    }
     STAMP(1);
     // ---- walk: (partition, rank) per end position, kept in registers -------------------
     uint32_t pr[SPAN];
@@ -1171,11 +1199,15 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
       const int jend = HALO + (e0 + SPAN < n_end ? e0 + SPAN : n_end);
       Roll x{0, 0, 0, 0};
       if (e0 < n_end) {
-        for (int j = (jemit - (k - 1)) & ~7; j < jemit; j += 8) {  // warm-up: no emission
-          uint64_t w = *reinterpret_cast<const uint64_t *>(codes + j);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) roll_step(x, (uint32_t)(w >> (8 * r)) & 3u, mask_lo, mask_hi);
-        }
+        // the frames as they stand just before the first end position: the k bases up to
+        // jemit-1, read as one window of either packed stream (N / foreign bases pack as A; the
+        // "k-mer ends here" bits keep windows that contain them from being emitted)
+        const uint64_t f0 = window_at(packed, jemit - k, k);
+        const uint64_t r0 = window_at(rcpacked, TILE_LDS - jemit, k) << (64 - 2 * k);
+        x.f_lo = (uint32_t)f0;
+        x.f_hi = (uint32_t)(f0 >> 32);
+        x.r_lo = (uint32_t)r0;
+        x.r_hi = (uint32_t)(r0 >> 32);
       }
 #pragma unroll
       for (int q = 0; q < SPAN / 8; ++q) {
@@ -1186,11 +1218,11 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
           uint32_t c = (uint32_t)(w >> (8 * r)) & 0xFF;
           roll_step(x, c & 3u, mask_lo, mask_hi);
           uint32_t v = 0xFFFFFFFFu;
-          if ((c & 4u) && jemit + q * 8 + r < jend) {
+          if (c & 4u) {  // (never set at or beyond the tile's end: stage_tile)
             const uint64_t fwd = ((uint64_t)x.f_hi << 32) | x.f_lo;
             const uint64_t rev = (((uint64_t)x.r_hi << 32) | x.r_lo) >> (64 - 2 * k);
             const bool rc = rev < fwd;
-            const uint32_t pc = (uint32_t)page_of(hash64(rc ? rev : fwd), log_parts);
+            const uint32_t pc = (uint32_t)page_of(hash64(rc ? rev : fwd, 2 * k), log_parts);
             v = (pc << 16) | (rc ? 0x8000u : 0u) | atomicAdd(&cnt[pc], 1u);  // rank < 2^14
           }
           pr[q * 8 + r] = v;
@@ -1260,7 +1292,7 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
       const uint64_t km0 = kmer_at(packed, rcpacked, HALO + (int)(e0 & 0x3FFFu), e0 >> 14, k);
       const uint64_t km1 =
           e1 == 0xFFFFu ? EMPTY : kmer_at(packed, rcpacked, HALO + (int)(e1 & 0x3FFFu), e1 >> 14, k);
-      const uint32_t pc = (uint32_t)page_of(hash64(km0), log_parts);
+      const uint32_t pc = (uint32_t)page_of(hash64(km0, 2 * k), log_parts);
       const uint32_t at = gbase[pc] + (2 * i - tstart[pc]);  // record index inside page pc's region
       if (at + 2 <= cap_p) {
         ulonglong2 rec;
@@ -1316,7 +1348,8 @@ constexpr int RS_TILE = 4096;              // records per tile: they stay in LDS
 constexpr int RS_SPAN = RS_TILE / RS_NT;   // 16 records per thread
 __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
     const uint64_t *__restrict__ src_buf, const unsigned int *__restrict__ src_cursor, uint32_t src_cap,
-    uint32_t tiles_per_region, uint32_t log_pages, uint32_t log_sub, unsigned int *__restrict__ dst_cursor,
+    uint32_t tiles_per_region, uint32_t log_pages, uint32_t log_sub, uint32_t key_bits,
+    unsigned int *__restrict__ dst_cursor,
     uint32_t dst_cap, uint64_t *__restrict__ dst_buf, uint32_t lane, DevStats *__restrict__ stats,
     SpillRef sp) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
@@ -1347,11 +1380,11 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
       const ulonglong2 rec = *reinterpret_cast<const ulonglong2 *>(src + i);
       *reinterpret_cast<ulonglong2 *>(recs + i) = rec;
       if (rec.x != EMPTY) {
-        const uint32_t sub = (uint32_t)page_of(hash64(rec.x), log_pages) & sub_mask;
+        const uint32_t sub = (uint32_t)page_of(hash64(rec.x, key_bits), log_pages) & sub_mask;
         va = (sub << 16) | atomicAdd(&cnt[sub], 1u);
       }
       if (rec.y != EMPTY) {
-        const uint32_t sub = (uint32_t)page_of(hash64(rec.y), log_pages) & sub_mask;
+        const uint32_t sub = (uint32_t)page_of(hash64(rec.y, key_bits), log_pages) & sub_mask;
         vb = (sub << 16) | atomicAdd(&cnt[sub], 1u);
       }
     }
@@ -1405,7 +1438,7 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
     const uint32_t ea = ee & 0xFFFFu, eb = ee >> 16;
     const uint64_t km0 = recs[ea];
     const uint64_t km1 = eb == 0xFFFFu ? EMPTY : recs[eb];
-    const uint32_t sub = (uint32_t)page_of(hash64(km0), log_pages) & sub_mask;
+    const uint32_t sub = (uint32_t)page_of(hash64(km0, key_bits), log_pages) & sub_mask;
     const uint32_t at = gbase[sub] + (2 * i - tstart[sub]);
     const uint64_t page = ((uint64_t)region << log_sub) + sub;
     if (at + 2 <= dst_cap) {
@@ -1498,7 +1531,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
   // general probe of one record into the LDS page: find the key or insert it, add one
   auto insert = [&](uint64_t key) {
     if (key == EMPTY) return;  // padding record of an odd (tile, page) run
-    uint32_t sl = slot_of(hash64(key), tb.log_pages);
+    uint32_t sl = slot_of(hash64(key, tb.key_bits), tb.log_pages);
     for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
       uint64_t cur = keys[sl];
       if (cur == EMPTY) {
@@ -1551,7 +1584,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
       nxt[1] = src2[ib + PG_WG];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ss[q] = slot_of(hash64(kk[q]), tb.log_pages);
+    for (int q = 0; q < 4; ++q) ss[q] = slot_of(hash64(kk[q], tb.key_bits), tb.log_pages);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       ba[q] = *reinterpret_cast<const ulonglong2 *>(&keys[ss[q]]);

@@ -198,6 +198,7 @@ int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out) {
   TableRef t{};
   t.log_pages = log_pages;
   t.n_lanes = c->n_lanes;
+  t.key_bits = 2 * c->cfg.k;
   t.cap = (uint64_t)PAGE_SLOTS << log_pages;
   HIPC(c, hipMalloc((void **)&t.keys, t.cap * sizeof(uint64_t)));
   hipError_t e = hipMalloc((void **)&t.vals, t.cap * sizeof(uint32_t) * t.n_lanes);
@@ -479,7 +480,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       ScopedTimer t(c, SHK_K_PSCAN);  // timer slot reused: the level-2 re-scatter
       hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
                          (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
-                         log_sub, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp);
+                         log_sub, 2 * c->cfg.k, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp);
     }
     {
       ScopedTimer t(c, SHK_K_PAGES);
