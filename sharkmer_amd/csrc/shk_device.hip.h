@@ -1132,10 +1132,13 @@ __device__ __forceinline__ uint64_t kmer_at(const uint32_t *packed, const uint32
   return window_at(rc ? rcpacked : packed, rc ? TILE_LDS - 1 - j : j - k + 1, k);  // one window read, no branch
 }
 
-template <int NT>
+// REC32: the 4-byte-record variant (one level, 2k - log_parts ≤ 32): a record is the low
+// 2k - log_parts bits of the MIXED key (the page is implied by the region, mix_key is a bijection),
+// runs are packed without padding, one 4-B store per record.
+template <int NT, bool REC32>
 __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sorted(
     BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
-    uint32_t cap_p, uint64_t *__restrict__ part_buf, DevStats *__restrict__ stats,
+    uint32_t cap_p, void *__restrict__ part_buf_, DevStats *__restrict__ stats,
     unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[NT / 64];
@@ -1170,6 +1173,9 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
   const uint64_t mask = (1ull << (2 * k)) - 1;
   const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
   const uint32_t per = P / NT ? P / NT : 1;  // partitions per thread in the scan (P ≥ WG or P < WG)
+  uint64_t *part_buf = reinterpret_cast<uint64_t *>(part_buf_);
+  uint32_t *part_buf32 = reinterpret_cast<uint32_t *>(part_buf_);
+  const uint32_t pad1 = REC32 ? 0u : 1u;  // runs are padded to even length unless REC32
 
   uint64_t t = blockIdx.x, t0, t1;
   uint32_t lane;
@@ -1235,7 +1241,7 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     {
       uint32_t lo = threadIdx.x * per, s = 0;
       if (lo < P)
-        for (uint32_t i = 0; i < per; ++i) s += (cnt[lo + i] + 1u) & ~1u;
+        for (uint32_t i = 0; i < per; ++i) s += (cnt[lo + i] + pad1) & ~pad1;
       uint32_t inc = s;
       for (int d = 1; d < 64; d <<= 1) {
         uint32_t o = __shfl_up(inc, d, 64);
@@ -1249,7 +1255,7 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
       if (lo < P)
         for (uint32_t i = 0; i < per; ++i) {
           tstart[lo + i] = run;
-          run += (cnt[lo + i] + 1u) & ~1u;
+          run += (cnt[lo + i] + pad1) & ~pad1;
         }
     }
     // reserve this tile's (even-padded) run in every page's output region: one returning
@@ -1262,7 +1268,7 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
       const uint32_t i = threadIdx.x + r * NT;
       gres[r] = 0;
       if (i < P) {
-        const uint32_t c2 = (cnt[i] + 1u) & ~1u;
+        const uint32_t c2 = (cnt[i] + pad1) & ~pad1;
         if (c2) gres[r] = atomicAdd(&cursor[i], c2);
       }
     }
@@ -1275,8 +1281,9 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
       if (v != 0xFFFFFFFFu)  // entry = end position | strand << 14
         sorted[tstart[v >> 16] + (v & 0x7FFFu)] = (uint16_t)((threadIdx.x * SPAN + i) | ((v & 0x8000u) >> 1));
     }
-    for (uint32_t i = threadIdx.x; i < P; i += NT)
-      if (cnt[i] & 1u) sorted[tstart[i] + cnt[i]] = 0xFFFFu;
+    if (!REC32)
+      for (uint32_t i = threadIdx.x; i < P; i += NT)
+        if (cnt[i] & 1u) sorted[tstart[i] + cnt[i]] = 0xFFFFu;
 #pragma unroll
     for (int r = 0; r < MAX_PARTS / NT; ++r)  // the reservations have had the place phase to come back
       if (threadIdx.x + r * NT < P) gbase[threadIdx.x + r * NT] = gres[r];
@@ -1284,7 +1291,28 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     STAMP(4);
     // ---- write: one PAIR of records per lane per store (16 B, aligned: runs start on even
     // record indices in LDS and in HBM); pairs never straddle partitions ----------------------
-    const uint32_t n_pairs = (tstart[P - 1] + ((cnt[P - 1] + 1u) & ~1u)) >> 1;
+    if (REC32) {
+      const uint32_t n_rec = tstart[P - 1] + cnt[P - 1];
+      const uint32_t rbits = 2u * (uint32_t)k - log_parts;  // ≤ 32
+      for (uint32_t i = threadIdx.x; i < n_rec; i += NT) {
+        const uint32_t e = sorted[i];
+        const uint64_t km = kmer_at(packed, rcpacked, HALO + (int)(e & 0x3FFFu), e >> 14, k);
+        const uint64_t y = mix_key(km, 2 * k);
+        const uint32_t pc = (uint32_t)(y >> rbits);  // = page_of(hash64(km)) for rbits < 2k
+        const uint32_t at = gbase[pc] + (i - tstart[pc]);
+        if (at < cap_p) {
+          part_buf32[(uint64_t)pc * cap_p + at] = (uint32_t)y & (uint32_t)(0xFFFFFFFFull >> (32 - rbits));
+        } else {  // the page's region is full (skewed input): the spill path takes the whole key
+          const unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
+          if (j < sp.cap) {
+            sp.keys[j] = km;
+            sp.lanes[j] = lane;
+            sp.counts[j] = 1u;
+          }
+        }
+      }
+    }
+    const uint32_t n_pairs = REC32 ? 0u : (tstart[P - 1] + ((cnt[P - 1] + 1u) & ~1u)) >> 1;
     const uint32_t *sorted2 = reinterpret_cast<const uint32_t *>(sorted);
     for (uint32_t i = threadIdx.x; i < n_pairs; i += NT) {
       const uint32_t ee = sorted2[i];
@@ -1640,6 +1668,183 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
       reinterpret_cast<ulonglong2 *>(gk)[j] = reinterpret_cast<const ulonglong2 *>(keys)[j];
     if (threadIdx.x == 0) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pages32: the page workgroup for 4-byte records (k_part_scatter_sorted<.., true>).  A record
+// is rec = mix_key(key) mod 2^R, R = 2k - log_pages ≤ 32: home bucket = its top 11 bits,
+// fingerprint fp = the R-11 bits below.  The page sits in LDS as 32-bit TAGS instead of keys:
+//     tag(slot) = fp(key) << 3 | d ,  d = (bucket(slot) - home bucket(key)) mod 2048, d ≤ 6
+// which — mix_key being a bijection and the page known — identifies the key.  A record hits when
+// one of the four tags of its home bucket (ONE ds_read_b128) equals fp << 3; no hash is computed
+// here at all.  Everything else (first occurrences, displaced keys) goes through a per-wave miss
+// queue IN LDS (the tags leave room for it) and the general probe, which compares (fp, d) slot
+// by slot, inserts with a CAS on the tag and then writes the rebuilt key (unmix_key) to the
+// page in HBM.  What a tag cannot express — a key ≥ 7 buckets from home (d = 7, only ever created
+// by the direct path) met on a probe, or a probe that would have to insert that far out —
+// sends the record to the spill list, i.e. through the exact global-memory path.
+// Counts: 16-bit deltas as in k_pages.  Keys are written when inserted, so the page's keys are
+// never written back wholesale.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t TAG_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t MQ32 = 1024;             // miss-queue entries per wave (LDS)
+constexpr uint32_t P32_RPS = 8;             // records per thread per step
+static_assert(PAGE_SLOTS * 4 + PAGE_SLOTS * 2 + (PG_WG / 64) * MQ32 * 4 <= 81920, "two page workgroups per CU");
+__global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
+                                                   const unsigned int *__restrict__ cursor, uint32_t cap_p,
+                                                   const uint32_t *__restrict__ part_buf,
+                                                   DevStats *__restrict__ stats, SpillRef sp) {
+  __shared__ __attribute__((aligned(16))) uint32_t tags[PAGE_SLOTS];
+  __shared__ __attribute__((aligned(16))) uint32_t dl[PAGE_SLOTS / 2];  // packed 16-bit deltas
+  __shared__ __attribute__((aligned(16))) uint32_t mqs[(PG_WG / 64) * MQ32];
+  if (stats->bad != ~0ull) return;
+  const uint32_t page = blockIdx.x;
+  const uint32_t filled = cursor[page] < cap_p ? cursor[page] : cap_p;  // beyond cap_p: spilled
+  if (filled == 0) return;
+  const uint32_t bits = tb.key_bits, R = bits - tb.log_pages, fpb = R - 11;
+  const uint32_t fpmask = (1u << fpb) - 1u;
+  uint64_t *gk = tb.keys + ((uint64_t)page << PAGE_LOG);
+  uint32_t *gv = tb.vals + (uint64_t)lane * tb.cap + ((uint64_t)page << PAGE_LOG);
+  // page keys → tags, counting occupied slots on the way
+  uint32_t my_occ = 0;
+  for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 2; i += PG_WG) {
+    const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(gk)[i];
+    const uint64_t kv[2] = {v.x, v.y};
+    uint32_t tg[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      tg[q] = TAG_EMPTY;
+      if (kv[q] != EMPTY) {
+        const uint32_t rec = (uint32_t)mix_key(kv[q], bits) & (uint32_t)(0xFFFFFFFFull >> (32 - R));
+        const uint32_t d = (((2 * i + q) >> 2) - (rec >> fpb)) & (PAGE_SLOTS / 4 - 1);
+        tg[q] = ((rec & fpmask) << 3) | (d < 7 ? d : 7u);
+        my_occ++;
+      }
+    }
+    reinterpret_cast<uint2 *>(tags)[i] = make_uint2(tg[0], tg[1]);
+  }
+  const uint32_t occ0 = pg_wg_sum(my_occ, dl);
+  const uint32_t room = occ0 < PAGE_FILL_CAP ? (PAGE_FILL_CAP - occ0) / (PG_WG / 64) : 0u;
+  for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 2; i += PG_WG) dl[i] = 0;
+  __syncthreads();
+  const uint32_t n = filled;
+  const uint32_t *src = part_buf + (uint64_t)page * cap_p;
+  const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+  uint32_t *mq = mqs + wave * MQ32;
+  uint32_t n_miss = 0;  // wave-uniform
+  uint32_t n_new = 0;   // per thread
+  bool may_insert = room > 0;
+  auto update_may_insert = [&]() {
+    uint32_t w = n_new;
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
+    may_insert = w < room;
+  };
+  auto spill = [&](uint32_t rec) {
+    const uint64_t key = unmix_key(((uint64_t)page << R) | rec, bits);
+    unsigned long long i = atomicAdd(&stats->spill_count, 1ull);
+    if (i < sp.cap) {
+      sp.keys[i] = key;
+      sp.lanes[i] = lane;
+      sp.counts[i] = 1u;
+    }
+  };
+  // general probe of one record: find its (fp, d) tag or insert it, add one
+  auto insert = [&](uint32_t rec) {
+    const uint32_t home = rec >> fpb, fp3 = (rec & fpmask) << 3;
+    uint32_t sl = home << 2;
+    for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
+      const uint32_t d = ((sl >> 2) - home) & (PAGE_SLOTS / 4 - 1);
+      uint32_t cur = tags[sl];
+      if (cur == TAG_EMPTY) {
+        if (!may_insert || d >= 7) break;  // share used up, or too far out for a tag → spill
+        const uint32_t prev = atomicCAS(&tags[sl], TAG_EMPTY, fp3 | d);
+        if (prev == TAG_EMPTY) {
+          n_new++;
+          gk[sl] = unmix_key(((uint64_t)page << R) | rec, bits);
+          cur = fp3 | d;
+        } else {
+          cur = prev;
+        }
+      }
+      if ((cur & 7u) == 7u) break;  // a far entry: cannot tell whether it is this key → spill
+      if (d < 7 && cur == (fp3 | d)) {
+        delta_add(dl, sl);
+        return;
+      }
+      sl = (sl + 1) & (PAGE_SLOTS - 1);
+    }
+    spill(rec);
+  };
+  auto drain = [&]() {
+    for (uint32_t j = lane_id; j < n_miss; j += 64) insert(mq[j]);  // this wave's own queue
+    n_miss = 0;
+    update_may_insert();
+  };
+  const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+  const uint32_t n_steps = n / (P32_RPS * PG_WG);
+  constexpr uint32_t SWEEP_EVERY = 4;  // steps between delta-overflow sweeps
+  static_assert(SWEEP_EVERY * P32_RPS * PG_WG < 0x8000, "a 16-bit delta must not wrap between checks");
+  uint4 nxt[2];
+  if (n_steps) {
+    nxt[0] = src4[threadIdx.x];
+    nxt[1] = src4[threadIdx.x + PG_WG];
+  }
+  for (uint32_t step = 0; step < n_steps; ++step) {
+    const uint32_t rr[8] = {nxt[0].x, nxt[0].y, nxt[0].z, nxt[0].w, nxt[1].x, nxt[1].y, nxt[1].z, nxt[1].w};
+    if (step + 1 < n_steps) {
+      const uint64_t ib = (uint64_t)(step + 1) * 2 * PG_WG + threadIdx.x;
+      nxt[0] = src4[ib];
+      nxt[1] = src4[ib + PG_WG];
+    }
+    uint4 bk[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bk[q] = *reinterpret_cast<const uint4 *>(&tags[(rr[q] >> fpb) << 2]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t want = (rr[q] & fpmask) << 3;
+      const int hit = bk[q].x == want ? 0 : bk[q].y == want ? 1 : bk[q].z == want ? 2 : bk[q].w == want ? 3 : -1;
+      if (hit >= 0) delta_add(dl, ((rr[q] >> fpb) << 2) + hit);
+      const unsigned long long mm = __ballot(hit < 0);
+      if (hit < 0) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = rr[q];
+      n_miss += (uint32_t)__popcll(mm);
+    }
+    // drain when the next step might not fit (worst case: every record of it misses), and at first
+    // after every step: an empty page misses on every first occurrence and on its repeats until
+    // it is inserted
+    if (n_miss > MQ32 - 64 * P32_RPS || step < 8) drain();
+    if ((step % SWEEP_EVERY) == SWEEP_EVERY - 1 || step + 1 == n_steps) {
+      drain();
+      __syncthreads();
+      // deltas >= 2^15 go to the 32-bit counts in HBM now (a slot gains < 2^15 between checks)
+      for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 2; j += PG_WG) {
+        const uint32_t w = dl[j];
+        if (w & 0x80008000u) {
+          if (w & 0x8000u) gv[2 * j] = sat_add_u32(gv[2 * j], w & 0xFFFFu);
+          if (w & 0x80000000u) gv[2 * j + 1] = sat_add_u32(gv[2 * j + 1], w >> 16);
+          dl[j] = (w & 0x8000u ? 0u : (w & 0xFFFFu)) | (w & 0x80000000u ? 0u : (w & 0xFFFF0000u));
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // tail (< P32_RPS*PG_WG records): straight through the general probe
+  for (uint32_t i = n_steps * P32_RPS * PG_WG + threadIdx.x; i < n; i += PG_WG) insert(src[i]);
+  __syncthreads();
+  // deltas → counts (saturating), four slots per lane
+  for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG) {
+    const uint2 d = reinterpret_cast<const uint2 *>(dl)[j];
+    if (d.x | d.y) {
+      uint4 v = reinterpret_cast<const uint4 *>(gv)[j];
+      v.x = sat_add_u32(v.x, d.x & 0xFFFFu);
+      v.y = sat_add_u32(v.y, d.x >> 16);
+      v.z = sat_add_u32(v.z, d.y & 0xFFFFu);
+      v.w = sat_add_u32(v.w, d.y >> 16);
+      reinterpret_cast<uint4 *>(gv)[j] = v;
+    }
+  }
+  __syncthreads();
+  const uint32_t nnew = pg_wg_sum(n_new, dl);
+  if (nnew && threadIdx.x == 0) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
 }
 
 }  // namespace shk

@@ -447,13 +447,18 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   // Every region is filled by per-tile reservations (one returning atomic per non-empty
   // (tile, region)); a region that still overflows (skewed input: one k-mer making up a large
   // share of the batch) sends the excess through the spill list — exact either way.
-  const uint32_t cap1 = region_cap(sub_kmers_ub, P1, b.tile_count);
+  // 4-byte records (k_part_scatter_sorted<.., true> + k_pages32) when a record fits: one level,
+  // 11 ≤ 2k - log_pages ≤ 32 (the low bits of the mixed key below the page bits)
+  const uint32_t rbits = 2 * c->cfg.k >= lp ? 2 * c->cfg.k - lp : 0;
+  const bool rec32 = !two_level && rbits >= 11 && rbits <= 32 && env_int("SHK_REC32", 1) != 0;
+  const uint32_t cap1 = (region_cap(sub_kmers_ub, P1, b.tile_count) + 3u) & ~3u;  // regions stay 16-B aligned
   const uint32_t tiles_per_region = (cap1 + RS_TILE - 1) / RS_TILE;
   const uint32_t cap_pg = two_level ? region_cap(sub_kmers_ub, n_pages, tiles_per_region) : cap1;
   DevBuf &buf_pg = two_level ? c->part3 : c->part;  // what k_pages reads
-  HIPC(c, c->part.ensure((uint64_t)P1 * cap1 * 8));
+  HIPC(c, c->part.ensure((uint64_t)P1 * cap1 * (rec32 ? 4 : 8)));
   if (two_level) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * 8));
-  HIPC(c, c->part2.ensure((uint64_t)n_pages * ((uint64_t)cap_pg + MISS_SLACK) * 8));  // k_pages miss queues
+  if (!rec32)
+    HIPC(c, c->part2.ensure((uint64_t)n_pages * ((uint64_t)cap_pg + MISS_SLACK) * 8));  // k_pages miss queues
   HIPC(c, c->part_meta.ensure(((size_t)P1 + n_pages) * 4 + 64));
   unsigned int *cursor1 = (unsigned int *)c->part_meta.p;
   unsigned int *cursor_pg = two_level ? cursor1 + P1 : cursor1;
@@ -472,9 +477,12 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       HIPC(c, hipMemsetAsync(cursor1, 0, (size_t)pg.cursor_words() * 4, c->stream));
     {
       ScopedTimer t(c, SHK_K_SCATTER);
-      hipLaunchKernelGGL(k_part_scatter_sorted<SC_NT>, dim3(G), dim3(SC_NT), lds_sorted, c->stream, b,
-                         log_p1, lane, cursor1, cap1, (uint64_t *)c->part.p, c->d_stats, c->d_lane_bases,
-                         sp, dbg);
+      if (rec32)
+        hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, true>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
+                           b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
+      else
+        hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, false>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
+                           b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
     }
     if (two_level) {
       ScopedTimer t(c, SHK_K_PSCAN);  // timer slot reused: the level-2 re-scatter
@@ -484,9 +492,13 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     }
     {
       ScopedTimer t(c, SHK_K_PAGES);
-      hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
-                         (const unsigned int *)cursor_pg, cap_pg, (const uint64_t *)buf_pg.p,
-                         (uint64_t *)c->part2.p, c->d_stats, sp);
+      if (rec32)
+        hipLaunchKernelGGL(k_pages32, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
+                           (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
+      else
+        hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
+                           (const unsigned int *)cursor_pg, cap_pg, (const uint64_t *)buf_pg.p,
+                           (uint64_t *)c->part2.p, c->d_stats, sp);
     }
 #ifdef SHK_PHASE_TIMING
     {

@@ -476,3 +476,32 @@ def test_find_oligos_reference_cases(orc, seq, k, oligo, min_count, expected):
         assert [orc.kmer_to_seq(int(x), k) for x in got_k] == expected
     else:
         assert len(got_k) > 0
+
+
+# ---- 4-byte-record path (k_part_scatter_sorted<.., true> + k_pages32): 11 ≤ 2k - log_pages ≤ 32 ----------
+
+@pytest.mark.parametrize("k,chunks,hint", [(6, 1, 0), (11, 3, 0), (13, 1, 0), (16, 2, 0), (16, 1, 40_000),
+                                           (17, 1, 20_000), (19, 4, 300_000), (21, 1, 4_200_000)])
+def test_rec32_path_parity(orc, k, chunks, hint):
+    """Records are the low bits of the mixed key; tags in LDS; keys rebuilt with unmix_key on insert.
+    Includes the boundary 2k - log_pages = 32 (k=16 on a one-page table, k=21 on 1024 pages) and a
+    first pass into an empty table followed by passes into a populated one."""
+    spec = sa.SynthSpec(genome_len=60_000, sub_per_64k=300, n_per_64k=40)
+    bases, offsets = sa.synth_reads(spec, 0, 24_000)
+    check_against_oracle(orc, bases, offsets, k, chunks, 200, flags=sa.FLAG_FORCE_PAGED, hint=hint,
+                         splits=[8_000, 16_000])
+
+
+def test_rec32_matches_8byte_records(orc, monkeypatch):
+    """Same input through both record formats: identical tables."""
+    spec = sa.SynthSpec(genome_len=200_000, sub_per_64k=100)
+    bases, offsets = sa.synth_reads(spec, 0, 40_000)
+    out = []
+    for rec32 in ("1", "0"):
+        monkeypatch.setenv("SHK_REC32", rec32)
+        with sa.KmerEngine(15, 2, 100, flags=sa.FLAG_FORCE_PAGED) as eng:
+            eng.ingest_reads(bases, offsets)
+            eng.finalize()
+            out.append((eng.histograms(), eng.export_table()))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
