@@ -1799,13 +1799,24 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
     uint4 bk[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) bk[q] = *reinterpret_cast<const uint4 *>(&tags[(rr[q] >> fpb) << 2]);
+    // Straight-line code on purpose (no ?: chains, which come out as nested exec-mask branches):
+    // at most one of the four tags can match, so the matching index is a sum of the compare bits,
+    // and a record that missed adds 0 to its bucket's first delta instead of skipping the add.
+    bool missed[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const uint32_t want = (rr[q] & fpmask) << 3;
-      const int hit = bk[q].x == want ? 0 : bk[q].y == want ? 1 : bk[q].z == want ? 2 : bk[q].w == want ? 3 : -1;
-      if (hit >= 0) delta_add(dl, ((rr[q] >> fpb) << 2) + hit);
-      const unsigned long long mm = __ballot(hit < 0);
-      if (hit < 0) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = rr[q];
+      const uint32_t e0 = bk[q].x == want, e1 = bk[q].y == want, e2 = bk[q].z == want, e3 = bk[q].w == want;
+      const uint32_t idx = e1 + 2u * e2 + 3u * e3;
+      const uint32_t found = e0 | e1 | e2 | e3;
+      // the bucket's four 16-bit deltas are the two words dl[2·bucket], dl[2·bucket+1]
+      atomicAdd(&dl[2u * (rr[q] >> fpb) + (idx >> 1)], found << (16u * (idx & 1u)));
+      missed[q] = !found;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned long long mm = __ballot(missed[q]);
+      if (missed[q]) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = rr[q];
       n_miss += (uint32_t)__popcll(mm);
     }
     // drain when the next step might not fit (worst case: every record of it misses), and at first
