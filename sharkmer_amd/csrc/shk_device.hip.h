@@ -1687,15 +1687,16 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
 // never written back wholesale.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t TAG_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t MQ32 = 1024;             // miss-queue entries per wave (LDS)
-constexpr uint32_t P32_RPS = 8;             // records per thread per step
-static_assert(PAGE_SLOTS * 4 + PAGE_SLOTS * 2 + (PG_WG / 64) * MQ32 * 4 <= 81920, "two page workgroups per CU");
+constexpr uint32_t MQ32 = 512;              // miss-queue entries per wave (LDS)
+constexpr uint32_t P32_RPS = 4;             // records per thread per step (one 16-B load)
+static_assert(PAGE_SLOTS * 4 + PAGE_SLOTS * 4 + (PG_WG / 64) * MQ32 * 4 <= 81920, "two page workgroups per CU");
+static_assert(MQ32 >= 2 * 64 * P32_RPS, "the queue must take a whole step of misses on top of the drain threshold");
 __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
                                                    const unsigned int *__restrict__ cursor, uint32_t cap_p,
                                                    const uint32_t *__restrict__ part_buf,
                                                    DevStats *__restrict__ stats, SpillRef sp) {
   __shared__ __attribute__((aligned(16))) uint32_t tags[PAGE_SLOTS];
-  __shared__ __attribute__((aligned(16))) uint32_t dl[PAGE_SLOTS / 2];  // packed 16-bit deltas
+  __shared__ __attribute__((aligned(16))) uint32_t dl[PAGE_SLOTS];  // this pass's count per slot
   __shared__ __attribute__((aligned(16))) uint32_t mqs[(PG_WG / 64) * MQ32];
   if (stats->bad != ~0ull) return;
   const uint32_t page = blockIdx.x;
@@ -1725,7 +1726,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
   }
   const uint32_t occ0 = pg_wg_sum(my_occ, dl);
   const uint32_t room = occ0 < PAGE_FILL_CAP ? (PAGE_FILL_CAP - occ0) / (PG_WG / 64) : 0u;
-  for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 2; i += PG_WG) dl[i] = 0;
+  for (uint32_t i = threadIdx.x; i < PAGE_SLOTS; i += PG_WG) dl[i] = 0;
   __syncthreads();
   const uint32_t n = filled;
   const uint32_t *src = part_buf + (uint64_t)page * cap_p;
@@ -1768,7 +1769,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
       }
       if ((cur & 7u) == 7u) break;  // a far entry: cannot tell whether it is this key → spill
       if (d < 7 && cur == (fp3 | d)) {
-        delta_add(dl, sl);
+        atomicAdd(&dl[sl], 1u);
         return;
       }
       sl = (sl + 1) & (PAGE_SLOTS - 1);
@@ -1780,41 +1781,34 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
     n_miss = 0;
     update_may_insert();
   };
+  // Main loop: one 16-B load = four records per thread per step, the next step's load in flight.
+  // No barrier in here: queues are per wave, and a slot's count of this pass is a full 32-bit word
+  // (a page sees < 2^31 records), so nothing has to be folded away mid-pass.
   const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
   const uint32_t n_steps = n / (P32_RPS * PG_WG);
-  constexpr uint32_t SWEEP_EVERY = 4;  // steps between delta-overflow sweeps
-  static_assert(SWEEP_EVERY * P32_RPS * PG_WG < 0x8000, "a 16-bit delta must not wrap between checks");
-  uint4 nxt[2];
-  if (n_steps) {
-    nxt[0] = src4[threadIdx.x];
-    nxt[1] = src4[threadIdx.x + PG_WG];
-  }
+  uint4 nxt;
+  if (n_steps) nxt = src4[threadIdx.x];
   for (uint32_t step = 0; step < n_steps; ++step) {
-    const uint32_t rr[8] = {nxt[0].x, nxt[0].y, nxt[0].z, nxt[0].w, nxt[1].x, nxt[1].y, nxt[1].z, nxt[1].w};
-    if (step + 1 < n_steps) {
-      const uint64_t ib = (uint64_t)(step + 1) * 2 * PG_WG + threadIdx.x;
-      nxt[0] = src4[ib];
-      nxt[1] = src4[ib + PG_WG];
-    }
-    uint4 bk[8];
+    const uint32_t rr[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+    if (step + 1 < n_steps) nxt = src4[(uint64_t)(step + 1) * PG_WG + threadIdx.x];
+    uint4 bk[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) bk[q] = *reinterpret_cast<const uint4 *>(&tags[(rr[q] >> fpb) << 2]);
+    for (int q = 0; q < 4; ++q) bk[q] = *reinterpret_cast<const uint4 *>(&tags[(rr[q] >> fpb) << 2]);
     // Straight-line code on purpose (no ?: chains, which come out as nested exec-mask branches):
     // at most one of the four tags can match, so the matching index is a sum of the compare bits,
-    // and a record that missed adds 0 to its bucket's first delta instead of skipping the add.
-    bool missed[8];
+    // and a record that missed adds 0 to its bucket's first slot instead of skipping the add.
+    bool missed[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const uint32_t want = (rr[q] & fpmask) << 3;
       const uint32_t e0 = bk[q].x == want, e1 = bk[q].y == want, e2 = bk[q].z == want, e3 = bk[q].w == want;
       const uint32_t idx = e1 + 2u * e2 + 3u * e3;
       const uint32_t found = e0 | e1 | e2 | e3;
-      // the bucket's four 16-bit deltas are the two words dl[2·bucket], dl[2·bucket+1]
-      atomicAdd(&dl[2u * (rr[q] >> fpb) + (idx >> 1)], found << (16u * (idx & 1u)));
+      atomicAdd(&dl[((rr[q] >> fpb) << 2) + idx], found);
       missed[q] = !found;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const unsigned long long mm = __ballot(missed[q]);
       if (missed[q]) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = rr[q];
       n_miss += (uint32_t)__popcll(mm);
@@ -1822,34 +1816,21 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
     // drain when the next step might not fit (worst case: every record of it misses), and at first
     // after every step: an empty page misses on every first occurrence and on its repeats until
     // it is inserted
-    if (n_miss > MQ32 - 64 * P32_RPS || step < 8) drain();
-    if ((step % SWEEP_EVERY) == SWEEP_EVERY - 1 || step + 1 == n_steps) {
-      drain();
-      __syncthreads();
-      // deltas >= 2^15 go to the 32-bit counts in HBM now (a slot gains < 2^15 between checks)
-      for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 2; j += PG_WG) {
-        const uint32_t w = dl[j];
-        if (w & 0x80008000u) {
-          if (w & 0x8000u) gv[2 * j] = sat_add_u32(gv[2 * j], w & 0xFFFFu);
-          if (w & 0x80000000u) gv[2 * j + 1] = sat_add_u32(gv[2 * j + 1], w >> 16);
-          dl[j] = (w & 0x8000u ? 0u : (w & 0xFFFFu)) | (w & 0x80000000u ? 0u : (w & 0xFFFF0000u));
-        }
-      }
-      __syncthreads();
-    }
+    if (n_miss > MQ32 - 64 * P32_RPS || step < 16) drain();
   }
+  drain();
   // tail (< P32_RPS*PG_WG records): straight through the general probe
   for (uint32_t i = n_steps * P32_RPS * PG_WG + threadIdx.x; i < n; i += PG_WG) insert(src[i]);
   __syncthreads();
-  // deltas → counts (saturating), four slots per lane
+  // this pass's counts → the page's counts (saturating), four slots per lane
   for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG) {
-    const uint2 d = reinterpret_cast<const uint2 *>(dl)[j];
-    if (d.x | d.y) {
+    const uint4 d = reinterpret_cast<const uint4 *>(dl)[j];
+    if (d.x | d.y | d.z | d.w) {
       uint4 v = reinterpret_cast<const uint4 *>(gv)[j];
-      v.x = sat_add_u32(v.x, d.x & 0xFFFFu);
-      v.y = sat_add_u32(v.y, d.x >> 16);
-      v.z = sat_add_u32(v.z, d.y & 0xFFFFu);
-      v.w = sat_add_u32(v.w, d.y >> 16);
+      v.x = sat_add_u32(v.x, d.x);
+      v.y = sat_add_u32(v.y, d.y);
+      v.z = sat_add_u32(v.z, d.z);
+      v.w = sat_add_u32(v.w, d.w);
       reinterpret_cast<uint4 *>(gv)[j] = v;
     }
   }
