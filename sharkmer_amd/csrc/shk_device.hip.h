@@ -1119,10 +1119,14 @@ __host__ __device__ inline uint32_t sort_region_bytes(uint32_t P) {
 // the k-base window that starts at base index q of an MSB-first packed stream
 __device__ __forceinline__ uint64_t window_at(const uint32_t *stream, int q, int k) {
   const int s = 2 * q;
-  const int wi = s >> 5, off = s & 31;
-  uint64_t x = ((uint64_t)stream[wi] << 32) | stream[wi + 1];
-  if (off) x = (x << off) | ((uint64_t)stream[wi + 2] >> (32 - off));
-  return x >> (64 - 2 * k);
+  const int wi = s >> 5;
+  const uint32_t off = (uint32_t)s & 31u;
+  // 64 stream bits from bit s on, as two funnel shifts (v_alignbit_b32 shifts by its count mod 32,
+  // hence the selects for off = 0); the third word is a pad word at worst, never out of bounds
+  const uint32_t w0 = stream[wi], w1 = stream[wi + 1], w2 = stream[wi + 2];
+  const uint32_t hi = off ? __builtin_amdgcn_alignbit(w0, w1, 32u - off) : w0;
+  const uint32_t lo = off ? __builtin_amdgcn_alignbit(w1, w2, 32u - off) : w1;
+  return (((uint64_t)hi << 32) | lo) >> (64 - 2 * k);
 }
 // Canonical k-mer whose LAST base sits at LDS position j (halo included).  The walk has already
 // decided the strand: rc = 1 ⇔ the reverse complement is the smaller one, and that is a plain
@@ -1286,7 +1290,8 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
         if (cnt[i] & 1u) sorted[tstart[i] + cnt[i]] = 0xFFFFu;
 #pragma unroll
     for (int r = 0; r < MAX_PARTS / NT; ++r)  // the reservations have had the place phase to come back
-      if (threadIdx.x + r * NT < P) gbase[threadIdx.x + r * NT] = gres[r];
+      if (threadIdx.x + r * NT < P)  // gbase - tstart: what the write phase adds to an entry's index
+        gbase[threadIdx.x + r * NT] = gres[r] - tstart[threadIdx.x + r * NT];
     __syncthreads();
     STAMP(4);
     // ---- write: one PAIR of records per lane per store (16 B, aligned: runs start on even
@@ -1294,20 +1299,40 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     if (REC32) {
       const uint32_t n_rec = tstart[P - 1] + cnt[P - 1];
       const uint32_t rbits = 2u * (uint32_t)k - log_parts;  // ≤ 32
-      for (uint32_t i = threadIdx.x; i < n_rec; i += NT) {
-        const uint32_t e = sorted[i];
-        const uint64_t km = kmer_at(packed, rcpacked, HALO + (int)(e & 0x3FFFu), e >> 14, k);
-        const uint64_t y = mix_key(km, 2 * k);
-        const uint32_t pc = (uint32_t)(y >> rbits);  // = page_of(hash64(km)) for rbits < 2k
-        const uint32_t at = gbase[pc] + (i - tstart[pc]);
-        if (at < cap_p) {
-          part_buf32[(uint64_t)pc * cap_p + at] = (uint32_t)y & (uint32_t)(0xFFFFFFFFull >> (32 - rbits));
-        } else {  // the page's region is full (skewed input): the spill path takes the whole key
-          const unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
-          if (j < sp.cap) {
-            sp.keys[j] = km;
-            sp.lanes[j] = lane;
-            sp.counts[j] = 1u;
+      // two consecutive entries per lane: they nearly always belong to the same page, and then
+      // leave as one 8-B store (4-B aligned is enough for global memory)
+      const uint32_t *sorted2r = reinterpret_cast<const uint32_t *>(sorted);
+      const uint32_t rmask = (uint32_t)(0xFFFFFFFFull >> (32 - rbits));
+      auto spill_km = [&](uint64_t km) {  // the page's region is full (skewed input)
+        const unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
+        if (j < sp.cap) {
+          sp.keys[j] = km;
+          sp.lanes[j] = lane;
+          sp.counts[j] = 1u;
+        }
+      };
+      for (uint32_t i = threadIdx.x; 2 * i < n_rec; i += NT) {
+        const uint32_t ee = sorted2r[i];
+        const uint32_t ea = ee & 0xFFFFu, eb = ee >> 16;
+        const bool two = 2 * i + 1 < n_rec;
+        const uint64_t km0 = kmer_at(packed, rcpacked, HALO + (int)(ea & 0x3FFFu), ea >> 14, k);
+        const uint64_t km1 = two ? kmer_at(packed, rcpacked, HALO + (int)(eb & 0x3FFFu), (eb >> 14) & 1u, k) : km0;
+        const uint64_t y0 = mix_key(km0, 2 * k), y1 = mix_key(km1, 2 * k);
+        const uint32_t pc0 = (uint32_t)(y0 >> rbits), pc1 = (uint32_t)(y1 >> rbits);  // = page_of(hash64(km))
+        const uint32_t r0 = (uint32_t)y0 & rmask, r1 = (uint32_t)y1 & rmask;
+        const uint32_t at0 = gbase[pc0] + 2 * i;  // record index inside the page's region
+        // (a launch covers ≤ 2^28 k-mers: byte offsets into part_buf fit 32 bits)
+        char *const base = reinterpret_cast<char *>(part_buf32);
+        if (two && pc1 == pc0 && at0 + 2 <= cap_p) {
+          uint2 rec2 = make_uint2(r0, r1);
+          __builtin_memcpy(base + (pc0 * cap_p + at0) * 4u, &rec2, 8);
+        } else {
+          if (at0 < cap_p) *reinterpret_cast<uint32_t *>(base + (pc0 * cap_p + at0) * 4u) = r0;
+          else spill_km(km0);
+          if (two) {
+            const uint32_t at1 = gbase[pc1] + 2 * i + 1;
+            if (at1 < cap_p) *reinterpret_cast<uint32_t *>(base + (pc1 * cap_p + at1) * 4u) = r1;
+            else spill_km(km1);
           }
         }
       }
@@ -1321,12 +1346,13 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
       const uint64_t km1 =
           e1 == 0xFFFFu ? EMPTY : kmer_at(packed, rcpacked, HALO + (int)(e1 & 0x3FFFu), e1 >> 14, k);
       const uint32_t pc = (uint32_t)page_of(hash64(km0, 2 * k), log_parts);
-      const uint32_t at = gbase[pc] + (2 * i - tstart[pc]);  // record index inside page pc's region
+      const uint32_t at = gbase[pc] + 2 * i;  // record index inside page pc's region
       if (at + 2 <= cap_p) {
         ulonglong2 rec;
         rec.x = km0;
         rec.y = km1;
-        *reinterpret_cast<ulonglong2 *>(part_buf + (uint64_t)pc * cap_p + at) = rec;
+        const uint32_t byte_off = (pc * cap_p + at) * 8u;  // < 2^32: ≤ 2^28 k-mers per launch
+        *reinterpret_cast<ulonglong2 *>(reinterpret_cast<char *>(part_buf) + byte_off) = rec;
       } else {  // the page's region is full (skewed input): these records take the spill path
         const unsigned long long j = atomicAdd(&stats->spill_count, km1 == EMPTY ? 1ull : 2ull);
         if (j < sp.cap) {

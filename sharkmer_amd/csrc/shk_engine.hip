@@ -455,6 +455,8 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const uint32_t tiles_per_region = (cap1 + RS_TILE - 1) / RS_TILE;
   const uint32_t cap_pg = two_level ? region_cap(sub_kmers_ub, n_pages, tiles_per_region) : cap1;
   DevBuf &buf_pg = two_level ? c->part3 : c->part;  // what k_pages reads
+  if ((uint64_t)P1 * cap1 * (rec32 ? 4 : 8) > 0xFFFFFFFFull)  // the scatter indexes part_buf with 32-bit byte offsets
+    return fail(c, SHK_ERR_INVARIANT, "partition buffer of one launch exceeds 4 GiB");
   HIPC(c, c->part.ensure((uint64_t)P1 * cap1 * (rec32 ? 4 : 8)));
   if (two_level) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * 8));
   if (!rec32)
