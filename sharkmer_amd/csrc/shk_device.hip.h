@@ -1516,6 +1516,132 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
   }
 }
 
+// k_part_rescatter32: the same second level for 4-byte records.  A level-1 record is the low
+// R1 = 2k - log_p1 bits of the mixed key (its super-page is the region it sits in); the page inside
+// the super-page is its top log_sub bits, and what goes on to k_pages32 is the rest.  Runs are packed
+// (no padding), two entries per lane leave as one 8-B store when they share a page.
+constexpr int RS32_TILE = 8192;                // records per tile: 32 KiB in LDS
+constexpr int RS32_SPAN = RS32_TILE / RS_NT;   // 32 records per thread
+__global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
+    const uint32_t *__restrict__ src_buf, const unsigned int *__restrict__ src_cursor, uint32_t src_cap,
+    uint32_t tiles_per_region, uint32_t log_sub, uint32_t r1_bits, uint32_t key_bits,
+    unsigned int *__restrict__ dst_cursor, uint32_t dst_cap, uint32_t *__restrict__ dst_buf, uint32_t lane,
+    DevStats *__restrict__ stats, SpillRef sp) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+  __shared__ uint32_t wsum[RS_NT / 64];
+  if (stats->bad != ~0ull) return;
+  const uint32_t S = 1u << log_sub;  // pages per super-page
+  const uint32_t region = blockIdx.x / tiles_per_region, tile = blockIdx.x % tiles_per_region;
+  const uint32_t filled = src_cursor[region] < src_cap ? src_cursor[region] : src_cap;
+  const uint32_t r0 = tile * RS32_TILE;
+  if (r0 >= filled) return;
+  const uint32_t n = filled - r0 < (uint32_t)RS32_TILE ? filled - r0 : (uint32_t)RS32_TILE;
+  const uint32_t *src = src_buf + (uint64_t)region * src_cap + r0;  // 16-B aligned: src_cap % 4 == 0
+  uint32_t *recs = sh;                                                      // RS32_TILE records
+  uint16_t *sorted = reinterpret_cast<uint16_t *>(sh + RS32_TILE);          // RS32_TILE entries
+  uint32_t *cnt = sh + RS32_TILE + RS32_TILE / 2;                           // S
+  uint32_t *tstart = cnt + S;                                               // S
+  uint32_t *gbase = tstart + S;                                             // S
+  for (uint32_t i = threadIdx.x; i < S; i += RS_NT) cnt[i] = 0;
+  __syncthreads();
+  // ---- rank: (page-in-super-page, rank) per record, in registers; four records per 16-B load ----
+  const uint32_t rbits2 = r1_bits - log_sub;  // record bits that go on to the page workgroup
+  uint32_t pr[RS32_SPAN];
+#pragma unroll
+  for (int q = 0; q < RS32_SPAN / 4; ++q) {
+    const uint32_t i = (uint32_t)(q * RS_NT + threadIdx.x) * 4;
+    uint32_t rr[4] = {0, 0, 0, 0};
+    if (i + 4 <= n) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(src + i);
+      rr[0] = v.x, rr[1] = v.y, rr[2] = v.z, rr[3] = v.w;
+      *reinterpret_cast<uint4 *>(recs + i) = v;
+    } else {
+      for (int r = 0; r < 4; ++r)
+        if (i + r < n) recs[i + r] = rr[r] = src[i + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint32_t v = 0xFFFFFFFFu;
+      if (i + r < n) {
+        const uint32_t sub = log_sub ? rr[r] >> rbits2 : 0u;
+        v = (sub << 16) | atomicAdd(&cnt[sub], 1u);
+      }
+      pr[4 * q + r] = v;
+    }
+  }
+  __syncthreads();
+  // ---- exclusive scan of the counts; reservation in the final page regions ---------------------
+  {
+    const uint32_t per = S / RS_NT ? S / RS_NT : 1;
+    uint32_t lo = threadIdx.x * per, sacc = 0;
+    if (lo < S)
+      for (uint32_t i = 0; i < per; ++i) sacc += cnt[lo + i];
+    uint32_t inc = sacc;
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(inc, d, 64);
+      if ((int)(threadIdx.x & 63) >= d) inc += o;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+    uint32_t run = woff + inc - sacc;
+    if (lo < S)
+      for (uint32_t i = 0; i < per; ++i) {
+        tstart[lo + i] = run;
+        run += cnt[lo + i];
+      }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < S; i += RS_NT) {
+    const uint32_t c1 = cnt[i];
+    gbase[i] = (c1 ? atomicAdd(&dst_cursor[((uint64_t)region << log_sub) + i], c1) : 0u) - tstart[i];
+  }
+  // ---- place: entry = record index inside the tile -----------------------------------------------
+#pragma unroll
+  for (int q = 0; q < RS32_SPAN / 4; ++q) {
+    const uint32_t i = (uint32_t)(q * RS_NT + threadIdx.x) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t v = pr[4 * q + r];
+      if (v != 0xFFFFFFFFu) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = (uint16_t)(i + r);
+    }
+  }
+  __syncthreads();
+  // ---- write: two entries per lane, re-read from the LDS copy of the tile ------------------------
+  const uint32_t *sorted2 = reinterpret_cast<const uint32_t *>(sorted);
+  const uint32_t rmask2 = rbits2 >= 32 ? 0xFFFFFFFFu : ((1u << rbits2) - 1u);
+  auto spill_rec = [&](uint32_t rec) {  // the page's region is full: the whole key takes the spill path
+    const uint64_t key = unmix_key(((uint64_t)region << r1_bits) | rec, key_bits);
+    const unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
+    if (j < sp.cap) {
+      sp.keys[j] = key;
+      sp.lanes[j] = lane;
+      sp.counts[j] = 1u;
+    }
+  };
+  for (uint32_t i = threadIdx.x; 2 * i < n; i += RS_NT) {
+    const uint32_t ee = sorted2[i];
+    const bool two = 2 * i + 1 < n;
+    const uint32_t ra = recs[ee & 0xFFFFu], rb = two ? recs[ee >> 16] : 0u;
+    const uint32_t sa = log_sub ? ra >> rbits2 : 0u, sb = two ? (log_sub ? rb >> rbits2 : 0u) : sa;
+    const uint32_t at0 = gbase[sa] + 2 * i;
+    const uint64_t pa = ((uint64_t)region << log_sub) + sa, pb = ((uint64_t)region << log_sub) + sb;
+    if (two && sb == sa && at0 + 2 <= dst_cap) {
+      const uint2 rec2 = make_uint2(ra & rmask2, rb & rmask2);
+      __builtin_memcpy(dst_buf + pa * dst_cap + at0, &rec2, 8);
+    } else {
+      if (at0 < dst_cap) dst_buf[pa * dst_cap + at0] = ra & rmask2;
+      else spill_rec(ra);
+      if (two) {
+        const uint32_t at1 = gbase[sb] + 2 * i + 1;
+        if (at1 < dst_cap) dst_buf[pb * dst_cap + at1] = rb & rmask2;
+        else spill_rec(rb);
+      }
+    }
+  }
+}
+
 // In LDS a page is 8192 keys (64 KiB) + 8192 sixteen-bit DELTAS of this pass (16 KiB, two per
 // word) = 80 KiB, so two page workgroups share a CU.  The deltas are folded into the page's
 // 32-bit counts in HBM when the workgroup leaves (saturating, counting.rs:82-85) — and earlier

@@ -450,15 +450,18 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   // 4-byte records (k_part_scatter_sorted<.., true> + k_pages32) when a record fits: one level,
   // 11 ≤ 2k - log_pages ≤ 32 (the low bits of the mixed key below the page bits)
   const uint32_t rbits = 2 * c->cfg.k >= lp ? 2 * c->cfg.k - lp : 0;
-  const bool rec32 = !two_level && rbits >= 11 && rbits <= 32 && env_int("SHK_REC32", 1) != 0;
+  // (two levels: the level-1 record, 2k - log_p1 bits, must fit as well)
+  const uint32_t r1_bits = 2 * c->cfg.k >= log_p1 ? 2 * c->cfg.k - log_p1 : 0;
+  const bool rec32 = rbits >= 11 && rbits <= 32 && r1_bits <= 32 && env_int("SHK_REC32", 1) != 0;
   const uint32_t cap1 = (region_cap(sub_kmers_ub, P1, b.tile_count) + 3u) & ~3u;  // regions stay 16-B aligned
-  const uint32_t tiles_per_region = (cap1 + RS_TILE - 1) / RS_TILE;
-  const uint32_t cap_pg = two_level ? region_cap(sub_kmers_ub, n_pages, tiles_per_region) : cap1;
+  const uint32_t rs_tile = rec32 ? (uint32_t)RS32_TILE : (uint32_t)RS_TILE;
+  const uint32_t tiles_per_region = (cap1 + rs_tile - 1) / rs_tile;
+  const uint32_t cap_pg = two_level ? (region_cap(sub_kmers_ub, n_pages, tiles_per_region) + 3u) & ~3u : cap1;
   DevBuf &buf_pg = two_level ? c->part3 : c->part;  // what k_pages reads
   if ((uint64_t)P1 * cap1 * (rec32 ? 4 : 8) > 0xFFFFFFFFull)  // the scatter indexes part_buf with 32-bit byte offsets
     return fail(c, SHK_ERR_INVARIANT, "partition buffer of one launch exceeds 4 GiB");
   HIPC(c, c->part.ensure((uint64_t)P1 * cap1 * (rec32 ? 4 : 8)));
-  if (two_level) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * 8));
+  if (two_level) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * (rec32 ? 4 : 8)));
   if (!rec32)
     HIPC(c, c->part2.ensure((uint64_t)n_pages * ((uint64_t)cap_pg + MISS_SLACK) * 8));  // k_pages miss queues
   HIPC(c, c->part_meta.ensure(((size_t)P1 + n_pages) * 4 + 64));
@@ -472,6 +475,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const size_t lds_sorted = (size_t)sort_region_bytes(P1) + (size_t)PACK_WORDS * 8 + (size_t)P1 * 12;
   const uint32_t S = 1u << log_sub;
   const size_t lds_rs = (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12;
+  const size_t lds_rs32 = (size_t)RS32_TILE * 4 + (size_t)RS32_TILE * 2 + (size_t)S * 12;
   const bool multi = b.tiles != nullptr;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
   for (uint32_t lane = lane_lo; lane < lane_hi; ++lane) {
@@ -488,9 +492,15 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     }
     if (two_level) {
       ScopedTimer t(c, SHK_K_PSCAN);  // timer slot reused: the level-2 re-scatter
-      hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
-                         (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
-                         log_sub, 2 * c->cfg.k, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp);
+      if (rec32)
+        hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs32, c->stream,
+                           (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
+                           log_sub, r1_bits, 2 * c->cfg.k, cursor_pg, cap_pg, (uint32_t *)buf_pg.p, lane,
+                           c->d_stats, sp);
+      else
+        hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
+                           (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
+                           log_sub, 2 * c->cfg.k, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp);
     }
     {
       ScopedTimer t(c, SHK_K_PAGES);

@@ -21,7 +21,8 @@ os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats, f"profiles/{rnd}_kernel_stats.csv")
 
-NAMES = {"k_part_scatter_sorted<512>": "scatter", "k_pages": "pages",
+NAMES = {"k_part_scatter_sorted<512, true>": "scatter", "k_part_scatter_sorted<512, false>": "scatter",
+         "k_pages32": "pages", "k_pages": "pages", "k_part_rescatter": "rescatter", "k_fill": "fill",
          "k_histo": "histo", "k_direct": "direct", "k_scan": "scan", "k_mark_starts": "mark"}
 
 
@@ -42,7 +43,7 @@ with open(f"profiles/{rnd}_pmc_summary.csv", "w") as f:
 kernels = {}
 for kn, short in NAMES.items():
     fs, ws = fetch.get((kn, "FETCH_SIZE")), write.get((kn, "WRITE_SIZE"))
-    if fs is None and ws is None:
+    if (fs is None and ws is None) or short in kernels:
         continue
     fb, wb = 2 * (fs or 0) * 1024, (ws or 0) * 1024
     kernels[short] = {"kernel": kn, "fetch_bytes_corrected": int(fb), "write_bytes": int(wb),
