@@ -128,21 +128,27 @@ def main():
         nd = cnt["n_unique_kmers"] if world == 1 else min(genome, n_kmers)
         cap = cnt["table_capacity"]
         lanes = max(args.chunks, 1)
-        # per-kernel algorithmic bytes of ONE launch (what the kernel must move by design):
-        alg = {
-            "scatter": n_bases * 1 + n_kmers * 8,        # bases read + one 8-B record per k-mer written
-            "pages": n_kmers * 8 + cap * 12 * 2,         # records read + every page (8-B key, 4-B count) in and out
-            "histo": cap * (8 + 4 * lanes),              # one table scan per histogram emit
-            "direct": n_bases * 1 + n_kmers * 16 + nd * 8,
-            "scan": n_bases * 1,
-        }
+        # per-kernel algorithmic bytes of ONE launch (SURVEY.md §8d's per-unit figures: 1 B per base,
+        # 8 B per k-mer record written and read, 12 B per table slot in and out); a step has several
+        # launches of a kernel when the batch spans chunk lanes or exceeds 2^28 bases, and then each
+        # launch moves its share of the batch (but every page of the table)
+        def alg_bytes(name, lps):
+            return {
+                "scatter": (n_bases * 1 + n_kmers * 8) / lps,      # bases read + one record per k-mer written
+                "pages": n_kmers * 8 / lps + cap * 12 * 2,         # records read + every page in and out
+                "histo": cap * (8 + 4 * lanes),                    # one table scan per histogram emit
+                "direct": (n_bases * 1 + n_kmers * 16 + nd * 8) / lps,
+                "scan": n_bases * 1 / lps,
+            }.get(name)
         per_kernel = {}
         for name, (ms, launches) in tim.items():
-            if name in alg and launches:
+            lps = launches / args.steps
+            if launches and alg_bytes(name, lps) is not None:
                 avg = ms / launches
-                per_kernel[name] = {"avg_launch_ms": round(avg, 4), "launches_per_step": launches / args.steps,
-                                    "alg_bytes_per_launch": int(alg[name]),
-                                    "achieved_GBps": round(alg[name] / (avg * 1e-3) / 1e9, 1)}
+                ab = alg_bytes(name, lps)
+                per_kernel[name] = {"avg_launch_ms": round(avg, 4), "launches_per_step": lps,
+                                    "alg_bytes_per_launch": int(ab),
+                                    "achieved_GBps": round(ab / (avg * 1e-3) / 1e9, 1)}
         hot = [k_ for k_ in ("direct", "scatter", "pages") if k_ in per_kernel]
         dom = max(hot, key=lambda k_: per_kernel[k_]["avg_launch_ms"] * per_kernel[k_]["launches_per_step"]) if hot else None
         roof = None

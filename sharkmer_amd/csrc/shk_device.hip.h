@@ -235,17 +235,19 @@ __device__ __noinline__ uint4 stage_edge_group(const uint8_t *bases, uint64_t n_
 
 // Raw bytes + read-start words of one thread's share of a tile, loaded ahead of time so that
 // the HBM latency of tile i+1 hides behind the processing of tile i.
-template <int NT>
+template <int NT, int TT = TILE_T>
 struct StageRegs {
-  static constexpr int R = (TILE_GROUPS + NT - 1) / NT;
+  static constexpr int GROUPS = (TT + HALO) / 16;  // 16-base groups of one staged tile of TT end positions
+  static constexpr int R = (GROUPS + NT - 1) / NT;
   uint32_t raw[R][4];
   uint32_t sb0[R], sb1[R];
 };
-template <int NT>
-__device__ __forceinline__ void stage_prefetch(const BatchRef &b, uint64_t t0, StageRegs<NT> &pre) {
+template <int NT, int TT = TILE_T>
+__device__ __forceinline__ void stage_prefetch(const BatchRef &b, uint64_t t0, StageRegs<NT, TT> &pre) {
+  constexpr int TILE_GROUPS = StageRegs<NT, TT>::GROUPS;
   const int64_t p0 = (int64_t)t0 - HALO;
 #pragma unroll
-  for (int r = 0; r < StageRegs<NT>::R; ++r) {
+  for (int r = 0; r < StageRegs<NT, TT>::R; ++r) {
     const int m = threadIdx.x + r * NT;
     const int64_t p = p0 + (int64_t)m * 16;
     if (m < TILE_GROUPS && p >= 0 && (uint64_t)p + 16 <= b.n_bases) {
@@ -256,16 +258,18 @@ __device__ __forceinline__ void stage_prefetch(const BatchRef &b, uint64_t t0, S
   }
 }
 
-template <bool VALIDATE, int NT = WG, bool PACK = false>
+template <bool VALIDATE, int NT = WG, bool PACK = false, int TT = TILE_T>
 __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, uint64_t t1,
                                                uint8_t *lds, DevStats *stats,
-                                               const StageRegs<NT> &pre, uint32_t *packed = nullptr,
+                                               const StageRegs<NT, TT> &pre, uint32_t *packed = nullptr,
                                                uint32_t *rcpacked = nullptr) {
+  constexpr int TILE_GROUPS = StageRegs<NT, TT>::GROUPS;  // (shadow the file-scope constants: this
+  constexpr int TILE_LDS = TT + HALO;                      // function stages tiles of TT positions)
   uint32_t *gmask = reinterpret_cast<uint32_t *>(lds + TILE_LDS);  // nmask16 | smask16<<16
   const int64_t p0 = (int64_t)t0 - HALO;
   uint32_t n_non_n = 0;
 #pragma unroll
-  for (int r = 0; r < StageRegs<NT>::R; ++r) {
+  for (int r = 0; r < StageRegs<NT, TT>::R; ++r) {
     const int m = threadIdx.x + r * NT;
     if (m >= TILE_GROUPS) continue;  // (no break: keeps r a compile-time index into `pre`)
     int64_t p = p0 + (int64_t)m * 16;
@@ -351,10 +355,10 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
       if (m < 2) {
         const uint32_t v = pack16(*reinterpret_cast<const uint4 *>(lds + m * 16));
         packed[m] = v;
-        rcpacked[TILE_GROUPS - 1 - m] = rev2(~v);
+        if (rcpacked) rcpacked[TILE_GROUPS - 1 - m] = rev2(~v);
       } else {
         packed[TILE_GROUPS + m - 2] = 0;
-        rcpacked[TILE_GROUPS + m - 2] = 0;
+        if (rcpacked) rcpacked[TILE_GROUPS + m - 2] = 0;
       }
     }
   }
@@ -387,7 +391,7 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
       if (PACK) {
         const uint32_t v = pack16(c4);
         packed[m] = v;
-        rcpacked[TILE_GROUPS - 1 - m] = rev2(~v);
+        if (rcpacked) rcpacked[TILE_GROUPS - 1 - m] = rev2(~v);
       }
       if (ok) {
         uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -1136,6 +1140,21 @@ __device__ __forceinline__ uint64_t kmer_at(const uint32_t *packed, const uint32
   return window_at(rc ? rcpacked : packed, rc ? TILE_LDS - 1 - j : j - k + 1, k);  // one window read, no branch
 }
 
+// Layout of the 4-byte-record buffers: BLOCK-INTERLEAVED.  Record j of region r (a page, or a
+// super-page at level 1) lives at
+//     ((j >> RB_LOG) · n_regions + r) << RB_LOG  |  (j & (2^RB_LOG - 1))
+// i.e. the regions' 4-KiB blocks alternate.  All regions fill at nearly the same rate (the hash
+// spreads k-mers evenly), so the write fronts of all ≤ 4096 regions stay within a few MiB of one
+// another instead of one per region-sized stride, and the scatter's stores — every store
+// instruction touches a dozen regions — keep hitting the same few address translations.
+constexpr uint32_t RB_LOG = 10;  // records per block: 4 KiB
+__device__ __forceinline__ uint32_t rec_slot(uint32_t region, uint32_t n_regions, uint32_t j) {
+  return (((j >> RB_LOG) * n_regions + region) << RB_LOG) | (j & ((1u << RB_LOG) - 1u));
+}
+__device__ __forceinline__ uint64_t rec_slot64(uint64_t region, uint64_t n_regions, uint32_t j) {
+  return ((((uint64_t)(j >> RB_LOG)) * n_regions + region) << RB_LOG) | (j & ((1u << RB_LOG) - 1u));
+}
+
 // REC32: the 4-byte-record variant (one level, 2k - log_parts ≤ 32): a record is the low
 // 2k - log_parts bits of the MIXED key (the page is implied by the region, mix_key is a bijection),
 // runs are packed without padding, one 4-B store per record.
@@ -1323,15 +1342,15 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
         const uint32_t at0 = gbase[pc0] + 2 * i;  // record index inside the page's region
         // (a launch covers ≤ 2^28 k-mers: byte offsets into part_buf fit 32 bits)
         char *const base = reinterpret_cast<char *>(part_buf32);
-        if (two && pc1 == pc0 && at0 + 2 <= cap_p) {
-          uint2 rec2 = make_uint2(r0, r1);
-          __builtin_memcpy(base + (pc0 * cap_p + at0) * 4u, &rec2, 8);
+        if (two && pc1 == pc0 && at0 + 2 <= cap_p && (at0 & ((1u << RB_LOG) - 1u)) != (1u << RB_LOG) - 1u) {
+          uint2 rec2 = make_uint2(r0, r1);  // (both records in one block)
+          __builtin_memcpy(base + rec_slot(pc0, P, at0) * 4u, &rec2, 8);
         } else {
-          if (at0 < cap_p) *reinterpret_cast<uint32_t *>(base + (pc0 * cap_p + at0) * 4u) = r0;
+          if (at0 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(pc0, P, at0) * 4u) = r0;
           else spill_km(km0);
           if (two) {
             const uint32_t at1 = gbase[pc1] + 2 * i + 1;
-            if (at1 < cap_p) *reinterpret_cast<uint32_t *>(base + (pc1 * cap_p + at1) * 4u) = r1;
+            if (at1 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(pc1, P, at1) * 4u) = r1;
             else spill_km(km1);
           }
         }
@@ -1373,6 +1392,224 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
     t0 = n0;
     t1 = n1;
     lane = nl;
+    have = hn;
+  }
+  __syncthreads();
+  {
+    uint32_t tot = wg_sum<NT>(n_non_n, red);
+    if (threadIdx.x == 0 && tot) atomicAdd(&lane_bases[lane_filter], (unsigned long long)tot);
+  }
+#ifdef SHK_PHASE_TIMING
+  if (dbg && threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i) dbg[(uint64_t)blockIdx.x * 8 + i] = ph[i];
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scatter32: the 4-byte-record scatter with the records kept in LDS.  Same job and same output
+// as k_part_scatter_sorted<.., true>, but a (macro) tile is processed as TILE_T/TT sub-tiles of
+// TT end positions, small enough that the RECORD of every k-mer (32 bits) stays in LDS from the
+// walk to the write-out:
+//   walk   : rolling extraction → mix_key → page (top bits) and record (low bits); the record goes
+//            to recs[], (page, rank) stays in a register
+//   scan, reserve : as before
+//   place  : sorted[tstart[page] + rank] = page << 14 | index into recs    (32-bit entries)
+//   write  : entry → record from recs[], page from the entry: no k-mer is rebuilt, nothing is
+//            hashed a second time; two entries per lane, one 8-B store when they share a page
+// LDS: 4·TT (entries; aliases the staged code bytes) + 4·TT (records) + one packed stream
+// (walk warm-up) + 12·P.
+// ------------------------------------------------------------------------------------------
+template <int NT, int TT>
+__global__ void __launch_bounds__(NT, 4) k_scatter32(
+    BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
+    uint32_t cap_p, uint32_t *__restrict__ part_buf32, DevStats *__restrict__ stats,
+    unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+  __shared__ uint32_t wsum[NT / 64];
+  __shared__ uint32_t red[NT / 64];
+  static_assert(TILE_T % TT == 0 && TT % (8 * NT) == 0 && 4 * TT >= TT + HALO + 4 * ((TT + HALO) / 16), "tile shape");
+  constexpr int SPAN = TT / NT;
+  constexpr int GROUPS = (TT + HALO) / 16;
+  const uint32_t P = 1u << log_parts;
+  uint8_t *codes = reinterpret_cast<uint8_t *>(sh);  // staged tile; dead once the walk is over
+  uint32_t *sorted = sh;                             // TT entries; aliases codes
+  uint32_t *recs = sh + TT;                          // TT records: thread t's i-th end position at i·NT + t
+  uint32_t *packed = recs + TT;                      // GROUPS + 2 words
+  uint32_t *cnt = packed + GROUPS + 2;               // P
+  uint32_t *tstart = cnt + P;                        // P
+  uint32_t *gbase = tstart + P;                      // P: (this tile's reservation) - tstart
+  // (cnt[P..P+7] = tstart[0..7] double as the spare counters of the walk: tstart is written after it)
+#ifdef SHK_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#endif
+  uint32_t n_non_n = 0;
+  const int k = b.k;
+  const uint64_t mask = (1ull << (2 * k)) - 1;
+  const uint32_t mask_lo = (uint32_t)mask, mask_hi = (uint32_t)(mask >> 32);
+  const uint32_t per = P / NT ? P / NT : 1;
+  const uint32_t rbits = 2u * (uint32_t)k - log_parts;  // ≤ 32: bits of a record
+  const uint32_t rmask = (uint32_t)(0xFFFFFFFFull >> (32 - rbits));
+
+  // iteration over sub-tiles: (macro tile t = [t0,t1) of chunk lane `lane`, sub-tile index sub)
+  uint64_t t = blockIdx.x, t0, t1;
+  uint32_t lane;
+  bool have = next_tile(b, t, true, lane_filter, t0, t1, lane);
+  uint32_t sub = 0;
+  StageRegs<NT, TT> pre;
+  if (have) stage_prefetch<NT, TT>(b, t0, pre);
+  while (have) {
+    const uint64_t s0 = t0 + (uint64_t)sub * TT;
+    const uint64_t s1 = s0 + TT < t1 ? s0 + TT : t1;
+    __syncthreads();  // previous sub-tile's write phase is done with sorted/recs/cnt/tstart/gbase
+#ifdef SHK_PHASE_TIMING
+    tprev = __builtin_readcyclecounter();
+#endif
+    for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
+    n_non_n += stage_tile<true, NT, true, TT>(b, s0, s1, codes, stats, pre, packed, nullptr);
+    // the next sub-tile: of this macro tile, or the first one of this workgroup's next macro tile
+    uint64_t nt = t, n0 = t0, n1 = t1;
+    uint32_t nl = lane, nsub = sub + 1;
+    bool hn = true;
+    if (t0 + (uint64_t)nsub * TT >= t1) {
+      nt = t + gridDim.x;
+      hn = next_tile(b, nt, true, lane_filter, n0, n1, nl);
+      nsub = 0;
+    }
+    if (hn) stage_prefetch<NT, TT>(b, n0 + (uint64_t)nsub * TT, pre);  // in flight during the rest of this one
+    __syncthreads();
+    STAMP(0);
+    // ---- walk ---------------------------------------------------------------------------------
+    uint32_t pr[SPAN];
+    {
+      const int e0 = threadIdx.x * SPAN;
+      const int n_end = (int)(s1 - s0);
+      const int jemit = HALO + e0;
+      const int jend = HALO + (e0 + SPAN < n_end ? e0 + SPAN : n_end);
+      Roll x{0, 0, 0, 0};
+      if (e0 < n_end) {
+        // frames just before the first end position: the k bases up to jemit-1 as one window
+        const uint64_t f0 = window_at(packed, jemit - k, k);
+        const uint64_t r0 = revcomp(f0, k) << (64 - 2 * k);
+        x.f_lo = (uint32_t)f0;
+        x.f_hi = (uint32_t)(f0 >> 32);
+        x.r_lo = (uint32_t)r0;
+        x.r_hi = (uint32_t)(r0 >> 32);
+      }
+#pragma unroll
+      for (int q = 0; q < SPAN / 8; ++q) {
+        uint64_t w = 0;
+        if (jemit + q * 8 < jend) w = *reinterpret_cast<const uint64_t *>(codes + jemit + q * 8);
+        // Straight-line on purpose: every lane mixes and issues its LDS add (end positions without
+        // a k-mer — bit 2 clear; never set at or beyond the tile's end — count into a spare
+        // counter behind cnt[P-1]), and the eight returned ranks are only looked at after the
+        // eighth add has been issued.  With a branch per k-mer the wave sits out a full LDS round
+        // trip for every single rank.
+        uint32_t pcs[8], rks[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const uint32_t c = (uint32_t)(w >> (8 * r)) & 0xFF;
+          roll_step(x, c & 3u, mask_lo, mask_hi);
+          const uint64_t fwd = ((uint64_t)x.f_hi << 32) | x.f_lo;
+          const uint64_t rev = (((uint64_t)x.r_hi << 32) | x.r_lo) >> (64 - 2 * k);
+          const uint64_t y = mix_key(rev < fwd ? rev : fwd, 2 * k);
+          pcs[r] = (c & 4u) ? (uint32_t)(y >> rbits) : P + (threadIdx.x & 7u);
+          recs[(q * 8 + r) * NT + threadIdx.x] = (uint32_t)y & rmask;  // transposed: no bank conflicts
+          rks[r] = atomicAdd(&cnt[pcs[r]], 1u);  // rank < 2^14
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pr[q * 8 + r] = pcs[r] >= P ? 0xFFFFFFFFu : (pcs[r] << 16) | rks[r];
+      }
+    }
+    __syncthreads();
+    STAMP(2);
+    // ---- exclusive scan of the counts → tstart ---------------------------------------------------
+    {
+      uint32_t lo = threadIdx.x * per, sacc = 0;
+      if (lo < P)
+        for (uint32_t i = 0; i < per; ++i) sacc += cnt[lo + i];
+      uint32_t inc = sacc;
+      for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) inc += o;
+      }
+      if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+      __syncthreads();
+      uint32_t woff = 0;
+      for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+      uint32_t run = woff + inc - sacc;
+      if (lo < P)
+        for (uint32_t i = 0; i < per; ++i) {
+          tstart[lo + i] = run;
+          run += cnt[lo + i];
+        }
+    }
+    // reserve this sub-tile's run in every page's region: one returning device-scope add per
+    // non-empty (sub-tile, page); the results are parked in registers over the place phase
+    uint32_t gres[MAX_PARTS / NT > 0 ? MAX_PARTS / NT : 1];
+#pragma unroll
+    for (int r = 0; r < (int)(sizeof(gres) / 4); ++r) {
+      const uint32_t i = threadIdx.x + r * NT;
+      gres[r] = 0;
+      if (i < P) {
+        const uint32_t c1 = cnt[i];
+        if (c1) gres[r] = atomicAdd(&cursor[i], c1);
+      }
+    }
+    __syncthreads();  // codes are dead from here: `sorted` may overwrite them; tstart is complete
+    STAMP(3);
+    // ---- place ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < SPAN; ++i) {
+      const uint32_t v = pr[i];
+      if (v != 0xFFFFFFFFu) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = ((v >> 16) << 14) | (i * NT + threadIdx.x);  // → recs index
+    }
+#pragma unroll
+    for (int r = 0; r < (int)(sizeof(gres) / 4); ++r)
+      if (threadIdx.x + r * NT < P) gbase[threadIdx.x + r * NT] = gres[r] - tstart[threadIdx.x + r * NT];
+    __syncthreads();
+    STAMP(4);
+    // ---- write: two entries per lane ------------------------------------------------------------
+    {
+      const uint32_t n_rec = tstart[P - 1] + cnt[P - 1];
+      const uint2 *sorted2 = reinterpret_cast<const uint2 *>(sorted);
+      char *const base = reinterpret_cast<char *>(part_buf32);
+      auto spill_rec = [&](uint32_t pc, uint32_t rec) {  // the page's region is full (skewed input)
+        const uint64_t km = unmix_key(((uint64_t)pc << rbits) | rec, 2 * k);
+        const unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
+        if (j < sp.cap) {
+          sp.keys[j] = km;
+          sp.lanes[j] = lane;
+          sp.counts[j] = 1u;
+        }
+      };
+      for (uint32_t i = threadIdx.x; 2 * i < n_rec; i += NT) {
+        const uint2 ee = sorted2[i];
+        const bool two = 2 * i + 1 < n_rec;
+        const uint32_t pc0 = ee.x >> 14, pc1 = two ? ee.y >> 14 : pc0;
+        const uint32_t r0 = recs[ee.x & 0x3FFFu], r1 = two ? recs[ee.y & 0x3FFFu] : 0u;
+        const uint32_t at0 = gbase[pc0] + 2 * i;  // record index inside the page's region
+        // (a launch covers ≤ 2^28 k-mers: byte offsets into part_buf fit 32 bits)
+        if (two && pc1 == pc0 && at0 + 2 <= cap_p && (at0 & ((1u << RB_LOG) - 1u)) != (1u << RB_LOG) - 1u) {
+          const uint2 rec2 = make_uint2(r0, r1);  // (both records in one block)
+          __builtin_memcpy(base + rec_slot(pc0, P, at0) * 4u, &rec2, 8);
+        } else {
+          if (at0 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(pc0, P, at0) * 4u) = r0;
+          else spill_rec(pc0, r0);
+          if (two) {
+            const uint32_t at1 = gbase[pc1] + 2 * i + 1;
+            if (at1 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(pc1, P, at1) * 4u) = r1;
+            else spill_rec(pc1, r1);
+          }
+        }
+      }
+    }
+    STAMP(5);
+    t = nt;
+    t0 = n0;
+    t1 = n1;
+    lane = nl;
+    sub = nsub;
     have = hn;
   }
   __syncthreads();
@@ -1536,7 +1773,7 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
   const uint32_t r0 = tile * RS32_TILE;
   if (r0 >= filled) return;
   const uint32_t n = filled - r0 < (uint32_t)RS32_TILE ? filled - r0 : (uint32_t)RS32_TILE;
-  const uint32_t *src = src_buf + (uint64_t)region * src_cap + r0;  // 16-B aligned: src_cap % 4 == 0
+  const uint32_t n_src_regions = gridDim.x / tiles_per_region;  // level-1 regions (super-pages)
   uint32_t *recs = sh;                                                      // RS32_TILE records
   uint16_t *sorted = reinterpret_cast<uint16_t *>(sh + RS32_TILE);          // RS32_TILE entries
   uint32_t *cnt = sh + RS32_TILE + RS32_TILE / 2;                           // S
@@ -1551,13 +1788,13 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
   for (int q = 0; q < RS32_SPAN / 4; ++q) {
     const uint32_t i = (uint32_t)(q * RS_NT + threadIdx.x) * 4;
     uint32_t rr[4] = {0, 0, 0, 0};
-    if (i + 4 <= n) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(src + i);
+    if (i + 4 <= n) {  // (four records at a multiple of four never straddle a block)
+      const uint4 v = *reinterpret_cast<const uint4 *>(src_buf + rec_slot64(region, n_src_regions, r0 + i));
       rr[0] = v.x, rr[1] = v.y, rr[2] = v.z, rr[3] = v.w;
       *reinterpret_cast<uint4 *>(recs + i) = v;
     } else {
       for (int r = 0; r < 4; ++r)
-        if (i + r < n) recs[i + r] = rr[r] = src[i + r];
+        if (i + r < n) recs[i + r] = rr[r] = src_buf[rec_slot64(region, n_src_regions, r0 + i + r)];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1627,15 +1864,16 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
     const uint32_t sa = log_sub ? ra >> rbits2 : 0u, sb = two ? (log_sub ? rb >> rbits2 : 0u) : sa;
     const uint32_t at0 = gbase[sa] + 2 * i;
     const uint64_t pa = ((uint64_t)region << log_sub) + sa, pb = ((uint64_t)region << log_sub) + sb;
-    if (two && sb == sa && at0 + 2 <= dst_cap) {
+    const uint64_t n_dst = (uint64_t)n_src_regions << log_sub;  // pages
+    if (two && sb == sa && at0 + 2 <= dst_cap && (at0 & ((1u << RB_LOG) - 1u)) != (1u << RB_LOG) - 1u) {
       const uint2 rec2 = make_uint2(ra & rmask2, rb & rmask2);
-      __builtin_memcpy(dst_buf + pa * dst_cap + at0, &rec2, 8);
+      __builtin_memcpy(dst_buf + rec_slot64(pa, n_dst, at0), &rec2, 8);
     } else {
-      if (at0 < dst_cap) dst_buf[pa * dst_cap + at0] = ra & rmask2;
+      if (at0 < dst_cap) dst_buf[rec_slot64(pa, n_dst, at0)] = ra & rmask2;
       else spill_rec(ra);
       if (two) {
         const uint32_t at1 = gbase[sb] + 2 * i + 1;
-        if (at1 < dst_cap) dst_buf[pb * dst_cap + at1] = rb & rmask2;
+        if (at1 < dst_cap) dst_buf[rec_slot64(pb, n_dst, at1)] = rb & rmask2;
         else spill_rec(rb);
       }
     }
@@ -1881,7 +2119,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
   for (uint32_t i = threadIdx.x; i < PAGE_SLOTS; i += PG_WG) dl[i] = 0;
   __syncthreads();
   const uint32_t n = filled;
-  const uint32_t *src = part_buf + (uint64_t)page * cap_p;
+  const uint64_t n_regions = gridDim.x;  // one region per page, block-interleaved (rec_slot)
   const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
   uint32_t *mq = mqs + wave * MQ32;
   uint32_t n_miss = 0;  // wave-uniform
@@ -1936,13 +2174,15 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
   // Main loop: one 16-B load = four records per thread per step, the next step's load in flight.
   // No barrier in here: queues are per wave, and a slot's count of this pass is a full 32-bit word
   // (a page sees < 2^31 records), so nothing has to be folded away mid-pass.
-  const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
   const uint32_t n_steps = n / (P32_RPS * PG_WG);
+  auto load4 = [&](uint32_t step) {  // this lane's four records of a step (they share a block)
+    return *reinterpret_cast<const uint4 *>(part_buf + rec_slot64(page, n_regions, (step * PG_WG + threadIdx.x) * 4u));
+  };
   uint4 nxt;
-  if (n_steps) nxt = src4[threadIdx.x];
+  if (n_steps) nxt = load4(0);
   for (uint32_t step = 0; step < n_steps; ++step) {
     const uint32_t rr[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
-    if (step + 1 < n_steps) nxt = src4[(uint64_t)(step + 1) * PG_WG + threadIdx.x];
+    if (step + 1 < n_steps) nxt = load4(step + 1);
     uint4 bk[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bk[q] = *reinterpret_cast<const uint4 *>(&tags[(rr[q] >> fpb) << 2]);
@@ -1972,7 +2212,8 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
   }
   drain();
   // tail (< P32_RPS*PG_WG records): straight through the general probe
-  for (uint32_t i = n_steps * P32_RPS * PG_WG + threadIdx.x; i < n; i += PG_WG) insert(src[i]);
+  for (uint32_t i = n_steps * P32_RPS * PG_WG + threadIdx.x; i < n; i += PG_WG)
+    insert(part_buf[rec_slot64(page, n_regions, i)]);
   __syncthreads();
   // this pass's counts → the page's counts (saturating), four slots per lane
   for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG) {

@@ -400,6 +400,7 @@ static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
 }
 
 constexpr int SC_NT = 512;  // threads of the partition count / sorted scatter workgroups
+constexpr int SC32_TT = 8192;  // sub-tile of k_scatter32: 32 KiB of records + 32 KiB of entries in LDS
 
 static uint32_t region_cap(uint64_t n_records_ub, uint64_t n_regions, uint64_t pads) {
   // mean load + 25 % + worst-case padding + slack, even
@@ -453,10 +454,12 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   // (two levels: the level-1 record, 2k - log_p1 bits, must fit as well)
   const uint32_t r1_bits = 2 * c->cfg.k >= log_p1 ? 2 * c->cfg.k - log_p1 : 0;
   const bool rec32 = rbits >= 11 && rbits <= 32 && r1_bits <= 32 && env_int("SHK_REC32", 1) != 0;
-  const uint32_t cap1 = (region_cap(sub_kmers_ub, P1, b.tile_count) + 3u) & ~3u;  // regions stay 16-B aligned
+  // (4-byte-record regions are block-interleaved, rec_slot: whole blocks of 2^RB_LOG records)
+  const uint32_t cap1 = (region_cap(sub_kmers_ub, P1, b.tile_count) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
   const uint32_t rs_tile = rec32 ? (uint32_t)RS32_TILE : (uint32_t)RS_TILE;
   const uint32_t tiles_per_region = (cap1 + rs_tile - 1) / rs_tile;
-  const uint32_t cap_pg = two_level ? (region_cap(sub_kmers_ub, n_pages, tiles_per_region) + 3u) & ~3u : cap1;
+  const uint32_t cap_pg =
+      two_level ? (region_cap(sub_kmers_ub, n_pages, tiles_per_region) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u) : cap1;
   DevBuf &buf_pg = two_level ? c->part3 : c->part;  // what k_pages reads
   if ((uint64_t)P1 * cap1 * (rec32 ? 4 : 8) > 0xFFFFFFFFull)  // the scatter indexes part_buf with 32-bit byte offsets
     return fail(c, SHK_ERR_INVARIANT, "partition buffer of one launch exceeds 4 GiB");
@@ -475,6 +478,9 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const size_t lds_sorted = (size_t)sort_region_bytes(P1) + (size_t)PACK_WORDS * 8 + (size_t)P1 * 12;
   const uint32_t S = 1u << log_sub;
   const size_t lds_rs = (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12;
+  // records-in-LDS scatter (k_scatter32) when its LDS footprint still lets two workgroups share a CU
+  const size_t lds_s32 = (size_t)SC32_TT * 8 + ((size_t)(SC32_TT + HALO) / 16 + 2) * 4 + (size_t)P1 * 12;
+  const bool lds32 = rec32 && lds_s32 <= 80 * 1024 && env_int("SHK_SCATTER32_LDS", 1) != 0;
   const size_t lds_rs32 = (size_t)RS32_TILE * 4 + (size_t)RS32_TILE * 2 + (size_t)S * 12;
   const bool multi = b.tiles != nullptr;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
@@ -483,7 +489,16 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       HIPC(c, hipMemsetAsync(cursor1, 0, (size_t)pg.cursor_words() * 4, c->stream));
     {
       ScopedTimer t(c, SHK_K_SCATTER);
-      if (rec32)
+      if (rec32 && lds32) {
+        static bool attr_set = false;  // > 64 KiB of dynamic LDS has to be asked for
+        if (!attr_set) {
+          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC_NT, SC32_TT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL((k_scatter32<SC_NT, SC32_TT>), dim3(G), dim3(SC_NT), lds_s32, c->stream, b, log_p1,
+                           lane, cursor1, cap1, (uint32_t *)c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
+      } else if (rec32)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, true>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
       else
