@@ -1419,6 +1419,19 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
 // LDS: 4·TT (entries; aliases the staged code bytes) + 4·TT (records) + one packed stream
 // (walk warm-up) + 12·P.
 // ------------------------------------------------------------------------------------------
+// place phase of k_scatter32.  The __restrict__ parameters are the point: `sorted` and `tstart`
+// are carved out of the same LDS block, and without the promise that they do not overlap every
+// tstart read has to wait behind the previous entry's write (one LDS round trip per entry).
+template <int NT, int SPAN>
+__device__ __forceinline__ void place_entries(uint32_t *__restrict__ sorted, const uint32_t *__restrict__ tstart,
+                                              const uint32_t (&pr)[SPAN]) {
+#pragma unroll
+  for (int i = 0; i < SPAN; ++i) {
+    const uint32_t v = pr[i];
+    if (v != 0xFFFFFFFFu) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = ((v >> 16) << 14) | (i * NT + threadIdx.x);  // → recs index
+  }
+}
+
 template <int NT, int TT>
 __global__ void __launch_bounds__(NT, 4) k_scatter32(
     BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
@@ -1559,11 +1572,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
     __syncthreads();  // codes are dead from here: `sorted` may overwrite them; tstart is complete
     STAMP(3);
     // ---- place ------------------------------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < SPAN; ++i) {
-      const uint32_t v = pr[i];
-      if (v != 0xFFFFFFFFu) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = ((v >> 16) << 14) | (i * NT + threadIdx.x);  // → recs index
-    }
+    place_entries<NT, SPAN>(sorted, tstart, pr);
 #pragma unroll
     for (int r = 0; r < (int)(sizeof(gres) / 4); ++r)
       if (threadIdx.x + r * NT < P) gbase[threadIdx.x + r * NT] = gres[r] - tstart[threadIdx.x + r * NT];
@@ -1583,6 +1592,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
           sp.counts[j] = 1u;
         }
       };
+#pragma unroll 4
       for (uint32_t i = threadIdx.x; 2 * i < n_rec; i += NT) {
         const uint2 ee = sorted2[i];
         const bool two = 2 * i + 1 < n_rec;

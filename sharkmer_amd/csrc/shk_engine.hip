@@ -62,6 +62,7 @@ struct TimedEvent {
 struct shk_ctx {
   shk_config cfg{};
   uint32_t n_lanes = 1;
+  uint32_t n_cus = 256;  // compute units of the device (multiProcessorCount)
   hipStream_t stream = nullptr;
   // table
   TableRef tb{};
@@ -400,7 +401,8 @@ static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
 }
 
 constexpr int SC_NT = 512;  // threads of the partition count / sorted scatter workgroups
-constexpr int SC32_TT = 8192;  // sub-tile of k_scatter32: 32 KiB of records + 32 KiB of entries in LDS
+constexpr int SC32_NT = 1024, SC32_TT = 16384;  // k_scatter32: 64 KiB of records + 64 KiB of entries in LDS,
+constexpr size_t SC32_LDS_MAX = 160 * 1024 - 256;  // one workgroup per CU (its static LDS is 128 B)
 
 static uint32_t region_cap(uint64_t n_records_ub, uint64_t n_regions, uint64_t pads) {
   // mean load + 25 % + worst-case padding + slack, even
@@ -478,9 +480,9 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const size_t lds_sorted = (size_t)sort_region_bytes(P1) + (size_t)PACK_WORDS * 8 + (size_t)P1 * 12;
   const uint32_t S = 1u << log_sub;
   const size_t lds_rs = (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12;
-  // records-in-LDS scatter (k_scatter32) when its LDS footprint still lets two workgroups share a CU
+  // records-in-LDS scatter (k_scatter32: one 1024-thread workgroup per CU) when its LDS footprint fits
   const size_t lds_s32 = (size_t)SC32_TT * 8 + ((size_t)(SC32_TT + HALO) / 16 + 2) * 4 + (size_t)P1 * 12;
-  const bool lds32 = rec32 && lds_s32 <= 80 * 1024 && env_int("SHK_SCATTER32_LDS", 1) != 0;
+  const bool lds32 = rec32 && lds_s32 <= SC32_LDS_MAX && env_int("SHK_SCATTER32_LDS", 1) != 0;
   const size_t lds_rs32 = (size_t)RS32_TILE * 4 + (size_t)RS32_TILE * 2 + (size_t)S * 12;
   const bool multi = b.tiles != nullptr;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
@@ -492,12 +494,13 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       if (rec32 && lds32) {
         static bool attr_set = false;  // > 64 KiB of dynamic LDS has to be asked for
         if (!attr_set) {
-          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC_NT, SC32_TT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
           attr_set = true;
         }
-        hipLaunchKernelGGL((k_scatter32<SC_NT, SC32_TT>), dim3(G), dim3(SC_NT), lds_s32, c->stream, b, log_p1,
-                           lane, cursor1, cap1, (uint32_t *)c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
+        hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT), lds_s32,
+                           c->stream, b, log_p1, lane, cursor1, cap1, (uint32_t *)c->part.p, c->d_stats,
+                           c->d_lane_bases, sp, dbg);
       } else if (rec32)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, true>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
@@ -638,6 +641,7 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   shk_ctx *c = new shk_ctx();
   c->cfg = *cfg;
   c->n_lanes = cfg->chunks == 0 ? 1 : cfg->chunks;  // io.rs:378
+  if (prop.multiProcessorCount > 0) c->n_cus = (uint32_t)prop.multiProcessorCount;
   c->lane_reads.assign(c->n_lanes, 0);
   auto bail = [&](int code) {
     g_create_error = c->err;
