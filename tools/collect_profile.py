@@ -21,9 +21,10 @@ os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats, f"profiles/{rnd}_kernel_stats.csv")
 
-NAMES = {"k_part_scatter_sorted<512, true>": "scatter", "k_part_scatter_sorted<512, false>": "scatter",
-         "k_pages32": "pages", "k_pages": "pages", "k_part_rescatter": "rescatter", "k_fill": "fill",
-         "k_histo": "histo", "k_direct": "direct", "k_scan": "scan", "k_mark_starts": "mark"}
+# kernel-name prefix → short name used by bench.py (first match wins)
+NAMES = [("k_scatter32", "scatter"), ("k_part_scatter_sorted", "scatter"), ("k_pages32", "pages"),
+         ("k_pages", "pages"), ("k_part_rescatter", "rescatter"), ("k_fill", "fill"), ("k_histo", "histo"),
+         ("k_direct", "direct"), ("k_scan", "scan"), ("k_mark_starts", "mark")]
 
 
 def means(sub):
@@ -41,10 +42,11 @@ with open(f"profiles/{rnd}_pmc_summary.csv", "w") as f:
     for (kn, c), v in sorted({**fetch, **write}.items()):
         f.write(f"{kn},{c},{v:.1f}\n")
 kernels = {}
-for kn, short in NAMES.items():
-    fs, ws = fetch.get((kn, "FETCH_SIZE")), write.get((kn, "WRITE_SIZE"))
-    if (fs is None and ws is None) or short in kernels:
+for kn in sorted({key[0] for key in list(fetch) + list(write)}):
+    short = next((sh for pre, sh in NAMES if kn.startswith(pre)), None)
+    if short is None or short in kernels:
         continue
+    fs, ws = fetch.get((kn, "FETCH_SIZE")), write.get((kn, "WRITE_SIZE"))
     fb, wb = 2 * (fs or 0) * 1024, (ws or 0) * 1024
     kernels[short] = {"kernel": kn, "fetch_bytes_corrected": int(fb), "write_bytes": int(wb),
                       "hbm_bytes_per_launch": int(fb + wb)}

@@ -1,56 +1,47 @@
 #!/usr/bin/env python3
-"""Quality check of the table hash (shk::hash64 in sharkmer_amd/csrc/shk_device.hip.h): page
-occupancy spread and (page, home-slot) collisions against a Poisson process, on random,
-AT-rich, tandem-repeat and sequential keys.  CPU only (numpy restatement of the device formula)."""
+"""Quality check of the table hash (shk::mix_key in sharkmer_amd/csrc/shk_device.hip.h): page
+occupancy spread and home-bucket overflow against a Poisson process, plus the bijection property,
+on random, AT-rich, tandem-repeat and sequential keys.  CPU only (numpy restatement of the device
+formula: multiply by an odd constant mod 2^2k, fold the upper half down, multiply again)."""
 import numpy as np
-
-M32 = np.uint64(0xFFFFFFFF)
-A, B, C = (np.uint64(0x9E3779B1 & 0xFFFFFF), np.uint64(0x85EBCA77 & 0xFFFFFF), np.uint64(0xC2B2AE3D & 0xFFFFFF))
-
-
-def hash64(key, fin=True):
-    c0 = key & np.uint64(0xFFFFFF)
-    c1 = (key >> np.uint64(24)) & np.uint64(0xFFFFFF)
-    c2 = key >> np.uint64(48)
-    h = (c0 * A + c1 * B + c2 * C) & M32
-    if fin:
-        h ^= h >> np.uint64(15)
-        h = (h * np.uint64(0x2C1B3C6D)) & M32
-        h ^= h >> np.uint64(12)
-    return h
-
-
-def canon(codes, k):
-    n = len(codes) - k + 1
-    f = np.zeros(n, dtype=np.uint64)
-    r = np.zeros(n, dtype=np.uint64)
+M1=np.uint64(0x9E3779B97F4A7C15); M2=np.uint64(0xD6E8FEB86659FD93)
+def mix(x,bits):
+    mask=np.uint64((1<<bits)-1)
+    s=np.uint64((bits+1)//2)
+    x=(x*M1)&mask
+    x^=x>>s
+    x=(x*M2)&mask
+    return x
+def canon(codes,k):
+    n=len(codes)-k+1
+    f=np.zeros(n,dtype=np.uint64); r=np.zeros(n,dtype=np.uint64)
     for j in range(k):
-        b = codes[j:j + n].astype(np.uint64)
-        f = (f << np.uint64(2)) | b
-        r |= (np.uint64(3) - b) << np.uint64(2 * j)
-    return np.unique(np.minimum(f, r))
-
-
-def stats(keys, name, log_pages=11):
-    for nm, fin in (("final", True), ("no-finaliser", False)):
-        h = hash64(keys, fin)
-        page = (h >> np.uint64(32 - log_pages)).astype(np.int64)
-        cnt = np.bincount(page, minlength=1 << log_pages)
-        slot = ((h >> np.uint64(20 - log_pages)) & np.uint64(4095)).astype(np.int64)
-        u = len(np.unique(page * 4096 + slot))
-        lam = len(keys) / (1 << log_pages)
-        print(f"{name:12s} {nm:13s} n={len(keys):8d} mean/page={lam:7.0f} max={cnt.max():6d} "
-              f"std={cnt.std():6.1f} (poisson {lam ** 0.5:5.1f}) distinct(page,slot)/n={u / len(keys):.4f}")
-
-
-if __name__ == "__main__":
-    rng = np.random.default_rng(1)
-    stats(canon(rng.integers(0, 4, size=3_000_000), 21), "random k21")
-    unit = rng.integers(0, 4, size=7)
-    g2 = np.tile(unit, 300000)
-    mut = rng.random(len(g2)) < 0.02
-    g2[mut] = rng.integers(0, 4, size=mut.sum())
-    stats(canon(g2, 21), "tandem7")
-    stats(canon(rng.choice(4, size=2_000_000, p=[0.45, 0.05, 0.05, 0.45]), 21), "AT-rich")
-    stats(np.arange(3_000_000, dtype=np.uint64) * np.uint64(4), "sequential")
-    stats(canon(rng.integers(0, 4, size=2_000_000), 31), "random k31")
+        b=codes[j:j+n].astype(np.uint64)
+        f=(f<<np.uint64(2))|b
+        r|=(np.uint64(3)-b)<<np.uint64(2*j)
+    return np.unique(np.minimum(f,r))
+def stats(keys,name,k,lp=10):
+    bits=2*k
+    y=mix(keys,bits)
+    assert len(np.unique(y))==len(keys)
+    Y=y<<np.uint64(64-bits)
+    page=(Y>>np.uint64(64-lp)).astype(np.int64)
+    bucket=((Y>>np.uint64(64-lp-11))&np.uint64(2047)).astype(np.int64)
+    cnt=np.bincount(page,minlength=1<<lp)
+    lam=len(keys)/(1<<lp)
+    pb=np.bincount(page*2048+bucket,minlength=(1<<lp)*2048)
+    lb=len(keys)/((1<<lp)*2048)
+    # poisson expectation of P(bucket load>4)
+    from math import exp,factorial
+    p_over=1-sum(exp(-lb)*lb**i/factorial(i) for i in range(5))
+    print(f"{name:12s} k={k} n={len(keys):8d} page mean {lam:7.0f} max {cnt.max():6d} std {cnt.std():6.1f} (poisson {lam**0.5:5.1f}) | bucket load {lb:.2f} frac>4 {np.mean(pb>4):.4f} (poisson {p_over:.4f}) max {pb.max()}")
+rng=np.random.default_rng(1)
+stats(canon(rng.integers(0,4,size=3_000_000),21),"random",21)
+unit=rng.integers(0,4,size=7); g2=np.tile(unit,300000); mut=rng.random(len(g2))<0.02; g2[mut]=rng.integers(0,4,size=mut.sum())
+stats(canon(g2,21),"tandem7",21)
+stats(canon(rng.choice(4,size=2_000_000,p=[0.45,0.05,0.05,0.45]),21),"AT-rich",21)
+stats(np.arange(3_000_000,dtype=np.uint64)*np.uint64(4),"sequential",21)
+stats(canon(rng.integers(0,4,size=2_000_000),31),"random",31)
+stats(np.arange(3_000_000,dtype=np.uint64)*np.uint64(4),"sequential",31)
+stats(canon(rng.integers(0,4,size=2_000_000),13),"random",13,lp=8)
+stats(np.arange(1<<18,dtype=np.uint64),"all k=9",9,lp=2)
