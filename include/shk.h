@@ -191,6 +191,15 @@ int shk_lookup(shk_ctx *ctx, const uint64_t *kmers, uint32_t *counts, uint64_t n
 int shk_find_oligos(shk_ctx *ctx, const uint64_t *oligos, uint32_t n_oligos, uint32_t oligo_len,
                     uint32_t min_count, uint64_t *kmers, uint32_t *counts, uint64_t cap, uint64_t *n_out);
 
+/* PrimerReadFilter::matches over a batch (src/pcr/read_filter.rs:24-55), the read selection in front
+ * of sPCR's read threading: out_matches[i] = 1 when read i has no byte outside ACGTN (otherwise
+ * kmers_from_ascii fails and the reference returns false for the read) and at least one of its
+ * canonical k-mers (k of the context) is among primer_kmers[] (canonical 2-bit k-mers, the union
+ * of the forward and reverse primer tables), else 0.  Host buffers; the context's table is not
+ * touched. */
+int shk_filter_reads(shk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
+                     const uint64_t *primer_kmers, uint64_t n_kmers, uint8_t *out_matches);
+
 /* ---- multi-GPU hooks (device pointers; exchanged by the caller over RCCL) ---- */
 
 /* Table geometry needed to shard by owner: n_pages (power of two),

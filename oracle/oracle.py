@@ -128,6 +128,8 @@ def lib():
     L.orc_counts_export.restype = C.c_size_t
     L.orc_find_oligos.argtypes = [C.c_void_p, u64p, C.c_size_t, C.c_int, C.c_uint32, u64p, u32p]
     L.orc_find_oligos.restype = C.c_size_t
+    L.orc_filter_matches.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.orc_filter_matches.restype = C.c_int
 
     L.orc_histo_new.argtypes = [C.c_uint64]
     L.orc_histo_new.restype = C.c_void_p
@@ -337,6 +339,11 @@ class KmerCounts:
         keys, cnts = keys[:m], cnts[:m]
         o = np.argsort(keys, kind="stable")
         return keys[o], cnts[o]
+
+    def filter_matches(self, seq) -> bool:
+        """PrimerReadFilter::matches (pcr/read_filter.rs:43-49) with this table as the primer set."""
+        b = _b(seq)
+        return bool(lib().orc_filter_matches(self._p, b, len(b)))
 
     def export(self):
         """iter(): (keys u64[n], counts u32[n]) sorted by key for comparison."""

@@ -1055,3 +1055,20 @@ size_t orc_find_oligos(const orc_counts *c, const uint64_t *oligos, size_t n_oli
   }
   return n;
 }
+
+/* PrimerReadFilter::matches, src/pcr/read_filter.rs:43-49: kmers_from_ascii must succeed (an
+ * invalid byte anywhere in the read → false) and some k-mer must be in the primer set (the union
+ * of two KmerCounts, :24-41; here: any orc_counts holding the canonical primer k-mers). */
+int orc_filter_matches(const orc_counts *primers, const uint8_t *seq, size_t len) {
+  const int k = primers->k;
+  if (len == 0) return 0;
+  uint64_t *km = (uint64_t *)malloc(sizeof(uint64_t) * (len ? len : 1));
+  if (!km) return 0;
+  size_t n = 0;
+  uint8_t bad = 0;
+  int hit = 0;
+  if (orc_kmers_from_ascii(seq, len, k, km, &n, &bad) == ORC_OK)
+    for (size_t i = 0; i < n && !hit; i++) hit = orc_counts_contains(primers, km[i]);
+  free(km);
+  return hit;
+}

@@ -88,6 +88,9 @@ size_t orc_counts_export(const orc_counts *c, uint64_t *keys, uint32_t *counts);
 size_t orc_find_oligos(const orc_counts *c, const uint64_t *oligos, size_t n_oligos, int oligo_len,
                        uint32_t min_count, uint64_t *out_kmers, uint32_t *out_counts);
 
+/* PrimerReadFilter::matches, src/pcr/read_filter.rs:43-49 (primers: the union table, :24-41) */
+int orc_filter_matches(const orc_counts *primers, const uint8_t *seq, size_t len);
+
 /* ---- histogram.rs: Histogram ----------------------------------------- */
 
 typedef struct orc_histo orc_histo;

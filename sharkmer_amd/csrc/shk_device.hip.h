@@ -976,6 +976,48 @@ __global__ void __launch_bounds__(WG) k_find_oligos(TableRef tb, uint64_t slot0,
 }
 
 // ==========================================================================================
+// K_FILTER: PrimerReadFilter::matches (src/pcr/read_filter.rs:43-49) for a batch of reads: a read
+// matches when kmers_from_ascii accepts it (no byte outside ACGTN — otherwise the reference
+// returns false for the whole read) and at least one of its canonical k-mers is in the set.
+// One thread per read (reads are a few hundred bases; this is the step before sPCR's read
+// threading, not the counting hot path); the set is a small open-addressing table of mixed keys.
+// ==========================================================================================
+__global__ void __launch_bounds__(WG) k_filter_reads(const uint8_t *__restrict__ bases,
+                                                     const uint64_t *__restrict__ offsets, uint64_t n_seqs,
+                                                     int k, const uint64_t *__restrict__ set_keys,
+                                                     uint32_t set_mask, uint8_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  if (i >= n_seqs) return;
+  const uint64_t mask = (1ull << (2 * k)) - 1;
+  uint64_t fwd = 0, rev = 0;
+  int n_valid = 0;
+  bool hit = false, ok = true;
+  for (uint64_t p = offsets[i], e = offsets[i + 1]; p < e; ++p) {
+    const uint32_t c = bases[p];
+    if (c == 'N') {  // encoding.rs:346-352
+      n_valid = 0;
+      continue;
+    }
+    if (!byte_is_acgtn(c)) {  // encoding.rs:353-356 → Err → matches() is false
+      ok = false;
+      break;
+    }
+    const uint64_t b2 = ((c >> 1) ^ (c >> 2)) & 3u;
+    fwd = ((fwd << 2) | b2) & mask;
+    rev = (rev >> 2) | ((3 - b2) << (2 * (k - 1)));
+    if (++n_valid >= k && !hit) {
+      const uint64_t key = fwd < rev ? fwd : rev;
+      for (uint32_t s = (uint32_t)mix_key(key, 2 * k) & set_mask;; s = (s + 1) & set_mask) {
+        const uint64_t cur = set_keys[s];
+        if (cur == key) hit = true;
+        if (cur == key || cur == EMPTY) break;
+      }
+    }
+  }
+  out[i] = ok && hit;
+}
+
+// ==========================================================================================
 // K_MERGE: KmerCounts::extend across devices (counting.rs:157-166): fold a peer's page range
 // (same geometry) into this table, lane by lane, saturating.
 // ==========================================================================================

@@ -1126,6 +1126,54 @@ int shk_find_oligos(shk_ctx *c, const uint64_t *oligos, uint32_t n_oligos, uint3
   return SHK_OK;
 }
 
+int shk_filter_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
+                     const uint64_t *primer_kmers, uint64_t n_kmers, uint8_t *out_matches) {
+  if (!c || (n_seqs && (!offsets || !out_matches))) return SHK_ERR_BAD_ARG;
+  if (n_seqs == 0) return SHK_OK;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  const uint32_t k = c->cfg.k;
+  // the union of the primer k-mers (read_filter.rs:24-41) as an open-addressing set at load ≤ 1/2
+  uint64_t cap = 16;
+  while (cap < 2 * n_kmers) cap <<= 1;
+  if (cap > (1ull << 31)) return fail(c, SHK_ERR_BAD_ARG, "primer k-mer set too large");
+  std::vector<uint64_t> set(cap, ~0ull);
+  for (uint64_t j = 0; j < n_kmers; ++j) {
+    const uint64_t key = primer_kmers[j];
+    if (2 * k < 64 && (key >> (2 * k)) != 0)
+      return fail(c, SHK_ERR_BAD_ARG, "primer k-mer %llu does not fit %u bases", (unsigned long long)key, k);
+    for (uint64_t sl = mix_key(key, 2 * k) & (cap - 1);; sl = (sl + 1) & (cap - 1)) {
+      if (set[sl] == key) break;
+      if (set[sl] == ~0ull) {
+        set[sl] = key;
+        break;
+      }
+    }
+  }
+  const uint64_t n_bases = offsets[n_seqs];
+  HIPC(c, c->in_bases.ensure(n_bases + 16));
+  HIPC(c, c->in_offsets.ensure((n_seqs + 2) * 8));
+  HIPC(c, c->misc.ensure(cap * 8 + n_seqs));
+  uint64_t *dset = (uint64_t *)c->misc.p;
+  uint8_t *dout = (uint8_t *)c->misc.p + cap * 8;
+  {
+    int rcs = settle(c);  // the staging buffers may still feed a counting launch
+    if (rcs != SHK_OK) return rcs;
+  }
+  HIPC(c, hipStreamSynchronize(c->stream));
+  if (n_bases) HIPC(c, hipMemcpyAsync(c->in_bases.p, bases, n_bases, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(c->in_offsets.p, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(dset, set.data(), cap * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedTimer t(c, SHK_K_LOOKUP);
+    hipLaunchKernelGGL(k_filter_reads, dim3((uint32_t)((n_seqs + WG - 1) / WG)), dim3(WG), 0, c->stream,
+                       (const uint8_t *)c->in_bases.p, (const uint64_t *)c->in_offsets.p, n_seqs, (int)k,
+                       (const uint64_t *)dset, (uint32_t)(cap - 1), dout);
+  }
+  HIPC(c, hipMemcpyAsync(out_matches, dout, n_seqs, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));  // (also keeps `set` alive until its copy ran)
+  return SHK_OK;
+}
+
 int shk_table_geometry(shk_ctx *c, uint64_t *n_pages, uint32_t *page_slots, uint32_t *n_lanes) {
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));

@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "shk_abi_version", "shk_create", "shk_destroy", "shk_reset", "shk_last_error", "shk_ingest_batch",
     "shk_ingest_reads", "shk_set_read_index", "shk_ingest_reads_device", "shk_insert_counts", "shk_sync", "shk_finalize",
     "shk_histograms", "shk_get_counters", "shk_get_timings", "shk_reset_timings",
-    "shk_export_table", "shk_lookup", "shk_find_oligos", "shk_table_geometry", "shk_table_reserve_pages",
+    "shk_export_table", "shk_lookup", "shk_find_oligos", "shk_filter_reads", "shk_table_geometry", "shk_table_reserve_pages",
     "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
     "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_synth_reads_device",
     "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_stats",
@@ -157,6 +157,7 @@ def load_library():
     L.shk_export_table.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.shk_lookup.argtypes = [vp, vp, vp, u64, C.c_int]
     L.shk_find_oligos.argtypes = [vp, vp, u32, u32, u32, vp, vp, u64, C.POINTER(u64)]
+    L.shk_filter_reads.argtypes = [vp, vp, vp, u64, vp, u64, vp]
     L.shk_table_geometry.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
     L.shk_table_reserve_pages.argtypes = [vp, u64]
     L.shk_table_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -344,6 +345,17 @@ class KmerEngine:
                                                 min_count, keys.ctypes.data, cnts.ctypes.data, cap, C.byref(n)))
         o = np.argsort(keys, kind="stable")
         return keys[o], cnts[o]
+
+    def filter_reads(self, bases: np.ndarray, offsets: np.ndarray, primer_kmers) -> np.ndarray:
+        """PrimerReadFilter::matches per read (pcr/read_filter.rs:43-55) → bool array."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        pk = np.ascontiguousarray(np.atleast_1d(primer_kmers), dtype=np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        self._check(self._L.shk_filter_reads(self._h, bases.ctypes.data, offsets.ctypes.data, n,
+                                             pk.ctypes.data, len(pk), out.ctypes.data))
+        return out[:n].astype(bool)
 
     # -- multi-GPU hooks ---------------------------------------------------------------
     def table_geometry(self):

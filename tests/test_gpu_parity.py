@@ -505,3 +505,31 @@ def test_rec32_matches_8byte_records(orc, monkeypatch):
             out.append((eng.histograms(), eng.export_table()))
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
+
+
+# ---- PrimerReadFilter::matches over a batch --------------------------------------------
+
+@pytest.mark.parametrize("k", [5, 21, 31])
+def test_filter_reads_matches_reference_semantics(orc, k):
+    """pcr/read_filter.rs:43-55: per read, false on any byte outside ACGTN, else any k-mer in the set."""
+    spec = sa.SynthSpec(genome_len=50_000, sub_per_64k=200, n_per_64k=100)
+    bases, offsets = sa.synth_reads(spec, 0, 3_000)
+    bases = bases.copy()
+    rng = np.random.default_rng(k)
+    for r in rng.choice(3_000, size=40, replace=False):      # a few reads with an invalid byte
+        bases[int(offsets[r]) + int(rng.integers(0, 150))] = ord("X")
+    seqs = [bytes(bases[int(offsets[i]):int(offsets[i + 1])]) for i in range(3_000)]
+    seqs += [b"", b"ACG", b"N" * 40]                          # empty, shorter than k, all N
+    bases2, offsets2 = pack(seqs)
+    primers = orc.KmerCounts(k)
+    for r in rng.choice(3_000, size=25, replace=False):      # primer set: k-mers of a few (valid) reads
+        if b"X" not in seqs[r]:
+            primers.ingest_seq(seqs[r][20:20 + k + 6])
+    pk, _ = primers.export()
+    want = np.array([primers.filter_matches(sq) for sq in seqs])
+    with sa.KmerEngine(k, 1, 10) as eng:
+        got = eng.filter_reads(bases2, offsets2, pk)
+        none = eng.filter_reads(bases2, offsets2, np.zeros(0, dtype=np.uint64))
+    assert want.sum() > 25 and (~want).sum() >= 40  # both classes present (k=5 matches nearly everywhere)
+    assert np.array_equal(got, want)
+    assert not none.any()                                     # test_empty_filter, read_filter.rs:62-67

@@ -269,3 +269,22 @@ def test_find_oligos_in_kmers(orc, seq, k, oligo, min_count, expected):
         assert got == expected
     for x, c in zip(kmers, counts):
         assert kc.get_canonical_count(int(x)) == int(c) >= min_count
+
+
+# ---- pcr/read_filter.rs:58-68 (+ the semantics of matches(), :43-49) ---------------------------------------
+
+def test_filter_empty_set(orc):
+    """test_empty_filter: no primer k-mers → nothing matches."""
+    assert not orc.KmerCounts(3).filter_matches("ACGTACGT")
+
+
+def test_filter_matches_semantics(orc):
+    primers = orc.KmerCounts(5)
+    primers.ingest_seq("ACGTAC")                       # ACGTA, CGTAC (canonical forms)
+    assert primers.filter_matches("TTTTACGTACTTTT")    # contains a primer k-mer
+    assert primers.filter_matches("AAAAGTACGTAAAA")    # … its reverse complement
+    assert not primers.filter_matches("TTTTTTTTTTTT")
+    assert not primers.filter_matches("ACGT")          # shorter than k
+    assert not primers.filter_matches("ACGNTAC")       # N splits the only candidate window
+    assert not primers.filter_matches("ACGTACXTTTT")   # invalid byte: kmers_from_ascii fails → false
+    assert not primers.filter_matches("")
