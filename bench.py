@@ -70,7 +70,7 @@ def main():
     # merged histogram is that of N × 50× coverage
     genome = args.genome
     spec = sa.SynthSpec(genome_len=genome, read_len=L)
-    flags = sa.FLAG_TIMING
+    flags = 0 if os.environ.get("SHK_BENCH_NO_TIMING") else sa.FLAG_TIMING  # (experiment hook)
     if args.path == "direct":
         flags |= sa.FLAG_FORCE_DIRECT
     elif args.path == "paged":

@@ -55,6 +55,7 @@ struct DevBuf {  // grow-only device scratch
 struct TimedEvent {
   int kid;
   hipEvent_t a, b;
+  bool a_shared;  // `a` is the previous timer's `b` (back-to-back launches share the event)
 };
 
 }  // namespace
@@ -98,6 +99,8 @@ struct shk_ctx {
   // timing
   std::vector<TimedEvent> events;
   std::vector<hipEvent_t> event_pool;
+  hipEvent_t chain_ev = nullptr;  // end event of the last timer (see ScopedTimer)
+  bool chain_from_mark = false;   // nothing was enqueued between k_mark_starts' timer and the first scatter
   shk_timings timings{};
 };
 
@@ -125,11 +128,16 @@ int fail(shk_ctx *c, int code, const char *fmt, ...) {
                   #expr);                                                                   \
   } while (0)
 
+// HIP-event timer around one launch.  Back-to-back launches can CHAIN: a timer constructed with
+// chain = true starts from the end event of the previous timer (c->chain_ev, valid only if nothing
+// else has been enqueued on the stream since) instead of recording an event of its own — every
+// event record costs the stream a few µs, and the bench times four kernels per step.
 struct ScopedTimer {
   shk_ctx *c;
   int kid;
   hipEvent_t a = nullptr, b = nullptr;
-  ScopedTimer(shk_ctx *c_, int kid_) : c(c_), kid(kid_) {
+  bool shared = false;
+  ScopedTimer(shk_ctx *c_, int kid_, bool chain = false) : c(c_), kid(kid_) {
     if (!(c->cfg.flags & SHK_FLAG_TIMING)) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -141,18 +149,25 @@ struct ScopedTimer {
       }
       return e;
     };
-    a = get();
+    if (chain && c->chain_ev) {
+      a = c->chain_ev;
+      shared = true;
+    } else {
+      a = get();
+      (void)hipEventRecord(a, c->stream);
+    }
     b = get();
-    (void)hipEventRecord(a, c->stream);
   }
   ~ScopedTimer() {
     if (!a) return;
     (void)hipEventRecord(b, c->stream);
-    c->events.push_back({kid, a, b});
+    c->events.push_back({kid, a, b, shared});
+    c->chain_ev = b;  // whoever enqueues anything else before the next timer must not chain
   }
 };
 
 void resolve_timings(shk_ctx *c) {
+  c->chain_ev = nullptr;  // its event goes back to the pool below
   for (auto &ev : c->events) {
     (void)hipEventSynchronize(ev.b);
     float ms = 0;
@@ -160,7 +175,7 @@ void resolve_timings(shk_ctx *c) {
       c->timings.ms[ev.kid] += ms;
       c->timings.launches[ev.kid] += 1;
     }
-    c->event_pool.push_back(ev.a);
+    if (!ev.a_shared) c->event_pool.push_back(ev.a);
     c->event_pool.push_back(ev.b);
   }
   c->events.clear();
@@ -301,6 +316,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     if (rc0 != SHK_OK) return rc0;
   }
   c->finalized = false;
+  c->chain_from_mark = false;
   const uint64_t g0 = c->n_reads_read;
   const uint32_t NL = c->n_lanes;
   // host-side bookkeeping that depends only on read indices
@@ -355,6 +371,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
       hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(TB_WG), 0, c->stream, d_offsets, n_seqs, g0,
                          NL, n_blocks, (TileDesc *)c->tiles.p, c->d_stats);
   }
+  c->chain_from_mark = true;  // (reset by the first scatter; nothing is enqueued in between)
   BatchRef b{};
   b.bases = d_bases;
   b.startbits = (const uint32_t *)c->startbits.p;
@@ -490,7 +507,8 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     if (!(prezeroed && lane == lane_lo))  // the first pass's cursors were cleared by k_mark_starts
       HIPC(c, hipMemsetAsync(cursor1, 0, (size_t)pg.cursor_words() * 4, c->stream));
     {
-      ScopedTimer t(c, SHK_K_SCATTER);
+      ScopedTimer t(c, SHK_K_SCATTER, /*chain=*/prezeroed && lane == lane_lo && c->chain_from_mark);
+      c->chain_from_mark = false;
       if (rec32 && lds32) {
         static bool attr_set = false;  // > 64 KiB of dynamic LDS has to be asked for
         if (!attr_set) {
@@ -509,7 +527,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
     }
     if (two_level) {
-      ScopedTimer t(c, SHK_K_PSCAN);  // timer slot reused: the level-2 re-scatter
+      ScopedTimer t(c, SHK_K_PSCAN, /*chain=*/true);  // timer slot reused: the level-2 re-scatter
       if (rec32)
         hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs32, c->stream,
                            (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
@@ -521,7 +539,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
                            log_sub, 2 * c->cfg.k, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp);
     }
     {
-      ScopedTimer t(c, SHK_K_PAGES);
+      ScopedTimer t(c, SHK_K_PAGES, /*chain=*/true);
       if (rec32)
         hipLaunchKernelGGL(k_pages32, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
                            (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
