@@ -1018,6 +1018,68 @@ __global__ void __launch_bounds__(WG) k_filter_reads(const uint8_t *__restrict__
 }
 
 // ==========================================================================================
+// K_OWNER_COUNTS / K_COMPACT_OWNERS: the sender side of the multi-GPU merge.  Owner o of W owns the
+// slots [o·spo, (o+1)·spo) (a contiguous page range).  Instead of shipping its range as it lies
+// in the table — EMPTY slots included, ≥ half of it — a rank ships only the occupied (key, counts)
+// entries: first the per-owner entry counts, then the entries, owner after owner.  The grid is
+// W × blocks_per_owner; a block owns a fixed slice of one owner's range, counts it, reserves its
+// share of the owner's segment with ONE atomic, and writes its entries in slot order.
+// ==========================================================================================
+constexpr int OWNER_BLOCKS = 64;  // blocks per owner
+__global__ void __launch_bounds__(WG) k_owner_counts(TableRef tb, uint64_t spo,
+                                                     unsigned long long *__restrict__ counts) {
+  __shared__ uint32_t red[WG / 64];
+  const uint32_t o = blockIdx.x / OWNER_BLOCKS, j = blockIdx.x % OWNER_BLOCKS;
+  const uint64_t per = (spo + OWNER_BLOCKS - 1) / OWNER_BLOCKS;
+  const uint64_t s0 = (uint64_t)o * spo + (uint64_t)j * per;
+  const uint64_t s1 = s0 + per < (uint64_t)(o + 1) * spo ? s0 + per : (uint64_t)(o + 1) * spo;
+  uint32_t n = 0;
+  for (uint64_t s = s0 + threadIdx.x; s < s1; s += WG) n += tb.keys[s] != EMPTY;
+  const uint32_t tot = wg_sum<WG>(n, red);
+  if (threadIdx.x == 0 && tot) atomicAdd(&counts[o], (unsigned long long)tot);
+}
+
+__global__ void __launch_bounds__(WG) k_compact_owners(TableRef tb, uint64_t spo,
+                                                       const unsigned long long *__restrict__ seg_offset,
+                                                       unsigned long long *__restrict__ seg_cursor,
+                                                       uint64_t *__restrict__ out_keys,
+                                                       uint32_t *__restrict__ out_vals, uint64_t lane_stride) {
+  __shared__ uint32_t red[WG / 64];
+  __shared__ uint32_t wbase[WG / 64];
+  __shared__ unsigned long long blk_base;
+  const uint32_t o = blockIdx.x / OWNER_BLOCKS, j = blockIdx.x % OWNER_BLOCKS;
+  const uint64_t per = (spo + OWNER_BLOCKS - 1) / OWNER_BLOCKS;
+  const uint64_t s0 = (uint64_t)o * spo + (uint64_t)j * per;
+  const uint64_t s1 = s0 + per < (uint64_t)(o + 1) * spo ? s0 + per : (uint64_t)(o + 1) * spo;
+  uint32_t n = 0;
+  for (uint64_t s = s0 + threadIdx.x; s < s1; s += WG) n += tb.keys[s] != EMPTY;
+  const uint32_t tot = wg_sum<WG>(n, red);  // valid in thread 0
+  if (threadIdx.x == 0) blk_base = seg_offset[o] + (tot ? atomicAdd(&seg_cursor[o], (unsigned long long)tot) : 0ull);
+  __syncthreads();
+  unsigned long long at = blk_base;
+  const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+  for (uint64_t sb = s0; sb < s1; sb += WG) {  // second pass: the slice is L2-resident by now
+    const uint64_t s = sb + threadIdx.x;
+    const uint64_t key = s < s1 ? tb.keys[s] : EMPTY;
+    const unsigned long long mm = __ballot(key != EMPTY);
+    if (lane_id == 0) wbase[wave] = (uint32_t)__popcll(mm);
+    __syncthreads();
+    uint32_t off = 0, chunk = 0;
+    for (uint32_t w = 0; w < WG / 64; ++w) {
+      if (w < wave) off += wbase[w];
+      chunk += wbase[w];
+    }
+    if (key != EMPTY) {
+      const unsigned long long i = at + off + __popcll(mm & ((1ull << lane_id) - 1ull));
+      out_keys[i] = key;
+      for (uint32_t l = 0; l < tb.n_lanes; ++l) out_vals[(uint64_t)l * lane_stride + i] = tb.vals[(uint64_t)l * tb.cap + s];
+    }
+    at += chunk;
+    __syncthreads();
+  }
+}
+
+// ==========================================================================================
 // K_MERGE: KmerCounts::extend across devices (counting.rs:157-166): fold a peer's page range
 // (same geometry) into this table, lane by lane, saturating.
 // ==========================================================================================

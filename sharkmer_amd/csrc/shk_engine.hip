@@ -1257,6 +1257,66 @@ int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, co
   return drain_spill(c, n_slots * c->n_lanes);
 }
 
+int shk_owner_counts(shk_ctx *c, uint32_t n_owners, uint64_t *counts) {
+  if (!c || !counts || n_owners == 0) return SHK_ERR_BAD_ARG;
+  const uint64_t n_pages = 1ull << c->tb.log_pages;
+  if (n_pages % n_owners) return fail(c, SHK_ERR_BAD_ARG, "%llu pages do not split over %u owners",
+                                      (unsigned long long)n_pages, n_owners);
+  HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
+  HIPC(c, c->misc.ensure((size_t)n_owners * 16));
+  unsigned long long *dc = (unsigned long long *)c->misc.p;
+  HIPC(c, hipMemsetAsync(dc, 0, (size_t)n_owners * 8, c->stream));
+  hipLaunchKernelGGL(k_owner_counts, dim3(n_owners * OWNER_BLOCKS), dim3(WG), 0, c->stream, c->tb,
+                     c->tb.cap / n_owners, dc);
+  HIPC(c, hipMemcpyAsync(counts, dc, (size_t)n_owners * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return SHK_OK;
+}
+
+int shk_compact_owners(shk_ctx *c, uint32_t n_owners, const uint64_t *seg_offsets, void *d_keys, void *d_vals,
+                       uint64_t vals_lane_stride) {
+  if (!c || !seg_offsets || n_owners == 0) return SHK_ERR_BAD_ARG;
+  const uint64_t n_pages = 1ull << c->tb.log_pages;
+  if (n_pages % n_owners) return fail(c, SHK_ERR_BAD_ARG, "%llu pages do not split over %u owners",
+                                      (unsigned long long)n_pages, n_owners);
+  HIPC(c, hipSetDevice(c->cfg.device));
+  HIPC(c, c->misc.ensure((size_t)n_owners * 16));
+  unsigned long long *doff = (unsigned long long *)c->misc.p, *dcur = doff + n_owners;
+  HIPC(c, hipMemcpyAsync(doff, seg_offsets, (size_t)n_owners * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemsetAsync(dcur, 0, (size_t)n_owners * 8, c->stream));
+  hipLaunchKernelGGL(k_compact_owners, dim3(n_owners * OWNER_BLOCKS), dim3(WG), 0, c->stream, c->tb,
+                     c->tb.cap / n_owners, (const unsigned long long *)doff, dcur, (uint64_t *)d_keys,
+                     (uint32_t *)d_vals, vals_lane_stride);
+  HIPC(c, hipStreamSynchronize(c->stream));  // the caller hands the buffers to a collective next
+  return SHK_OK;
+}
+
+int shk_merge_entries(shk_ctx *c, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (n == 0) return SHK_OK;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
+  c->finalized = false;
+  HIPC(c, c->spillA.ensure(n * c->n_lanes * 16));  // worst case every entry spills on every lane
+  SpillRef sp = spill_ref(c->spillA, n * c->n_lanes);
+  HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  {
+    ScopedTimer t(c, SHK_K_MERGE);
+    hipLaunchKernelGGL(k_merge, dim3(grid_for(n, WG, 8192)), dim3(WG), 0, c->stream, c->tb, n, vals_lane_stride,
+                       (const uint64_t *)d_keys, (const uint32_t *)d_vals, c->d_stats, sp);
+  }
+  int rc = read_stats(c);
+  if (rc != SHK_OK) return rc;
+  return drain_spill(c, n * c->n_lanes);
+}
+
 int shk_set_owned_pages(shk_ctx *c, uint64_t p0, uint64_t p1) {
   if (!c) return SHK_ERR_BAD_ARG;
   if (p1 < p0 || p1 > (1ull << c->tb.log_pages)) return fail(c, SHK_ERR_BAD_ARG, "bad page range");

@@ -7,20 +7,25 @@ What it reproduces: the reference merges per-chunk tables into one with
 merged table (io.rs:1020-1028).  Here the "tables to merge" are the per-rank tables:
 
   1. all ranks agree on a table geometry (all_reduce MAX of the page count; smaller tables grow)
-  2. rank r OWNS pages [r·P/W, (r+1)·P/W): a page is a contiguous slice of every table array,
-     so "send every peer its range" is ONE all_to_all_single per array, straight out of the
-     table memory — the fully connected xGMI mesh carries all W-1 transfers of a rank at once
-  3. every rank folds the W-1 received slices into its own slice (saturating per lane)
+  2. rank r OWNS pages [r·P/W, (r+1)·P/W).  Every rank compacts the OCCUPIED entries of each
+     owner's range (at load ≤ 1/2 the EMPTY slots would be most of the bytes), the per-owner
+     entry counts are exchanged, and then "send every peer its entries" is ONE all_to_all_single
+     per array with those split sizes — the fully connected xGMI mesh carries all W-1 transfers
+     of a rank at once.  (SHK_DIST_DENSE=1: ship the ranges as they lie in the table instead.)
+  3. every rank folds the received entries into its own range (saturating per lane)
   4. histogram scan restricted to the owned slice; bins are additive across disjoint key
      shards, so a dense all_reduce(SUM) of the (chunks × (histo_max+2)) u64 histogram and of
      the scalar totals finishes the job
 
-The engine object is duck-typed (`table_geometry, reserve_pages, table_tensors,
-merge_page_tensors, set_owned_pages, finalize, histograms, counters`): the product passes
+The engine object is duck-typed (`table_geometry, reserve_pages, owner_counts,
+compact_owner_tensors, merge_entry_tensors, table_tensors, merge_page_tensors, set_owned_pages,
+finalize, histograms, counters`): the product passes
 `KmerEngine` (HIP); the CPU tests pass a numpy stand-in to exercise the collective logic under
 gloo with world_size 2.
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import torch
@@ -45,20 +50,70 @@ class DistCounter:
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.device = device
+        self.dense = bool(int(os.environ.get("SHK_DIST_DENSE", "0")))
 
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
         return t if self.device is None else t.to(f"cuda:{self.device}")
 
-    def exchange_and_merge(self):
-        """Steps 1-3.  After it, this rank's owned page range holds the merged counts."""
+    def _agree_on_pages(self):
+        """Step 1: every rank ends up with the same page count P, a multiple of the world size."""
         dist, W = self.dist, self.world
-        n_pages, page_slots, n_lanes = self.eng.table_geometry()
+        n_pages, _, _ = self.eng.table_geometry()
         t = self._dev(torch.tensor([max(n_pages, W)], dtype=torch.int64))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         P = int(t.item())
         self.eng.reserve_pages(P)
         n_pages, page_slots, n_lanes = self.eng.table_geometry()
         assert n_pages == P and P % W == 0, (n_pages, P, W)
+        return P, page_slots, n_lanes
+
+    def _own(self, P_before):
+        """Owned page range after the merges (a merge that had to grow the table splits every page
+        into consecutive child pages, so the range scales with the page count)."""
+        P_now, _, _ = self.eng.table_geometry()
+        f = P_now // P_before
+        per = P_before // self.world
+        p0, p1 = self.rank * per * f, (self.rank + 1) * per * f
+        self.eng.set_owned_pages(p0, p1)
+        return p0, p1
+
+    def exchange_and_merge(self):
+        """Steps 1-3.  After it, this rank's owned page range holds the merged counts.
+        Only the occupied (key, counts) entries cross the links: per-owner entry counts first
+        (one small all_to_all), then one all_to_all with those split sizes per array."""
+        if self.dense:
+            return self.exchange_and_merge_dense()
+        dist, W = self.dist, self.world
+        P, _, n_lanes = self._agree_on_pages()
+        counts = np.asarray(self.eng.owner_counts(W), dtype=np.int64)   # what I hold of every owner's range
+        send_n = self._dev(torch.from_numpy(counts.copy()))
+        recv_n = torch.empty_like(send_n)
+        dist.all_to_all_single(recv_n, send_n)
+        recv = [int(x) for x in recv_n.cpu().tolist()]                  # what every peer holds of MY range
+        send = [int(x) for x in counts.tolist()]
+        keys, vals = self.eng.compact_owner_tensors(counts)             # [sum(send)], [L, sum(send)]
+        n_recv = sum(recv)
+        rk = keys.new_empty(n_recv)
+        rv = vals.new_empty((n_lanes, n_recv))
+        dist.all_to_all_single(rk, keys, output_split_sizes=recv, input_split_sizes=send)
+        for l in range(n_lanes):
+            dist.all_to_all_single(rv[l], vals[l].contiguous(), output_split_sizes=recv, input_split_sizes=send)
+        if rk.is_cuda:
+            # RCCL enqueues on torch's stream; the merge below runs on the engine's own HIP
+            # stream, so the received entries must have landed before it is launched
+            torch.cuda.synchronize()
+        # my own segment (what I sent to myself) is already in my table: merge what lies around it
+        a = sum(recv[:self.rank])
+        b = a + recv[self.rank]
+        self.eng.merge_entry_tensors(rk[:a], rv[:, :a])
+        self.eng.merge_entry_tensors(rk[b:], rv[:, b:])
+        return self._own(P)
+
+    def exchange_and_merge_dense(self):
+        """The same with the owner ranges shipped as they lie in the table (EMPTY slots included):
+        no compaction pass, one all_to_all per array with equal splits."""
+        dist, W = self.dist, self.world
+        P, page_slots, n_lanes = self._agree_on_pages()
         per = P // W                      # pages per owner
         n = per * page_slots              # slots per owner slice
         keys, vals = self.eng.table_tensors()          # [P*S], [L, P*S]
@@ -68,16 +123,13 @@ class DistCounter:
         for l in range(n_lanes):
             dist.all_to_all_single(rv[l], vals[l])
         if rk.is_cuda:
-            # RCCL enqueues on torch's stream; the merge below runs on the engine's own HIP
-            # stream, so the received slices must have landed before it is launched
             torch.cuda.synchronize()
         p0, p1 = self.rank * per, (self.rank + 1) * per
         for s in range(W):
             if s == self.rank:
                 continue
             self.eng.merge_page_tensors(p0, p1, rk[s * n:(s + 1) * n], rv[:, s * n:(s + 1) * n])
-        self.eng.set_owned_pages(p0, p1)
-        return p0, p1
+        return self._own(P)
 
     def finalize_histograms(self):
         """Steps 1-4.  Returns the (chunks, histo_max+2) uint64 histogram of the union of all

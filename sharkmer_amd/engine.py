@@ -89,7 +89,8 @@ ABI_SYMBOLS = [
     "shk_abi_version", "shk_create", "shk_destroy", "shk_reset", "shk_last_error", "shk_ingest_batch",
     "shk_ingest_reads", "shk_set_read_index", "shk_ingest_reads_device", "shk_insert_counts", "shk_sync", "shk_finalize",
     "shk_histograms", "shk_get_counters", "shk_get_timings", "shk_reset_timings",
-    "shk_export_table", "shk_lookup", "shk_find_oligos", "shk_filter_reads", "shk_table_geometry", "shk_table_reserve_pages",
+    "shk_export_table", "shk_lookup", "shk_find_oligos", "shk_filter_reads", "shk_table_geometry", "shk_table_reserve_pages", "shk_owner_counts", "shk_compact_owners",
+    "shk_merge_entries",
     "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
     "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_synth_reads_device",
     "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_stats",
@@ -158,6 +159,9 @@ def load_library():
     L.shk_lookup.argtypes = [vp, vp, vp, u64, C.c_int]
     L.shk_find_oligos.argtypes = [vp, vp, u32, u32, u32, vp, vp, u64, C.POINTER(u64)]
     L.shk_filter_reads.argtypes = [vp, vp, vp, u64, vp, u64, vp]
+    L.shk_owner_counts.argtypes = [vp, u32, vp]
+    L.shk_compact_owners.argtypes = [vp, u32, vp, vp, vp, u64]
+    L.shk_merge_entries.argtypes = [vp, vp, vp, u64, u64]
     L.shk_table_geometry.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
     L.shk_table_reserve_pages.argtypes = [vp, u64]
     L.shk_table_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -405,6 +409,35 @@ class KmerEngine:
 
     def set_owned_pages(self, p0: int, p1: int):
         self._check(self._L.shk_set_owned_pages(self._h, p0, p1))
+
+    def owner_counts(self, n_owners: int) -> np.ndarray:
+        """Occupied slots in each of n_owners equal page ranges."""
+        out = np.zeros(n_owners, dtype=np.uint64)
+        self._check(self._L.shk_owner_counts(self._h, n_owners, out.ctypes.data))
+        return out
+
+    def compact_owner_tensors(self, counts):
+        """The occupied entries, owner after owner: (keys int64[n], vals int32[n_lanes, n]) as new
+        CUDA tensors, n = sum(counts) (counts from owner_counts with the same number of owners)."""
+        import torch
+        counts = np.asarray(counts, dtype=np.uint64)
+        n = int(counts.sum())
+        _, _, n_lanes = self.table_geometry()
+        keys = torch.empty(max(n, 1), dtype=torch.int64, device="cuda")
+        vals = torch.empty((n_lanes, max(n, 1)), dtype=torch.int32, device="cuda")
+        off = np.zeros(len(counts), dtype=np.uint64)
+        off[1:] = np.cumsum(counts)[:-1]
+        self._check(self._L.shk_compact_owners(self._h, len(counts), off.ctypes.data, keys.data_ptr(),
+                                               vals.data_ptr(), vals.stride(0)))
+        return keys[:n], vals[:, :n]
+
+    def merge_entry_tensors(self, keys_t, vals_t):
+        """KmerCounts::extend of received entries (keys_t int64[n], vals_t int32[n_lanes, n], unit stride)."""
+        n = keys_t.numel()
+        if n == 0:
+            return
+        assert keys_t.is_contiguous() and vals_t.stride(-1) == 1
+        self._check(self._L.shk_merge_entries(self._h, keys_t.data_ptr(), vals_t.data_ptr(), n, vals_t.stride(0)))
 
     # -- device memory + synthetic input ---------------------------------------------
     def alloc_device(self, nbytes: int) -> int:

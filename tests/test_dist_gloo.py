@@ -92,6 +92,34 @@ class NumpyPagedEngine:
             v = self.counts.setdefault(key, np.zeros(self.n_lanes, dtype=np.int64))
             v[:] = np.minimum(v + vals[:, i].astype(np.int64), 0xFFFFFFFF)
 
+    def owner_counts(self, n_owners):
+        P = 1 << self.log_pages
+        per = P // n_owners
+        out = np.zeros(n_owners, dtype=np.uint64)
+        for key in self.counts:
+            out[self._page(key) // per] += 1
+        return out
+
+    def compact_owner_tensors(self, counts):
+        P = 1 << self.log_pages
+        per = P // len(counts)
+        order = sorted(self.counts, key=lambda key: (self._page(key) // per, key))
+        assert [sum(1 for key in order if self._page(key) // per == o) for o in range(len(counts))] == \
+            [int(c) for c in counts]
+        keys = np.array(order, dtype=np.uint64).view(np.int64) if order else np.zeros(0, dtype=np.int64)
+        vals = np.zeros((self.n_lanes, len(order)), dtype=np.int32)
+        for i, key in enumerate(order):
+            vals[:, i] = np.array(self.counts[key], dtype=np.uint32).view(np.int32)
+        return torch.from_numpy(keys.copy()), torch.from_numpy(vals)
+
+    def merge_entry_tensors(self, keys_t, vals_t):
+        keys = keys_t.numpy().view(np.uint64)
+        vals = vals_t.numpy().view(np.uint32)
+        for i in range(len(keys)):
+            key = int(keys[i])
+            v = self.counts.setdefault(key, np.zeros(self.n_lanes, dtype=np.int64))
+            v[:] = np.minimum(v + vals[:, i].astype(np.int64), 0xFFFFFFFF)
+
     def set_owned_pages(self, p0, p1):
         self.owned = (p0, p1)
 
@@ -128,8 +156,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, k, chunks, histo_max, n_reads, out_dir):
+def _worker(rank, world, port, k, chunks, histo_max, n_reads, out_dir, dense=False):
     import sys
+    os.environ["SHK_DIST_DENSE"] = "1" if dense else "0"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import sharkmer_amd as sa
@@ -152,12 +181,14 @@ def _worker(rank, world, port, k, chunks, histo_max, n_reads, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,chunks,n_reads", [(21, 1, 2500), (15, 3, 4321), (9, 0, 1800)])
-def test_two_rank_merge_matches_single_oracle(orc, tmp_path, k, chunks, n_reads):
+@pytest.mark.parametrize("k,chunks,n_reads,dense", [(21, 1, 2500, False), (15, 3, 4321, False), (9, 0, 1800, False),
+                                                      (15, 3, 4321, True)])
+def test_two_rank_merge_matches_single_oracle(orc, tmp_path, k, chunks, n_reads, dense):
+    """Compact exchange (occupied entries, uneven all_to_all splits) and the dense one (page ranges)."""
     import sharkmer_amd as sa
     histo_max = 40
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, k, chunks, histo_max, n_reads, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, k, chunks, histo_max, n_reads, str(tmp_path), dense), nprocs=2, join=True)
     spec = sa.SynthSpec(genome_len=3000, sub_per_64k=400, n_per_64k=100)
     bases, offsets = sa.synth_reads(spec, 0, n_reads)
     ref = orc.run_batch(bases, offsets, k, chunks, histo_max)

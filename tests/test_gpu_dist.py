@@ -1,7 +1,7 @@
 """GPU test of the multi-GPU merge path on ONE card: two KmerEngine contexts play two ranks
 and a thread-based stand-in for torch.distributed moves the tensors between them, so the real
-HIP entry points (shk_table_reserve_pages, shk_table_device_ptrs, shk_merge_pages,
-shk_set_owned_pages, owned-range finalize) are checked against the oracle.  The RCCL transport
+HIP entry points (shk_table_reserve_pages, shk_owner_counts, shk_compact_owners, shk_merge_entries,
+shk_table_device_ptrs, shk_merge_pages, shk_set_owned_pages, owned-range finalize) are checked against the oracle.  The RCCL transport
 itself is exercised by bench.py --gpus N on the 8-GPU node."""
 import threading
 
@@ -49,19 +49,30 @@ class ThreadGroup:
         t.copy_(res)
         torch.cuda.synchronize()
 
-    def all_to_all_single(self, out, inp):
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
         torch.cuda.synchronize()
-        self.s.slots[self.rank] = inp
+        W = self.s.world
+        n = inp.numel() // W
+        ins = input_split_sizes if input_split_sizes is not None else [n] * W
+        self.s.slots[self.rank] = (inp, ins)
         self.s.barrier.wait()
-        n = inp.numel() // self.s.world
-        for src in range(self.s.world):
-            out[src * n:(src + 1) * n].copy_(self.s.slots[src][self.rank * n:(self.rank + 1) * n])
+        at = 0
+        for src in range(W):
+            sinp, sins = self.s.slots[src]
+            a = sum(sins[:self.rank])
+            cnt = sins[self.rank]
+            if output_split_sizes is not None:
+                assert output_split_sizes[src] == cnt, (output_split_sizes, sins)
+            out[at:at + cnt].copy_(sinp[a:a + cnt])
+            at += cnt
         torch.cuda.synchronize()
         self.s.barrier.wait()
 
 
+@pytest.mark.parametrize("dense", ["0", "1"])
 @pytest.mark.parametrize("k,chunks,flags", [(21, 1, 0), (21, 3, 0), (31, 2, sa.FLAG_FORCE_DIRECT), (15, 0, 0)])
-def test_two_contexts_merge_like_two_ranks(orc, k, chunks, flags):
+def test_two_contexts_merge_like_two_ranks(orc, monkeypatch, k, chunks, flags, dense):
+    monkeypatch.setenv("SHK_DIST_DENSE", dense)  # "0": occupied entries only; "1": whole page ranges
     world, n_reads, histo_max = 2, 24_500, 300
     spec = sa.SynthSpec(genome_len=40_000, sub_per_64k=328, n_per_64k=66)
     bases, offsets = sa.synth_reads(spec, 0, n_reads)
