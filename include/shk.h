@@ -222,11 +222,12 @@ int shk_merge_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1, const void *d_keys,
  * n_owners contiguous ranges (owner o = pages [o·P/n, (o+1)·P/n)).
  *   shk_owner_counts   : counts[o] = occupied slots of owner o's range
  *   shk_compact_owners : writes owner o's entries to d_keys[seg_offsets[o] ..] (and lane l of their
- *                        counts to d_vals + l·vals_lane_stride + the same index), owner after owner
+ *                        counts to d_vals + l·vals_lane_stride + the same index), owner after owner;
+ *                        skip_owner ≥ 0: that owner's range is left out (a rank keeps its own)
  *   shk_merge_entries  : KmerCounts::extend (counting.rs:157-166) of n received entries */
 int shk_owner_counts(shk_ctx *ctx, uint32_t n_owners, uint64_t *counts);
 int shk_compact_owners(shk_ctx *ctx, uint32_t n_owners, const uint64_t *seg_offsets, void *d_keys, void *d_vals,
-                       uint64_t vals_lane_stride);
+                       uint64_t vals_lane_stride, int32_t skip_owner);
 int shk_merge_entries(shk_ctx *ctx, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride);
 /* Restrict finalize's histogram scan to pages [p0,p1) (owner shard). */
 int shk_set_owned_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1);

@@ -1043,11 +1043,13 @@ __global__ void __launch_bounds__(WG) k_compact_owners(TableRef tb, uint64_t spo
                                                        const unsigned long long *__restrict__ seg_offset,
                                                        unsigned long long *__restrict__ seg_cursor,
                                                        uint64_t *__restrict__ out_keys,
-                                                       uint32_t *__restrict__ out_vals, uint64_t lane_stride) {
+                                                       uint32_t *__restrict__ out_vals, uint64_t lane_stride,
+                                                       uint32_t skip_owner) {
   __shared__ uint32_t red[WG / 64];
   __shared__ uint32_t wbase[WG / 64];
   __shared__ unsigned long long blk_base;
   const uint32_t o = blockIdx.x / OWNER_BLOCKS, j = blockIdx.x % OWNER_BLOCKS;
+  if (o == skip_owner) return;  // (a rank does not ship its own range to itself)
   const uint64_t per = (spo + OWNER_BLOCKS - 1) / OWNER_BLOCKS;
   const uint64_t s0 = (uint64_t)o * spo + (uint64_t)j * per;
   const uint64_t s1 = s0 + per < (uint64_t)(o + 1) * spo ? s0 + per : (uint64_t)(o + 1) * spo;

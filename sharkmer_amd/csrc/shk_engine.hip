@@ -1278,7 +1278,7 @@ int shk_owner_counts(shk_ctx *c, uint32_t n_owners, uint64_t *counts) {
 }
 
 int shk_compact_owners(shk_ctx *c, uint32_t n_owners, const uint64_t *seg_offsets, void *d_keys, void *d_vals,
-                       uint64_t vals_lane_stride) {
+                       uint64_t vals_lane_stride, int32_t skip_owner) {
   if (!c || !seg_offsets || n_owners == 0) return SHK_ERR_BAD_ARG;
   const uint64_t n_pages = 1ull << c->tb.log_pages;
   if (n_pages % n_owners) return fail(c, SHK_ERR_BAD_ARG, "%llu pages do not split over %u owners",
@@ -1290,7 +1290,7 @@ int shk_compact_owners(shk_ctx *c, uint32_t n_owners, const uint64_t *seg_offset
   HIPC(c, hipMemsetAsync(dcur, 0, (size_t)n_owners * 8, c->stream));
   hipLaunchKernelGGL(k_compact_owners, dim3(n_owners * OWNER_BLOCKS), dim3(WG), 0, c->stream, c->tb,
                      c->tb.cap / n_owners, (const unsigned long long *)doff, dcur, (uint64_t *)d_keys,
-                     (uint32_t *)d_vals, vals_lane_stride);
+                     (uint32_t *)d_vals, vals_lane_stride, skip_owner < 0 ? ~0u : (uint32_t)skip_owner);
   HIPC(c, hipStreamSynchronize(c->stream));  // the caller hands the buffers to a collective next
   return SHK_OK;
 }

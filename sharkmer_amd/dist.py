@@ -86,12 +86,13 @@ class DistCounter:
         dist, W = self.dist, self.world
         P, _, n_lanes = self._agree_on_pages()
         counts = np.asarray(self.eng.owner_counts(W), dtype=np.int64)   # what I hold of every owner's range
+        counts[self.rank] = 0                                           # … my own range stays where it is
         send_n = self._dev(torch.from_numpy(counts.copy()))
         recv_n = torch.empty_like(send_n)
         dist.all_to_all_single(recv_n, send_n)
         recv = [int(x) for x in recv_n.cpu().tolist()]                  # what every peer holds of MY range
         send = [int(x) for x in counts.tolist()]
-        keys, vals = self.eng.compact_owner_tensors(counts)             # [sum(send)], [L, sum(send)]
+        keys, vals = self.eng.compact_owner_tensors(counts, self.rank)  # [sum(send)], [L, sum(send)]
         n_recv = sum(recv)
         rk = keys.new_empty(n_recv)
         rv = vals.new_empty((n_lanes, n_recv))
@@ -102,11 +103,7 @@ class DistCounter:
             # RCCL enqueues on torch's stream; the merge below runs on the engine's own HIP
             # stream, so the received entries must have landed before it is launched
             torch.cuda.synchronize()
-        # my own segment (what I sent to myself) is already in my table: merge what lies around it
-        a = sum(recv[:self.rank])
-        b = a + recv[self.rank]
-        self.eng.merge_entry_tensors(rk[:a], rv[:, :a])
-        self.eng.merge_entry_tensors(rk[b:], rv[:, b:])
+        self.eng.merge_entry_tensors(rk, rv)
         return self._own(P)
 
     def exchange_and_merge_dense(self):

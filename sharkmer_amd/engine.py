@@ -160,7 +160,7 @@ def load_library():
     L.shk_find_oligos.argtypes = [vp, vp, u32, u32, u32, vp, vp, u64, C.POINTER(u64)]
     L.shk_filter_reads.argtypes = [vp, vp, vp, u64, vp, u64, vp]
     L.shk_owner_counts.argtypes = [vp, u32, vp]
-    L.shk_compact_owners.argtypes = [vp, u32, vp, vp, vp, u64]
+    L.shk_compact_owners.argtypes = [vp, u32, vp, vp, vp, u64, C.c_int32]
     L.shk_merge_entries.argtypes = [vp, vp, vp, u64, u64]
     L.shk_table_geometry.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
     L.shk_table_reserve_pages.argtypes = [vp, u64]
@@ -416,9 +416,10 @@ class KmerEngine:
         self._check(self._L.shk_owner_counts(self._h, n_owners, out.ctypes.data))
         return out
 
-    def compact_owner_tensors(self, counts):
+    def compact_owner_tensors(self, counts, skip_owner: int = -1):
         """The occupied entries, owner after owner: (keys int64[n], vals int32[n_lanes, n]) as new
-        CUDA tensors, n = sum(counts) (counts from owner_counts with the same number of owners)."""
+        CUDA tensors, n = sum(counts) (counts from owner_counts with the same number of owners;
+        skip_owner's count must be 0: its range is left out)."""
         import torch
         counts = np.asarray(counts, dtype=np.uint64)
         n = int(counts.sum())
@@ -428,7 +429,7 @@ class KmerEngine:
         off = np.zeros(len(counts), dtype=np.uint64)
         off[1:] = np.cumsum(counts)[:-1]
         self._check(self._L.shk_compact_owners(self._h, len(counts), off.ctypes.data, keys.data_ptr(),
-                                               vals.data_ptr(), vals.stride(0)))
+                                               vals.data_ptr(), vals.stride(0), skip_owner))
         return keys[:n], vals[:, :n]
 
     def merge_entry_tensors(self, keys_t, vals_t):

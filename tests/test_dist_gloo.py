@@ -100,10 +100,11 @@ class NumpyPagedEngine:
             out[self._page(key) // per] += 1
         return out
 
-    def compact_owner_tensors(self, counts):
+    def compact_owner_tensors(self, counts, skip_owner=-1):
         P = 1 << self.log_pages
         per = P // len(counts)
-        order = sorted(self.counts, key=lambda key: (self._page(key) // per, key))
+        order = sorted((key for key in self.counts if self._page(key) // per != skip_owner),
+                       key=lambda key: (self._page(key) // per, key))
         assert [sum(1 for key in order if self._page(key) // per == o) for o in range(len(counts))] == \
             [int(c) for c in counts]
         keys = np.array(order, dtype=np.uint64).view(np.int64) if order else np.zeros(0, dtype=np.int64)
