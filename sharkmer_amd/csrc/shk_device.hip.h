@@ -14,6 +14,7 @@
 //   histogram    src/kmer/counting.rs:171-202 + src/kmer/histogram.rs:51-85,125-134
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -2294,11 +2295,9 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
   auto load4 = [&](uint32_t step) {  // this lane's four records of a step (they share a block)
     return *reinterpret_cast<const uint4 *>(part_buf + rec_slot64(page, n_regions, (step * PG_WG + threadIdx.x) * 4u));
   };
-  uint4 nxt;
-  if (n_steps) nxt = load4(0);
-  for (uint32_t step = 0; step < n_steps; ++step) {
-    const uint32_t rr[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
-    if (step + 1 < n_steps) nxt = load4(step + 1);
+  // `nv` = how many of the lane's four records exist (4 in every step but a page's last, partial one)
+  auto body = [&](uint32_t step, const uint4 &cur, uint32_t nv, auto partial) {
+    const uint32_t rr[4] = {cur.x, cur.y, cur.z, cur.w};
     uint4 bk[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bk[q] = *reinterpret_cast<const uint4 *>(&tags[(rr[q] >> fpb) << 2]);
@@ -2311,9 +2310,14 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
       const uint32_t want = (rr[q] & fpmask) << 3;
       const uint32_t e0 = bk[q].x == want, e1 = bk[q].y == want, e2 = bk[q].z == want, e3 = bk[q].w == want;
       const uint32_t idx = e1 + 2u * e2 + 3u * e3;
-      const uint32_t found = e0 | e1 | e2 | e3;
+      uint32_t found = e0 | e1 | e2 | e3;
+      bool exists = true;
+      if (decltype(partial)::value) {
+        exists = (uint32_t)q < nv;
+        found &= (uint32_t)exists;
+      }
       atomicAdd(&dl[((rr[q] >> fpb) << 2) + idx], found);
-      missed[q] = !found;
+      missed[q] = exists && !found;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -2325,11 +2329,22 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
     // after every step: an empty page misses on every first occurrence and on its repeats until
     // it is inserted
     if (n_miss > MQ32 - 64 * P32_RPS || step < 16) drain();
+  };
+  uint4 nxt;
+  if (n_steps) nxt = load4(0);
+  for (uint32_t step = 0; step < n_steps; ++step) {
+    const uint4 cur = nxt;
+    if (step + 1 < n_steps) nxt = load4(step + 1);
+    body(step, cur, 4u, std::false_type{});
+  }
+  if (n_steps * P32_RPS * PG_WG < n) {  // the page's last, partial step: lanes past the end sit it out
+    const uint32_t j = (n_steps * PG_WG + threadIdx.x) * 4u;
+    const uint32_t nv = j < n ? (n - j < 4u ? n - j : 4u) : 0u;
+    uint4 cur = make_uint4(0u, 0u, 0u, 0u);
+    if (nv) cur = load4(n_steps);  // (a quad never straddles a block; its tail past n is ignored)
+    body(n_steps, cur, nv, std::true_type{});
   }
   drain();
-  // tail (< P32_RPS*PG_WG records): straight through the general probe
-  for (uint32_t i = n_steps * P32_RPS * PG_WG + threadIdx.x; i < n; i += PG_WG)
-    insert(part_buf[rec_slot64(page, n_regions, i)]);
   __syncthreads();
   // this pass's counts → the page's counts (saturating), four slots per lane
   for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG) {
