@@ -2196,6 +2196,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
 constexpr uint32_t TAG_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t MQ32 = 512;              // miss-queue entries per wave (LDS)
 constexpr uint32_t P32_RPS = 4;             // records per thread per step (one 16-B load)
+constexpr uint32_t P32_EARLY = 4;           // steps after which the miss queue is drained regardless of its fill
 static_assert(PAGE_SLOTS * 4 + PAGE_SLOTS * 4 + (PG_WG / 64) * MQ32 * 4 <= 81920, "two page workgroups per CU");
 static_assert(MQ32 >= 2 * 64 * P32_RPS, "the queue must take a whole step of misses on top of the drain threshold");
 __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
@@ -2325,10 +2326,10 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
       if (missed[q]) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = rr[q];
       n_miss += (uint32_t)__popcll(mm);
     }
-    // drain when the next step might not fit (worst case: every record of it misses), and at first
-    // after every step: an empty page misses on every first occurrence and on its repeats until
-    // it is inserted
-    if (n_miss > MQ32 - 64 * P32_RPS || step < 16) drain();
+    // drain when the next step might not fit (worst case: every record of it misses), and after
+    // each of the first few steps: an empty page misses on every first occurrence and on its
+    // repeats until it is inserted (measured: 4 early drains 0.232 ms, 0 → 0.240, 16 → 0.257)
+    if (n_miss > MQ32 - 64 * P32_RPS || step < P32_EARLY) drain();
   };
   uint4 nxt;
   if (n_steps) nxt = load4(0);
