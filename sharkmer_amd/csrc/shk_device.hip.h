@@ -1543,10 +1543,16 @@ template <int NT, int TT>
 __global__ void __launch_bounds__(NT, 4) k_scatter32(
     BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
     uint32_t cap_p, uint32_t *__restrict__ part_buf32, DevStats *__restrict__ stats,
-    unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg) {
+    unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg,
+    uint32_t n_region_lanes) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[NT / 64];
   __shared__ uint32_t red[NT / 64];
+  __shared__ unsigned long long lane_nn[64];  // ALL-LANES mode: non-N bases per chunk lane (n_lanes ≤ 64 here)
+  // lane_filter = ~0: ALL-LANES mode — one pass over the tiles of every chunk lane; region and cursor
+  // index = lane · P + page (n_region_lanes · P regions, block-interleaved together)
+  const bool all_lanes = lane_filter == 0xFFFFFFFFu;
+  if (all_lanes && threadIdx.x < 64) lane_nn[threadIdx.x] = 0;
   static_assert(TILE_T % TT == 0 && TT % (8 * NT) == 0 && 4 * TT >= TT + HALO + 4 * ((TT + HALO) / 16), "tile shape");
   constexpr int SPAN = TT / NT;
   constexpr int GROUPS = (TT + HALO) / 16;
@@ -1570,11 +1576,12 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   const uint32_t per = P / NT ? P / NT : 1;
   const uint32_t rbits = 2u * (uint32_t)k - log_parts;  // ≤ 32: bits of a record
   const uint32_t rmask = (uint32_t)(0xFFFFFFFFull >> (32 - rbits));
+  const uint32_t n_regions = (all_lanes ? n_region_lanes : 1u) * P;
 
   // iteration over sub-tiles: (macro tile t = [t0,t1) of chunk lane `lane`, sub-tile index sub)
   uint64_t t = blockIdx.x, t0, t1;
   uint32_t lane;
-  bool have = next_tile(b, t, true, lane_filter, t0, t1, lane);
+  bool have = next_tile(b, t, !all_lanes, lane_filter, t0, t1, lane);
   uint32_t sub = 0;
   StageRegs<NT, TT> pre;
   if (have) stage_prefetch<NT, TT>(b, t0, pre);
@@ -1586,14 +1593,23 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
     tprev = __builtin_readcyclecounter();
 #endif
     for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
-    n_non_n += stage_tile<true, NT, true, TT>(b, s0, s1, codes, stats, pre, packed, nullptr);
+    {
+      const uint32_t nn = stage_tile<true, NT, true, TT>(b, s0, s1, codes, stats, pre, packed, nullptr);
+      if (all_lanes) {  // this tile's lane: wave sum, one LDS add per wave
+        uint32_t v = nn;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lane_nn[lane], (unsigned long long)v);
+      } else {
+        n_non_n += nn;
+      }
+    }
     // the next sub-tile: of this macro tile, or the first one of this workgroup's next macro tile
     uint64_t nt = t, n0 = t0, n1 = t1;
     uint32_t nl = lane, nsub = sub + 1;
     bool hn = true;
     if (t0 + (uint64_t)nsub * TT >= t1) {
       nt = t + gridDim.x;
-      hn = next_tile(b, nt, true, lane_filter, n0, n1, nl);
+      hn = next_tile(b, nt, !all_lanes, lane_filter, n0, n1, nl);
       nsub = 0;
     }
     if (hn) stage_prefetch<NT, TT>(b, n0 + (uint64_t)nsub * TT, pre);  // in flight during the rest of this one
@@ -1664,6 +1680,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
           run += cnt[lo + i];
         }
     }
+    const uint32_t rbase = all_lanes ? lane * P : 0u;  // first region of this tile's lane
     // reserve this sub-tile's run in every page's region: one returning device-scope add per
     // non-empty (sub-tile, page); the results are parked in registers over the place phase
     uint32_t gres[MAX_PARTS / NT > 0 ? MAX_PARTS / NT : 1];
@@ -1673,7 +1690,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
       gres[r] = 0;
       if (i < P) {
         const uint32_t c1 = cnt[i];
-        if (c1) gres[r] = atomicAdd(&cursor[i], c1);
+        if (c1) gres[r] = atomicAdd(&cursor[rbase + i], c1);
       }
     }
     __syncthreads();  // codes are dead from here: `sorted` may overwrite them; tstart is complete
@@ -1709,13 +1726,13 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
         // (a launch covers ≤ 2^28 k-mers: byte offsets into part_buf fit 32 bits)
         if (two && pc1 == pc0 && at0 + 2 <= cap_p && (at0 & ((1u << RB_LOG) - 1u)) != (1u << RB_LOG) - 1u) {
           const uint2 rec2 = make_uint2(r0, r1);  // (both records in one block)
-          __builtin_memcpy(base + rec_slot(pc0, P, at0) * 4u, &rec2, 8);
+          __builtin_memcpy(base + rec_slot(rbase + pc0, n_regions, at0) * 4u, &rec2, 8);
         } else {
-          if (at0 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(pc0, P, at0) * 4u) = r0;
+          if (at0 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(rbase + pc0, n_regions, at0) * 4u) = r0;
           else spill_rec(pc0, r0);
           if (two) {
             const uint32_t at1 = gbase[pc1] + 2 * i + 1;
-            if (at1 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(pc1, P, at1) * 4u) = r1;
+            if (at1 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(rbase + pc1, n_regions, at1) * 4u) = r1;
             else spill_rec(pc1, r1);
           }
         }
@@ -1730,7 +1747,10 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
     have = hn;
   }
   __syncthreads();
-  {
+  if (all_lanes) {
+    if (threadIdx.x < 64 && threadIdx.x < n_region_lanes && lane_nn[threadIdx.x])
+      atomicAdd(&lane_bases[threadIdx.x], lane_nn[threadIdx.x]);
+  } else {
     uint32_t tot = wg_sum<NT>(n_non_n, red);
     if (threadIdx.x == 0 && tot) atomicAdd(&lane_bases[lane_filter], (unsigned long long)tot);
   }
@@ -2199,7 +2219,12 @@ constexpr uint32_t P32_RPS = 4;             // records per thread per step (one 
 constexpr uint32_t P32_EARLY = 4;           // steps after which the miss queue is drained regardless of its fill
 static_assert(PAGE_SLOTS * 4 + PAGE_SLOTS * 4 + (PG_WG / 64) * MQ32 * 4 <= 81920, "two page workgroups per CU");
 static_assert(MQ32 >= 2 * 64 * P32_RPS, "the queue must take a whole step of misses on top of the drain threshold");
-__global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
+// Chunk lanes [lane_lo, lane_hi) are processed one after the other on the same LDS copy of the
+// page (tags stay, the per-pass counts are written back and cleared in between); lane l's records
+// are region l·lane_stride + page of the n_regions block-interleaved regions (lane_stride = 0: the
+// buffer holds one lane, region = page).
+__global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo, uint32_t lane_hi,
+                                                   uint32_t lane_stride, uint32_t n_regions_,
                                                    const unsigned int *__restrict__ cursor, uint32_t cap_p,
                                                    const uint32_t *__restrict__ part_buf,
                                                    DevStats *__restrict__ stats, SpillRef sp) {
@@ -2208,12 +2233,16 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
   __shared__ __attribute__((aligned(16))) uint32_t mqs[(PG_WG / 64) * MQ32];
   if (stats->bad != ~0ull) return;
   const uint32_t page = blockIdx.x;
-  const uint32_t filled = cursor[page] < cap_p ? cursor[page] : cap_p;  // beyond cap_p: spilled
-  if (filled == 0) return;
+  {
+    uint32_t any = 0;
+    for (uint32_t l = lane_lo; l < lane_hi; ++l) any |= cursor[l * lane_stride + page];
+    if (any == 0) return;  // nothing for this page in any lane: leave it untouched in HBM
+  }
+  uint32_t lane = lane_lo;
   const uint32_t bits = tb.key_bits, R = bits - tb.log_pages, fpb = R - 11;
   const uint32_t fpmask = (1u << fpb) - 1u;
   uint64_t *gk = tb.keys + ((uint64_t)page << PAGE_LOG);
-  uint32_t *gv = tb.vals + (uint64_t)lane * tb.cap + ((uint64_t)page << PAGE_LOG);
+  uint32_t *gv = nullptr;  // this lane's counts of the page (set per lane below)
   // page keys → tags, counting occupied slots on the way
   uint32_t my_occ = 0;
   for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 2; i += PG_WG) {
@@ -2236,8 +2265,9 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
   const uint32_t room = occ0 < PAGE_FILL_CAP ? (PAGE_FILL_CAP - occ0) / (PG_WG / 64) : 0u;
   for (uint32_t i = threadIdx.x; i < PAGE_SLOTS; i += PG_WG) dl[i] = 0;
   __syncthreads();
-  const uint32_t n = filled;
-  const uint64_t n_regions = gridDim.x;  // one region per page, block-interleaved (rec_slot)
+  uint32_t n = 0;        // records of the current lane's region (set per lane below)
+  uint64_t region = 0;   // … and its index among the block-interleaved regions (rec_slot)
+  const uint64_t n_regions = n_regions_;
   const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
   uint32_t *mq = mqs + wave * MQ32;
   uint32_t n_miss = 0;  // wave-uniform
@@ -2289,74 +2319,88 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane,
     n_miss = 0;
     update_may_insert();
   };
-  // Main loop: one 16-B load = four records per thread per step, the next step's load in flight.
-  // No barrier in here: queues are per wave, and a slot's count of this pass is a full 32-bit word
-  // (a page sees < 2^31 records), so nothing has to be folded away mid-pass.
-  const uint32_t n_steps = n / (P32_RPS * PG_WG);
-  auto load4 = [&](uint32_t step) {  // this lane's four records of a step (they share a block)
-    return *reinterpret_cast<const uint4 *>(part_buf + rec_slot64(page, n_regions, (step * PG_WG + threadIdx.x) * 4u));
-  };
-  // `nv` = how many of the lane's four records exist (4 in every step but a page's last, partial one)
-  auto body = [&](uint32_t step, const uint4 &cur, uint32_t nv, auto partial) {
-    const uint32_t rr[4] = {cur.x, cur.y, cur.z, cur.w};
-    uint4 bk[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bk[q] = *reinterpret_cast<const uint4 *>(&tags[(rr[q] >> fpb) << 2]);
-    // Straight-line code on purpose (no ?: chains, which come out as nested exec-mask branches):
-    // at most one of the four tags can match, so the matching index is a sum of the compare bits,
-    // and a record that missed adds 0 to its bucket's first slot instead of skipping the add.
-    bool missed[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t want = (rr[q] & fpmask) << 3;
-      const uint32_t e0 = bk[q].x == want, e1 = bk[q].y == want, e2 = bk[q].z == want, e3 = bk[q].w == want;
-      const uint32_t idx = e1 + 2u * e2 + 3u * e3;
-      uint32_t found = e0 | e1 | e2 | e3;
-      bool exists = true;
-      if (decltype(partial)::value) {
-        exists = (uint32_t)q < nv;
-        found &= (uint32_t)exists;
+  for (lane = lane_lo; lane < lane_hi; ++lane) {
+    {
+      const uint32_t filled = cursor[lane * lane_stride + page];
+      n = filled < cap_p ? filled : cap_p;  // beyond cap_p: spilled
+    }
+    if (n == 0) continue;  // (uniform across the workgroup)
+    region = (uint64_t)lane * lane_stride + page;
+    gv = tb.vals + (uint64_t)lane * tb.cap + ((uint64_t)page << PAGE_LOG);
+    // Main loop: one 16-B load = four records per thread per step, the next step's load in flight.
+    // No barrier in here: queues are per wave, and a slot's count of this pass is a full 32-bit word
+    // (a page sees < 2^31 records), so nothing has to be folded away mid-pass.
+    const uint32_t n_steps = n / (P32_RPS * PG_WG);
+    auto load4 = [&](uint32_t step) {  // this lane's four records of a step (they share a block)
+      return *reinterpret_cast<const uint4 *>(part_buf + rec_slot64(region, n_regions, (step * PG_WG + threadIdx.x) * 4u));
+    };
+    // `nv` = how many of the lane's four records exist (4 in every step but a page's last, partial one)
+    auto body = [&](uint32_t step, const uint4 &cur, uint32_t nv, auto partial) {
+      const uint32_t rr[4] = {cur.x, cur.y, cur.z, cur.w};
+      uint4 bk[4];
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) bk[q] = *reinterpret_cast<const uint4 *>(&tags[(rr[q] >> fpb) << 2]);
+      // Straight-line code on purpose (no ?: chains, which come out as nested exec-mask branches):
+      // at most one of the four tags can match, so the matching index is a sum of the compare bits,
+      // and a record that missed adds 0 to its bucket's first slot instead of skipping the add.
+      bool missed[4];
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t want = (rr[q] & fpmask) << 3;
+        const uint32_t e0 = bk[q].x == want, e1 = bk[q].y == want, e2 = bk[q].z == want, e3 = bk[q].w == want;
+        const uint32_t idx = e1 + 2u * e2 + 3u * e3;
+        uint32_t found = e0 | e1 | e2 | e3;
+        bool exists = true;
+        if (decltype(partial)::value) {
+          exists = (uint32_t)q < nv;
+          found &= (uint32_t)exists;
+        }
+        atomicAdd(&dl[((rr[q] >> fpb) << 2) + idx], found);
+        missed[q] = exists && !found;
       }
-      atomicAdd(&dl[((rr[q] >> fpb) << 2) + idx], found);
-      missed[q] = exists && !found;
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned long long mm = __ballot(missed[q]);
+        if (missed[q]) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = rr[q];
+        n_miss += (uint32_t)__popcll(mm);
+      }
+      // drain when the next step might not fit (worst case: every record of it misses), and after
+      // each of the first few steps: an empty page misses on every first occurrence and on its
+      // repeats until it is inserted (measured: 4 early drains 0.232 ms, 0 → 0.240, 16 → 0.257)
+      if (n_miss > MQ32 - 64 * P32_RPS || step < P32_EARLY) drain();
+    };
+    uint4 nxt;
+    if (n_steps) nxt = load4(0);
+    for (uint32_t step = 0; step < n_steps; ++step) {
+      const uint4 cur = nxt;
+      if (step + 1 < n_steps) nxt = load4(step + 1);
+      body(step, cur, 4u, std::false_type{});
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const unsigned long long mm = __ballot(missed[q]);
-      if (missed[q]) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = rr[q];
-      n_miss += (uint32_t)__popcll(mm);
+    if (n_steps * P32_RPS * PG_WG < n) {  // the page's last, partial step: lanes past the end sit it out
+      const uint32_t j = (n_steps * PG_WG + threadIdx.x) * 4u;
+      const uint32_t nv = j < n ? (n - j < 4u ? n - j : 4u) : 0u;
+      uint4 cur = make_uint4(0u, 0u, 0u, 0u);
+      if (nv) cur = load4(n_steps);  // (a quad never straddles a block; its tail past n is ignored)
+      body(n_steps, cur, nv, std::true_type{});
     }
-    // drain when the next step might not fit (worst case: every record of it misses), and after
-    // each of the first few steps: an empty page misses on every first occurrence and on its
-    // repeats until it is inserted (measured: 4 early drains 0.232 ms, 0 → 0.240, 16 → 0.257)
-    if (n_miss > MQ32 - 64 * P32_RPS || step < P32_EARLY) drain();
-  };
-  uint4 nxt;
-  if (n_steps) nxt = load4(0);
-  for (uint32_t step = 0; step < n_steps; ++step) {
-    const uint4 cur = nxt;
-    if (step + 1 < n_steps) nxt = load4(step + 1);
-    body(step, cur, 4u, std::false_type{});
-  }
-  if (n_steps * P32_RPS * PG_WG < n) {  // the page's last, partial step: lanes past the end sit it out
-    const uint32_t j = (n_steps * PG_WG + threadIdx.x) * 4u;
-    const uint32_t nv = j < n ? (n - j < 4u ? n - j : 4u) : 0u;
-    uint4 cur = make_uint4(0u, 0u, 0u, 0u);
-    if (nv) cur = load4(n_steps);  // (a quad never straddles a block; its tail past n is ignored)
-    body(n_steps, cur, nv, std::true_type{});
-  }
-  drain();
-  __syncthreads();
-  // this pass's counts → the page's counts (saturating), four slots per lane
-  for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG) {
-    const uint4 d = reinterpret_cast<const uint4 *>(dl)[j];
-    if (d.x | d.y | d.z | d.w) {
-      uint4 v = reinterpret_cast<const uint4 *>(gv)[j];
-      v.x = sat_add_u32(v.x, d.x);
-      v.y = sat_add_u32(v.y, d.y);
-      v.z = sat_add_u32(v.z, d.z);
-      v.w = sat_add_u32(v.w, d.w);
-      reinterpret_cast<uint4 *>(gv)[j] = v;
+    drain();
+    __syncthreads();
+    // this pass's counts → the page's counts (saturating), four slots per lane
+    for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG) {
+      const uint4 d = reinterpret_cast<const uint4 *>(dl)[j];
+      if (d.x | d.y | d.z | d.w) {
+        uint4 v = reinterpret_cast<const uint4 *>(gv)[j];
+        v.x = sat_add_u32(v.x, d.x);
+        v.y = sat_add_u32(v.y, d.y);
+        v.z = sat_add_u32(v.z, d.z);
+        v.w = sat_add_u32(v.w, d.w);
+        reinterpret_cast<uint4 *>(gv)[j] = v;
+      }
+    }
+    __syncthreads();
+    if (lane + 1 < lane_hi) {  // the next lane counts from zero
+      for (uint32_t i = threadIdx.x; i < PAGE_SLOTS; i += PG_WG) dl[i] = 0;
+      __syncthreads();
     }
   }
   __syncthreads();

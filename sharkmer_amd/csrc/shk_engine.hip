@@ -21,7 +21,7 @@ using namespace shk;
 
 struct shk_ctx;
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed);
-static int prepare_cursors(shk_ctx *c, uint32_t *n_words);
+static int prepare_cursors(shk_ctx *c, bool multi, uint32_t *n_words);
 static int settle(shk_ctx *c);
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
@@ -100,6 +100,7 @@ struct shk_ctx {
   std::vector<TimedEvent> events;
   std::vector<hipEvent_t> event_pool;
   hipEvent_t chain_ev = nullptr;  // end event of the last timer (see ScopedTimer)
+  uint64_t cur_blocks = 1;        // 1000-read blocks in the batch being counted (ingest_core)
   bool chain_from_mark = false;   // nothing was enqueued between k_mark_starts' timer and the first scatter
   shk_timings timings{};
 };
@@ -357,9 +358,10 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     int rc = ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : first_kmers_ub / 4);
     if (rc != SHK_OK) return rc;
   }
+  c->cur_blocks = n_blocks;
   uint32_t n_cursor_words = 0;
   {
-    int rc = prepare_cursors(c, &n_cursor_words);
+    int rc = prepare_cursors(c, striped && n_blocks > 1, &n_cursor_words);
     if (rc != SHK_OK) return rc;
   }
   {
@@ -418,8 +420,6 @@ static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
 }
 
 constexpr int SC_NT = 512;  // threads of the partition count / sorted scatter workgroups
-constexpr int SC32_NT = 1024, SC32_TT = 16384;  // k_scatter32: 64 KiB of records + 64 KiB of entries in LDS,
-constexpr size_t SC32_LDS_MAX = 160 * 1024 - 256;  // one workgroup per CU (its static LDS is 128 B)
 
 static uint32_t region_cap(uint64_t n_records_ub, uint64_t n_regions, uint64_t pads) {
   // mean load + 25 % + worst-case padding + slack, even
@@ -448,11 +448,36 @@ static PartGeom part_geom(const shk_ctx *c) {
   return g;
 }
 
+// 4-byte records (k_scatter32 / k_part_scatter_sorted<.., true> + k_pages32) when a record fits:
+// 11 ≤ 2k - log_pages ≤ 32 (the low bits of the mixed key below the page bits); with two levels
+// the level-1 record, 2k - log_p1 bits, must fit as well.
+static bool use_rec32(const shk_ctx *c, const PartGeom &g) {
+  const uint32_t rbits = 2 * c->cfg.k >= g.lp ? 2 * c->cfg.k - g.lp : 0;
+  const uint32_t r1_bits = 2 * c->cfg.k >= g.log_p1 ? 2 * c->cfg.k - g.log_p1 : 0;
+  return rbits >= 11 && rbits <= 32 && r1_bits <= 32 && env_int("SHK_REC32", 1) != 0;
+}
+constexpr int SC32_NT = 1024, SC32_TT = 16384;  // k_scatter32: 64 KiB of records + 64 KiB of entries in LDS,
+constexpr size_t SC32_LDS_MAX = 160 * 1024 - 1024;  // one workgroup per CU (its static LDS is < 1 KiB)
+static size_t scatter32_lds(uint32_t P1) {
+  return (size_t)SC32_TT * 8 + ((size_t)(SC32_TT + HALO) / 16 + 2) * 4 + (size_t)P1 * 12;
+}
+// records-in-LDS scatter (k_scatter32: one 1024-thread workgroup per CU) when its LDS footprint fits
+static bool use_scatter32(const shk_ctx *c, const PartGeom &g) {
+  return use_rec32(c, g) && scatter32_lds(g.P1) <= SC32_LDS_MAX && env_int("SHK_SCATTER32_LDS", 1) != 0;
+}
+// ALL-LANES mode: a batch that spans several chunk lanes is partitioned in ONE scatter pass (regions
+// and cursors per (lane, page)) and counted by ONE k_pages32 launch that keeps a page in LDS for all
+// its lanes — instead of one scatter + one page pass per lane.  One level, k_scatter32 only.
+static bool use_all_lanes(const shk_ctx *c, const PartGeom &g, bool multi) {
+  return multi && !g.two_level && use_scatter32(c, g) && c->n_lanes <= 64 && env_int("SHK_ALL_LANES", 1) != 0;
+}
+
 // Room for the partition cursors of the next paged pass; *n_words = how many k_mark_starts clears.
-static int prepare_cursors(shk_ctx *c, uint32_t *n_words) {
+static int prepare_cursors(shk_ctx *c, bool multi, uint32_t *n_words) {
   const PartGeom g = part_geom(c);
-  HIPC(c, c->part_meta.ensure(((size_t)g.P1 + g.n_pages) * 4 + 64));  // same size as paged_count asks for
-  *n_words = g.cursor_words();
+  const size_t lanes = use_all_lanes(c, g, multi) ? c->n_lanes : 1;
+  HIPC(c, c->part_meta.ensure((lanes * g.P1 + g.n_pages) * 4 + 64));  // same size as paged_count asks for
+  *n_words = (uint32_t)(lanes * g.P1) + (g.two_level ? g.n_pages : 0);
   return SHK_OK;
 }
 
@@ -467,26 +492,40 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   // Every region is filled by per-tile reservations (one returning atomic per non-empty
   // (tile, region)); a region that still overflows (skewed input: one k-mer making up a large
   // share of the batch) sends the excess through the spill list — exact either way.
-  // 4-byte records (k_part_scatter_sorted<.., true> + k_pages32) when a record fits: one level,
-  // 11 ≤ 2k - log_pages ≤ 32 (the low bits of the mixed key below the page bits)
-  const uint32_t rbits = 2 * c->cfg.k >= lp ? 2 * c->cfg.k - lp : 0;
-  // (two levels: the level-1 record, 2k - log_p1 bits, must fit as well)
   const uint32_t r1_bits = 2 * c->cfg.k >= log_p1 ? 2 * c->cfg.k - log_p1 : 0;
-  const bool rec32 = rbits >= 11 && rbits <= 32 && r1_bits <= 32 && env_int("SHK_REC32", 1) != 0;
+  const bool rec32 = use_rec32(c, pg);
+  const bool multi = b.tiles != nullptr;
+  bool all_lanes = use_all_lanes(c, pg, multi);
+  const uint32_t NL = c->n_lanes;
+  // per-lane share of the batch's k-mers in ALL-LANES mode: blocks go round the lanes, so a lane
+  // holds at most ceil(blocks / lanes) of them; half as much again for uneven read lengths
+  // (what still overflows a region takes the spill path)
+  uint64_t lane_kmers_ub = sub_kmers_ub;
+  if (all_lanes) {
+    const uint64_t nb = std::max<uint64_t>(c->cur_blocks, 1);
+    const uint64_t per_lane_blocks = (nb + NL - 1) / NL;
+    lane_kmers_ub = std::min<uint64_t>(sub_kmers_ub, sub_kmers_ub / nb * per_lane_blocks * 3 / 2 + 2 * TILE_T);
+  }
   // (4-byte-record regions are block-interleaved, rec_slot: whole blocks of 2^RB_LOG records)
-  const uint32_t cap1 = (region_cap(sub_kmers_ub, P1, b.tile_count) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
+  const uint64_t pads = rec32 ? 0 : b.tile_count;  // (only 8-B record runs are padded, once per (tile, region) at most)
+  uint32_t cap1 = (region_cap(lane_kmers_ub, P1, pads) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
+  if (all_lanes && (uint64_t)NL * P1 * cap1 * 4 > 0xFFFFFFFFull) {  // 32-bit byte offsets: fall back to a pass per lane
+    all_lanes = false;
+    cap1 = (region_cap(sub_kmers_ub, P1, pads) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
+  }
+  const uint32_t region_lanes = all_lanes ? NL : 1;
   const uint32_t rs_tile = rec32 ? (uint32_t)RS32_TILE : (uint32_t)RS_TILE;
   const uint32_t tiles_per_region = (cap1 + rs_tile - 1) / rs_tile;
   const uint32_t cap_pg =
-      two_level ? (region_cap(sub_kmers_ub, n_pages, tiles_per_region) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u) : cap1;
+      two_level ? (region_cap(sub_kmers_ub, n_pages, rec32 ? 0 : tiles_per_region) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u) : cap1;
   DevBuf &buf_pg = two_level ? c->part3 : c->part;  // what k_pages reads
-  if ((uint64_t)P1 * cap1 * (rec32 ? 4 : 8) > 0xFFFFFFFFull)  // the scatter indexes part_buf with 32-bit byte offsets
+  if ((uint64_t)region_lanes * P1 * cap1 * (rec32 ? 4 : 8) > 0xFFFFFFFFull)  // the scatter indexes part_buf with 32-bit byte offsets
     return fail(c, SHK_ERR_INVARIANT, "partition buffer of one launch exceeds 4 GiB");
-  HIPC(c, c->part.ensure((uint64_t)P1 * cap1 * (rec32 ? 4 : 8)));
+  HIPC(c, c->part.ensure((uint64_t)region_lanes * P1 * cap1 * (rec32 ? 4 : 8)));
   if (two_level) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * (rec32 ? 4 : 8)));
   if (!rec32)
     HIPC(c, c->part2.ensure((uint64_t)n_pages * ((uint64_t)cap_pg + MISS_SLACK) * 8));  // k_pages miss queues
-  HIPC(c, c->part_meta.ensure(((size_t)P1 + n_pages) * 4 + 64));
+  HIPC(c, c->part_meta.ensure(((size_t)(use_all_lanes(c, pg, multi) ? NL : 1) * P1 + n_pages) * 4 + 64));
   unsigned int *cursor1 = (unsigned int *)c->part_meta.p;
   unsigned int *cursor_pg = two_level ? cursor1 + P1 : cursor1;
   unsigned long long *dbg = nullptr;
@@ -497,15 +536,15 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const size_t lds_sorted = (size_t)sort_region_bytes(P1) + (size_t)PACK_WORDS * 8 + (size_t)P1 * 12;
   const uint32_t S = 1u << log_sub;
   const size_t lds_rs = (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12;
-  // records-in-LDS scatter (k_scatter32: one 1024-thread workgroup per CU) when its LDS footprint fits
-  const size_t lds_s32 = (size_t)SC32_TT * 8 + ((size_t)(SC32_TT + HALO) / 16 + 2) * 4 + (size_t)P1 * 12;
-  const bool lds32 = rec32 && lds_s32 <= SC32_LDS_MAX && env_int("SHK_SCATTER32_LDS", 1) != 0;
+  const size_t lds_s32 = scatter32_lds(P1);
+  const bool lds32 = use_scatter32(c, pg);
   const size_t lds_rs32 = (size_t)RS32_TILE * 4 + (size_t)RS32_TILE * 2 + (size_t)S * 12;
-  const bool multi = b.tiles != nullptr;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
-  for (uint32_t lane = lane_lo; lane < lane_hi; ++lane) {
+  const size_t n_cursor_words = (size_t)region_lanes * P1 + (two_level ? n_pages : 0);
+  // one pass per chunk lane — or a single pass for all of them (ALL-LANES: `lane` = ~0 below)
+  for (uint32_t lane = lane_lo; lane < (all_lanes ? lane_lo + 1 : lane_hi); ++lane) {
     if (!(prezeroed && lane == lane_lo))  // the first pass's cursors were cleared by k_mark_starts
-      HIPC(c, hipMemsetAsync(cursor1, 0, (size_t)pg.cursor_words() * 4, c->stream));
+      HIPC(c, hipMemsetAsync(cursor1, 0, n_cursor_words * 4, c->stream));
     {
       ScopedTimer t(c, SHK_K_SCATTER, /*chain=*/prezeroed && lane == lane_lo && c->chain_from_mark);
       c->chain_from_mark = false;
@@ -517,8 +556,8 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
           attr_set = true;
         }
         hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT), lds_s32,
-                           c->stream, b, log_p1, lane, cursor1, cap1, (uint32_t *)c->part.p, c->d_stats,
-                           c->d_lane_bases, sp, dbg);
+                           c->stream, b, log_p1, all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1, (uint32_t *)c->part.p,
+                           c->d_stats, c->d_lane_bases, sp, dbg, NL);
       } else if (rec32)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, true>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
@@ -541,7 +580,8 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     {
       ScopedTimer t(c, SHK_K_PAGES, /*chain=*/true);
       if (rec32)
-        hipLaunchKernelGGL(k_pages32, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
+        hipLaunchKernelGGL(k_pages32, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, all_lanes ? 0u : lane,
+                           all_lanes ? NL : lane + 1, all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
                            (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
       else
         hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
