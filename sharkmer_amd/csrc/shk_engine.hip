@@ -99,6 +99,7 @@ struct shk_ctx {
   // timing
   std::vector<TimedEvent> events;
   std::vector<hipEvent_t> event_pool;
+  hipEvent_t done_ev = nullptr;   // finalize: "the control block has been copied back"
   hipEvent_t chain_ev = nullptr;  // end event of the last timer (see ScopedTimer)
   uint64_t cur_blocks = 1;        // 1000-read blocks in the batch being counted (ingest_core)
   bool chain_from_mark = false;   // nothing was enqueued between k_mark_starts' timer and the first scatter
@@ -715,6 +716,7 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
     }                                                                                        \
   } while (0)
   HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPB(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
   const size_t hist_n = (size_t)std::max<uint32_t>(cfg->chunks, 1) * (cfg->histo_max + 2);
   {
     size_t off = sizeof(DevStats) + sizeof(HistoTotals) + sizeof(unsigned long long) * c->n_lanes;
@@ -751,6 +753,7 @@ void shk_destroy(shk_ctx *c) {
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->tb.keys) (void)hipFree(c->tb.keys);
   if (c->tb.vals) (void)hipFree(c->tb.vals);
+  if (c->done_ev) (void)hipEventDestroy(c->done_ev);
   if (c->d_ctl) (void)hipFree(c->d_ctl);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   c->in_bases.release();
@@ -976,6 +979,7 @@ int shk_finalize(shk_ctx *c) {
   // invalid byte) it is settled now and the scan repeated over the repaired table.
   const bool was_unsettled = c->unsettled;
   HIPC(c, hipMemcpyAsync(c->h_ctl, c->d_ctl, c->ctl_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipEventRecord(c->done_ev, c->stream));  // the host waits for the copy, not for what follows it
   {  // histogram + totals back to zero for the next scan; nobody waits for this
     FillSegs f{};
     f.ptr[0] = c->d_tot;
@@ -984,7 +988,15 @@ int shk_finalize(shk_ctx *c) {
     f.n16[1] = (c->ctl_bytes - c->ctl_hist_off) / 16;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(f.n16[0] + f.n16[1], WG * 4, 1024)), dim3(WG), 0, c->stream, f);
   }
-  HIPC(c, hipStreamSynchronize(c->stream));
+  {
+    // poll first: the blocking wait's wake-up alone costs the host tens of µs, a tenth of a whole
+    // 1 M-read job; a run that takes longer than the poll window falls through to the blocking wait
+    hipError_t q = hipErrorNotReady;
+    for (int spin = 0; spin < 20000 && (q = hipEventQuery(c->done_ev)) == hipErrorNotReady; ++spin) {
+    }
+    if (q == hipErrorNotReady) q = hipEventSynchronize(c->done_ev);
+    HIPC(c, q);
+  }
   c->h_tot = *c->h_totp;
   if (was_unsettled) {
     const bool redo = c->h_stats->bad != ~0ull || c->h_stats->spill_count > 0;
