@@ -533,3 +533,20 @@ def test_filter_reads_matches_reference_semantics(orc, k):
     assert want.sum() > 25 and (~want).sum() >= 40  # both classes present (k=5 matches nearly everywhere)
     assert np.array_equal(got, want)
     assert not none.any()                                     # test_empty_filter, read_filter.rs:62-67
+
+
+def test_all_lanes_uneven_blocks_overflow_to_spill(orc):
+    """ALL-LANES mode sizes a (lane, page) region for an even share of the batch (+50 %); with
+    read lengths that differ by block one lane gets several times that — the excess must take the
+    spill path and nothing may be lost or double counted."""
+    rng = np.random.default_rng(5)
+    genome = rng.integers(0, 4, size=400_000)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    for blk in range(30):                      # 30 blocks of 1000 reads over 3 lanes
+        L = 400 if blk % 3 == 0 else 25        # lane 0 gets ~16× the bases of lanes 1 and 2
+        starts = rng.integers(0, len(genome) - L, size=1000)
+        seqs += [lut[genome[s:s + L]].tobytes() for s in starts]
+    bases, offsets = pack(seqs)
+    cnt = check_against_oracle(orc, bases, offsets, 15, 3, 500, flags=sa.FLAG_FORCE_PAGED, hint=400_000)
+    assert cnt["n_spilled"] > 0
