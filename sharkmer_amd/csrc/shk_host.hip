@@ -18,12 +18,18 @@
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -40,12 +46,87 @@ std::string fmt(const char *f, ...) {
 }  // namespace
 
 // ---- FASTQ reader --------------------------------------------------------------------------------
+// Read-ahead: a background thread does the gzread()s (file I/O + inflate, the slowest stage of the
+// host front-end) into a small ring of blocks while the caller's thread splits lines, fills the
+// batch and feeds the GPU.  The parser's view is unchanged: a stream of bytes, EOF, or a read error.
+struct ReadAhead {
+  static constexpr int NB = 4;
+  static constexpr size_t BLOCK = 4u << 20;
+  std::vector<char> blk[NB];
+  int len[NB];                 // bytes in the block; 0 = EOF marker; < 0 = gzread error
+  unsigned head = 0, tail = 0; // produced / consumed block counts
+  bool stop = false;
+  std::mutex m;
+  std::condition_variable cv;
+  std::thread th;
+  gzFile f = nullptr;
+  int fd = -1;  // ≥ 0: plain file, read() straight into the blocks (no pass through zlib's buffer)
+
+  void start(gzFile file, int raw_fd) {
+    f = file;
+    fd = raw_fd;
+    head = tail = 0;
+    stop = false;
+    for (auto &b : blk)
+      if (b.size() != BLOCK) b.resize(BLOCK);
+    th = std::thread([this] {
+      for (;;) {
+        unsigned slot;
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [this] { return stop || head - tail < (unsigned)NB; });
+          if (stop) return;
+          slot = head % NB;
+        }
+        int n;
+        if (fd >= 0) {
+          ssize_t got = 0, r = 0;  // fill the block: short reads would only shrink the blocks
+          while ((size_t)got < BLOCK && (r = ::read(fd, blk[slot].data() + got, BLOCK - (size_t)got)) > 0) got += r;
+          n = r < 0 ? -1 : (int)got;
+        } else {
+          n = gzread(f, blk[slot].data(), (unsigned)BLOCK);
+        }
+        {
+          std::lock_guard<std::mutex> lk(m);
+          len[slot] = n;
+          ++head;
+        }
+        cv.notify_all();
+        if (n <= 0) return;  // EOF or error: nothing more to produce
+      }
+    });
+  }
+  // next block for the consumer (releases the previous one); n = its length, 0 = EOF, < 0 = error
+  const char *next(bool release_prev, int *n) {
+    std::unique_lock<std::mutex> lk(m);
+    if (release_prev) {
+      ++tail;
+      cv.notify_all();
+    }
+    cv.wait(lk, [this] { return head > tail; });
+    const unsigned slot = tail % NB;
+    *n = len[slot];
+    return blk[slot].data();
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+
 struct shk_fastq {
   std::vector<std::string> paths;
   size_t file_idx = 0;
   gzFile f = nullptr;
+  int fd = -1;  // plain (not gzip) regular file: read without zlib
   std::string cur_name;
-  std::vector<char> buf;   // gz read buffer
+  ReadAhead ra;
+  const char *buf = nullptr;  // current read-ahead block
+  bool have_block = false;
   size_t buf_pos = 0, buf_len = 0;
   bool file_eof = false;
   uint64_t max_reads = 0, validate_every = 0;
@@ -55,36 +136,49 @@ struct shk_fastq {
   int err_code = 0;
   std::string line[4];
 
-  ~shk_fastq() {
+  void close_file() {
+    ra.shutdown();
     if (f) gzclose(f);
+    if (fd >= 0) ::close(fd);
+    f = nullptr;
+    fd = -1;
+    have_block = false;
   }
+  ~shk_fastq() { close_file(); }
 
-  // BufRead::lines(): split on '\n', strip one trailing '\r'.  1 = line, 0 = EOF, -1 = I/O error
-  int next_line(std::string &out) {
+  // BufRead::lines(): split on '\n', strip one trailing '\r'.  1 = line, 0 = EOF, -1 = I/O error.
+  // keep = false: the line's text is not needed (header / separator / quality of a record that is
+  // not validated, io.rs:321-332), only that it exists.
+  int next_line(std::string &out, bool keep = true) {
     out.clear();
     bool got_any = false;
     for (;;) {
       if (buf_pos == buf_len) {
         if (file_eof) break;
-        int n = gzread(f, buf.data(), (unsigned)buf.size());
+        int n = 0;
+        buf = ra.next(have_block, &n);
+        have_block = true;
         if (n < 0) return -1;
         if (n == 0) {
           file_eof = true;
+          buf_pos = buf_len = 0;
           break;
         }
         buf_pos = 0;
         buf_len = (size_t)n;
       }
-      const char *p = buf.data() + buf_pos;
+      const char *p = buf + buf_pos;
       const char *nl = (const char *)memchr(p, '\n', buf_len - buf_pos);
       if (nl) {
-        out.append(p, nl - p);
+        if (keep) {
+          out.append(p, nl - p);
+          if (!out.empty() && out.back() == '\r') out.pop_back();
+        }
         buf_pos += (size_t)(nl - p) + 1;
-        if (!out.empty() && out.back() == '\r') out.pop_back();
         return 1;
       }
-      out.append(p, buf_len - buf_pos);
-      got_any = true;
+      if (keep) out.append(p, buf_len - buf_pos);
+      got_any = got_any || buf_len > buf_pos;
       buf_pos = buf_len;
     }
     if (!out.empty() || got_any) return 1;  // last line without newline
@@ -92,21 +186,29 @@ struct shk_fastq {
   }
 
   int open_next() {  // open_fastq_reader, io.rs:598-625 (gzread passes plain files through)
-    if (f) {
-      gzclose(f);
-      f = nullptr;
-    }
+    close_file();
     if (file_idx >= paths.size()) return 0;
     cur_name = paths[file_idx++];
-    f = cur_name == "-" ? gzdopen(0, "rb") : gzopen(cur_name.c_str(), "rb");
-    if (!f) {
-      err = fmt("Failed to open file: %s", cur_name.c_str());
-      err_code = SHK_ERR_IO;
-      return -1;
+    if (cur_name != "-") {  // a file that does not start with the gzip magic is read directly
+      fd = ::open(cur_name.c_str(), O_RDONLY);
+      unsigned char magic[2] = {0, 0};
+      if (fd >= 0 && (::pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b))) {
+        ::close(fd);
+        fd = -1;
+      }
     }
-    gzbuffer(f, 1 << 20);
+    if (fd < 0) {
+      f = cur_name == "-" ? gzdopen(0, "rb") : gzopen(cur_name.c_str(), "rb");
+      if (!f) {
+        err = fmt("Failed to open file: %s", cur_name.c_str());
+        err_code = SHK_ERR_IO;
+        return -1;
+      }
+      gzbuffer(f, 1 << 20);
+    }
     buf_pos = buf_len = 0;
     file_eof = false;
+    ra.start(f, fd);
     if (cur_name == "-") cur_name = "stdin";
     return 1;
   }
@@ -141,14 +243,16 @@ struct shk_fastq {
 
   // One record into line[0..3].  1 = record, 0 = end of this file, <0 = error
   int next_record() {
-    int g = next_line(line[0]);
+    // io.rs:321-332: only record 0 and every validate_every-th are looked at beyond their sequence
+    const bool keep = n_reads_read == 0 || (validate_every > 0 && n_reads_read % validate_every == 0);
+    int g = next_line(line[0], keep);
     if (g == 0) return 0;
     static const char *role[4] = {"header", "sequence", "separator", "quality"};
     if (g < 0)
       return fail(SHK_ERR_IO, fmt("Failed to read %s line of record %llu in %s", role[0],
                                   (unsigned long long)n_reads_read + 1, cur_name.c_str()));
     for (int i = 1; i < 4; ++i) {
-      g = next_line(line[i]);
+      g = next_line(line[i], keep || i == 1);
       if (g == 0)  // io.rs:291-317
         return fail(SHK_ERR_FASTQ, fmt("Truncated FASTQ record at record %llu in %s: missing %s line",
                                        (unsigned long long)n_reads_read + 1, cur_name.c_str(), role[i]));
@@ -170,7 +274,6 @@ int shk_fastq_open(const char *const *paths, uint32_t n_paths, uint64_t max_read
   if (n_paths == 0) r->paths.emplace_back("-");  // stdin, io.rs:517-537
   r->max_reads = max_reads;
   r->validate_every = validate_every;
-  r->buf.resize(1 << 20);
   *out = r;
   return SHK_OK;
 }
@@ -199,7 +302,7 @@ int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint6
   if (r->err_code) return r->err_code;
   uint64_t used = 0, n = 0;
   while (!r->done && n < max_seqs) {
-    if (!r->f && !r->pending) {
+    if (!r->f && r->fd < 0 && !r->pending) {
       int o = r->open_next();
       if (o < 0) return r->err_code;
       if (o == 0) {
@@ -211,8 +314,7 @@ int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint6
       int g = r->next_record();
       if (g < 0) return g;
       if (g == 0) {  // this file is exhausted; state persists into the next one (io.rs:498-512)
-        gzclose(r->f);
-        r->f = nullptr;
+        r->close_file();
         continue;
       }
       // io.rs:321-332
