@@ -1246,6 +1246,20 @@ __host__ __device__ inline uint32_t sort_region_bytes(uint32_t P) {
   return ((a > b ? a : b) + 15u) & ~15u;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (VALU only;
+// the __shfl_up formulation costs six ds_bpermute round trips).
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+  // within each row of 16 lanes: shifts by 1, 2, 4, 8 (bound_ctrl: lanes shifted in read 0)
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+  // across rows: lane 15 of a row into the next row (rows 1 and 3), then lane 31 into rows 2 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31
+  return v;
+}
+
 // the k-base window that starts at base index q of an MSB-first packed stream
 __device__ __forceinline__ uint64_t window_at(const uint32_t *stream, int q, int k) {
   const int s = 2 * q;
@@ -1391,15 +1405,12 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
       uint32_t lo = threadIdx.x * per, s = 0;
       if (lo < P)
         for (uint32_t i = 0; i < per; ++i) s += (cnt[lo + i] + pad1) & ~pad1;
-      uint32_t inc = s;
-      for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(inc, d, 64);
-        if ((int)(threadIdx.x & 63) >= d) inc += o;
-      }
+      const uint32_t inc = wave_scan_incl(s);
       if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
       __syncthreads();
-      uint32_t woff = 0;
-      for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+      const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+      const uint32_t part = (ln < wv && ln < (uint32_t)(NT / 64)) ? wsum[ln] : 0u;
+      const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(part), 63);
       uint32_t run = woff + inc - s;
       if (lo < P)
         for (uint32_t i = 0; i < per; ++i) {
@@ -1529,20 +1540,6 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
   if (dbg && threadIdx.x == 0)
     for (int i = 0; i < 8; ++i) dbg[(uint64_t)blockIdx.x * 8 + i] = ph[i];
 #endif
-}
-
-// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (VALU only;
-// the __shfl_up formulation costs six ds_bpermute round trips).
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
-  // within each row of 16 lanes: shifts by 1, 2, 4, 8 (bound_ctrl: lanes shifted in read 0)
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
-  // across rows: lane 15 of a row into the next row (rows 1 and 3), then lane 31 into rows 2 and 3
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31
-  return v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1858,15 +1855,12 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
     uint32_t lo = threadIdx.x * per, sacc = 0;
     if (lo < S)
       for (uint32_t i = 0; i < per; ++i) sacc += (cnt[lo + i] + 1u) & ~1u;
-    uint32_t inc = sacc;
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t o = __shfl_up(inc, d, 64);
-      if ((int)(threadIdx.x & 63) >= d) inc += o;
-    }
+    const uint32_t inc = wave_scan_incl(sacc);
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
-    uint32_t woff = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const uint32_t part = (ln < wv && ln < (uint32_t)(RS_NT / 64)) ? wsum[ln] : 0u;
+    const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(part), 63);
     uint32_t run = woff + inc - sacc;
     if (lo < S)
       for (uint32_t i = 0; i < per; ++i) {
@@ -1982,15 +1976,12 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
     uint32_t lo = threadIdx.x * per, sacc = 0;
     if (lo < S)
       for (uint32_t i = 0; i < per; ++i) sacc += cnt[lo + i];
-    uint32_t inc = sacc;
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t o = __shfl_up(inc, d, 64);
-      if ((int)(threadIdx.x & 63) >= d) inc += o;
-    }
+    const uint32_t inc = wave_scan_incl(sacc);
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
-    uint32_t woff = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const uint32_t part = (ln < wv && ln < (uint32_t)(RS_NT / 64)) ? wsum[ln] : 0u;
+    const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(part), 63);
     uint32_t run = woff + inc - sacc;
     if (lo < S)
       for (uint32_t i = 0; i < per; ++i) {

@@ -549,4 +549,6 @@ def test_all_lanes_uneven_blocks_overflow_to_spill(orc):
         seqs += [lut[genome[s:s + L]].tobytes() for s in starts]
     bases, offsets = pack(seqs)
     cnt = check_against_oracle(orc, bases, offsets, 15, 3, 500, flags=sa.FLAG_FORCE_PAGED, hint=400_000)
-    assert cnt["n_spilled"] > 0
+    import os
+    if all(os.environ.get(v, "1") != "0" for v in ("SHK_REC32", "SHK_SCATTER32_LDS", "SHK_ALL_LANES")):
+        assert cnt["n_spilled"] > 0  # (with the mode switched off by a test hook there is nothing to overflow)
