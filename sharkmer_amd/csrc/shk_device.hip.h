@@ -2171,10 +2171,17 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint64_t kq = kk[q];
-      int hit = ba[q].x == kq ? 0 : ba[q].y == kq ? 1 : bb[q].x == kq ? 2 : bb[q].y == kq ? 3 : -1;
-      if (hit >= 0 && kq != EMPTY) delta_add(dl, ss[q] + hit);  // EMPTY = padding ("hits" a free slot)
-      const unsigned long long mm = __ballot(hit < 0);
-      if (hit < 0) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = kq;
+      // straight-line (a ?: chain comes out as nested exec-mask branches): at most one of the four
+      // keys can match, so the matching index is a sum of the compare bits; a record that missed —
+      // or a padding record — adds 0 to the bucket's first delta instead of skipping the add
+      const uint32_t e0 = ba[q].x == kq, e1 = ba[q].y == kq, e2 = bb[q].x == kq, e3 = bb[q].y == kq;
+      const uint32_t idx = e1 + 2u * e2 + 3u * e3;
+      const uint32_t found = e0 | e1 | e2 | e3;       // (EMPTY = padding "finds" a free slot)
+      const uint32_t slot = ss[q] + idx;
+      atomicAdd(&dl[slot >> 1], (found & (uint32_t)(kq != EMPTY)) << (16u * (slot & 1u)));
+      const bool missed = !found;
+      const unsigned long long mm = __ballot(missed);
+      if (missed) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = kq;
       n_miss += (uint32_t)__popcll(mm);
     }
     // drain after every step at first (an empty page misses on every first occurrence, and
