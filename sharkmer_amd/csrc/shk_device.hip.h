@@ -2184,9 +2184,9 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
       if (missed) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = kq;
       n_miss += (uint32_t)__popcll(mm);
     }
-    // drain after every step at first (an empty page misses on every first occurrence, and
-    // on its repeats until it is inserted), then every DRAIN_EVERY steps
-    if (quad < 2 * DRAIN_EVERY || (quad % DRAIN_EVERY) == DRAIN_EVERY - 1 || quad + 1 == n_quads) {
+    // drain after each of the first DRAIN_EVERY steps (an empty page misses on every first
+    // occurrence, and on its repeats until it is inserted), then every DRAIN_EVERY steps
+    if (quad < DRAIN_EVERY || (quad % DRAIN_EVERY) == DRAIN_EVERY - 1 || quad + 1 == n_quads) {
       for (uint32_t j = lane_id; j < n_miss; j += 64) insert(mq[j]);  // this wave's own queue
       n_miss = 0;
       update_may_insert();
