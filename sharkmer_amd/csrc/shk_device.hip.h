@@ -1574,7 +1574,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
     BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
     uint32_t cap_p, uint32_t *__restrict__ part_buf32, DevStats *__restrict__ stats,
     unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg,
-    uint32_t n_region_lanes) {
+    uint32_t n_region_lanes, uint32_t wide) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[NT / 64];
   __shared__ uint32_t red[NT / 64];
@@ -1752,16 +1752,21 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
         const uint32_t pc0 = ee.x >> 14, pc1 = two ? ee.y >> 14 : pc0;
         const uint32_t r0 = recs[ee.x & 0x3FFFu], r1 = two ? recs[ee.y & 0x3FFFu] : 0u;
         const uint32_t at0 = gbase[pc0] + 2 * i;  // record index inside the page's region
-        // (a launch covers ≤ 2^28 k-mers: byte offsets into part_buf fit 32 bits)
+        // (a launch covers ≤ 2^28 k-mers: byte offsets into a per-launch buffer fit 32 bits; `wide`:
+        // the buffer accumulates the records of many launches and needs 64-bit offsets)
+        auto slot_ptr = [&](uint32_t region, uint32_t at) -> uint32_t * {
+          return wide ? part_buf32 + rec_slot64(region, n_regions, at)
+                      : reinterpret_cast<uint32_t *>(base + rec_slot(region, n_regions, at) * 4u);
+        };
         if (two && pc1 == pc0 && at0 + 2 <= cap_p && (at0 & ((1u << RB_LOG) - 1u)) != (1u << RB_LOG) - 1u) {
           const uint2 rec2 = make_uint2(r0, r1);  // (both records in one block)
-          __builtin_memcpy(base + rec_slot(rbase + pc0, n_regions, at0) * 4u, &rec2, 8);
+          __builtin_memcpy(slot_ptr(rbase + pc0, at0), &rec2, 8);
         } else {
-          if (at0 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(rbase + pc0, n_regions, at0) * 4u) = r0;
+          if (at0 < cap_p) *slot_ptr(rbase + pc0, at0) = r0;
           else spill_rec(pc0, r0);
           if (two) {
             const uint32_t at1 = gbase[pc1] + 2 * i + 1;
-            if (at1 < cap_p) *reinterpret_cast<uint32_t *>(base + rec_slot(rbase + pc1, n_regions, at1) * 4u) = r1;
+            if (at1 < cap_p) *slot_ptr(rbase + pc1, at1) = r1;
             else spill_rec(pc1, r1);
           }
         }
@@ -1926,7 +1931,7 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
     const uint32_t *__restrict__ src_buf, const unsigned int *__restrict__ src_cursor, uint32_t src_cap,
     uint32_t tiles_per_region, uint32_t log_sub, uint32_t r1_bits, uint32_t key_bits,
     unsigned int *__restrict__ dst_cursor, uint32_t dst_cap, uint32_t *__restrict__ dst_buf, uint32_t lane,
-    DevStats *__restrict__ stats, SpillRef sp) {
+    DevStats *__restrict__ stats, SpillRef sp, uint64_t dst_region_base, uint64_t n_dst_total) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[RS_NT / 64];
   if (stats->bad != ~0ull) return;
@@ -1992,7 +1997,7 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < S; i += RS_NT) {
     const uint32_t c1 = cnt[i];
-    gbase[i] = (c1 ? atomicAdd(&dst_cursor[((uint64_t)region << log_sub) + i], c1) : 0u) - tstart[i];
+    gbase[i] = (c1 ? atomicAdd(&dst_cursor[dst_region_base + ((uint64_t)region << log_sub) + i], c1) : 0u) - tstart[i];
   }
   // ---- place: entry = record index inside the tile -----------------------------------------------
 #pragma unroll
@@ -2023,8 +2028,9 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
     const uint32_t ra = recs[ee & 0xFFFFu], rb = two ? recs[ee >> 16] : 0u;
     const uint32_t sa = log_sub ? ra >> rbits2 : 0u, sb = two ? (log_sub ? rb >> rbits2 : 0u) : sa;
     const uint32_t at0 = gbase[sa] + 2 * i;
-    const uint64_t pa = ((uint64_t)region << log_sub) + sa, pb = ((uint64_t)region << log_sub) + sb;
-    const uint64_t n_dst = (uint64_t)n_src_regions << log_sub;  // pages
+    // destination regions: (this lane's first region) + page; n_dst regions interleave together
+    const uint64_t pa = dst_region_base + ((uint64_t)region << log_sub) + sa, pb = dst_region_base + ((uint64_t)region << log_sub) + sb;
+    const uint64_t n_dst = n_dst_total;
     if (two && sb == sa && at0 + 2 <= dst_cap && (at0 & ((1u << RB_LOG) - 1u)) != (1u << RB_LOG) - 1u) {
       const uint2 rec2 = make_uint2(ra & rmask2, rb & rmask2);
       __builtin_memcpy(dst_buf + rec_slot64(pa, n_dst, at0), &rec2, 8);

@@ -21,8 +21,12 @@ using namespace shk;
 
 struct shk_ctx;
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed);
-static int prepare_cursors(shk_ctx *c, bool multi, uint32_t *n_words);
+static int prepare_cursors(shk_ctx *c, bool multi, bool defer, uint32_t *n_words);
+static int acc_prepare(shk_ctx *c, uint64_t kmers_ub);
+static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub);
 static int settle(shk_ctx *c);
+static int settle_light(shk_ctx *c);
+static int flush_acc(shk_ctx *c);
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -102,6 +106,14 @@ struct shk_ctx {
   hipEvent_t done_ev = nullptr;   // finalize: "the control block has been copied back"
   hipEvent_t chain_ev = nullptr;  // end event of the last timer (see ScopedTimer)
   uint64_t cur_blocks = 1;        // 1000-read blocks in the batch being counted (ingest_core)
+  // Deferred page passes (see count_tiles): partitioned records of several batches wait here
+  DevBuf acc_buf, acc_cur;        // page regions (4-B records, block-interleaved) and their cursors
+  bool acc_active = false;        // the regions hold records that k_pages32 has not counted yet
+  uint32_t acc_lp = 0, acc_cap = 0, acc_region_lanes = 1;  // geometry the regions were planned for
+  uint64_t acc_records_ub = 0, acc_budget = 0;              // records in the regions (upper bound) / allowed
+  uint64_t acc_spill_cap = 0;     // ONE spill list per accumulation window: every launch of it uses this capacity
+  uint64_t acc_nd0 = 0;           // distinct keys when the window was planned
+  double acc_new_frac = 1.0;      // new keys per record in the last window (1 = nothing known yet)
   bool chain_from_mark = false;   // nothing was enqueued between k_mark_starts' timer and the first scatter
   shk_timings timings{};
 };
@@ -237,6 +249,11 @@ int read_stats(shk_ctx *c) {
 
 int grow_to(shk_ctx *c, uint32_t new_log_pages) {
   if (new_log_pages <= c->tb.log_pages) return SHK_OK;
+  if (c->acc_active) {  // the waiting records were partitioned for the current geometry
+    int rcf = settle(c);
+    if (rcf != SHK_OK) return rcf;
+    if (new_log_pages <= c->tb.log_pages) return SHK_OK;
+  }
   TableRef nt{};
   int rc = alloc_table(c, new_log_pages, &nt);
   if (rc != SHK_OK) return rc;
@@ -314,7 +331,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
                 uint64_t n_bases, int64_t lane_fixed) {
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
   {
-    int rc0 = settle(c);  // the previous launch's spill list / scratch must be done with
+    int rc0 = settle_light(c);  // the previous launch's spill list / scratch must be done with
     if (rc0 != SHK_OK) return rc0;
   }
   c->finalized = false;
@@ -362,7 +379,10 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   c->cur_blocks = n_blocks;
   uint32_t n_cursor_words = 0;
   {
-    int rc = prepare_cursors(c, striped && n_blocks > 1, &n_cursor_words);
+    const uint64_t first_kmers_ub = std::min(tiles_per_sub, n_tiles_ub) * TILE_T;
+    const bool defer = first_launch_defers(c, first_kmers_ub);
+    int rc = defer ? acc_prepare(c, first_kmers_ub) : (c->acc_active ? settle(c) : SHK_OK);  // (may flush: launch + settle)
+    if (rc == SHK_OK) rc = prepare_cursors(c, striped && n_blocks > 1, defer && first_launch_defers(c, first_kmers_ub), &n_cursor_words);
     if (rc != SHK_OK) return rc;
   }
   {
@@ -394,7 +414,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     b.tile_first = ta;
     b.tile_count = tn;
     if (ta) {
-      int rcs = settle(c);
+      int rcs = settle_light(c);
       if (rcs != SHK_OK) return rcs;
     }
     int rc = ta ? ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : sub_kmers_ub / 4) : SHK_OK;
@@ -473,16 +493,88 @@ static bool use_all_lanes(const shk_ctx *c, const PartGeom &g, bool multi) {
   return multi && !g.two_level && use_scatter32(c, g) && c->n_lanes <= 64 && env_int("SHK_ALL_LANES", 1) != 0;
 }
 
-// Room for the partition cursors of the next paged pass; *n_words = how many k_mark_starts clears.
-static int prepare_cursors(shk_ctx *c, bool multi, uint32_t *n_words) {
+// Which way a counting launch goes.
+//   PATH_PAGED  : partition, then count every page in LDS right away — pays when the batch is at
+//                 least comparable to the table (every page is streamed through LDS once per pass)
+//   PATH_DEFER  : partition only; the 4-byte records wait in the page regions, which go on filling
+//                 over the following launches, and ONE page pass counts them when their number
+//                 has become comparable to the table (or when anybody needs the table).  This is
+//                 what keeps small batches into a large table (the usual case: reads stream in,
+//                 the table holds a genome) at the partition rate instead of the rate of scattered
+//                 global atomics
+//   PATH_DIRECT : global atomics; whatever the paged paths cannot take (> 16 lanes, records that
+//                 do not fit 4 bytes on a table too small for an immediate pass, …)
+enum CountPath { PATH_DIRECT, PATH_PAGED, PATH_DEFER };
+static bool paged_feasible(const shk_ctx *c);
+static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub);
+static CountPath count_path(const shk_ctx *c, uint64_t sub_kmers_ub) {
+  if (!paged_feasible(c) || (c->cfg.flags & SHK_FLAG_FORCE_DIRECT)) return PATH_DIRECT;
+  if ((c->cfg.flags & SHK_FLAG_FORCE_PAGED) || paged_pays(c, sub_kmers_ub)) return PATH_PAGED;
   const PartGeom g = part_geom(c);
+  if (use_scatter32(c, g) && env_int("SHK_DEFER", 1) != 0) return PATH_DEFER;
+  return PATH_DIRECT;
+}
+
+// Make room for `kmers_ub` more records in the accumulation regions: plan them if there are none,
+// count what is waiting first (flush) if these would not fit any more.
+static int acc_prepare(shk_ctx *c, uint64_t kmers_ub) {
+  if (c->acc_active && (c->acc_lp != c->tb.log_pages || c->acc_records_ub + kmers_ub > c->acc_budget)) {
+    int rc = settle(c);  // flush + settle (may grow the table)
+    if (rc != SHK_OK) return rc;
+  }
+  if (c->acc_active) return SHK_OK;
+  const uint64_t n_pages = 1ull << c->tb.log_pages;
+  const uint32_t NL = c->n_lanes;
+  // Budget: half a table's worth of records (the new keys among them cannot take the load past 1
+  // before the next flush looks at it), at least this batch, at most what memory allows.
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  // Budget = the records after which the table should be looked at again: as many as would take the
+  // pages to 80 % full if new keys kept arriving at the last window's rate (with a margin; at first
+  // every record is assumed to bring a new key), between a quarter of and eight times the table.
+  const uint64_t nd = c->h_stats->n_distinct;
+  const double room = 0.8 * (double)c->tb.cap - (double)nd;
+  const double per_rec = std::max(0.02, std::min(1.0, c->acc_new_frac * 1.3));
+  uint64_t budget = room > 0 ? (uint64_t)(room / per_rec) : 0;
+  budget = std::min<uint64_t>(std::max<uint64_t>(budget, c->tb.cap / 4), c->tb.cap * 8);
+  budget = std::max<uint64_t>(budget, kmers_ub);
+  if (env_int("SHK_DEFER_BUDGET", 0) > 0)  // test hook: flush early and often
+    budget = std::max<uint64_t>((uint64_t)env_int("SHK_DEFER_BUDGET", 0), kmers_ub);
+  const uint64_t mem_records = (uint64_t)(free_b / 2 + c->acc_buf.cap) / (4ull * NL + 1);  // lanes each get a full-size region set
+  budget = std::min(budget, std::max<uint64_t>(mem_records, kmers_ub));
+  uint64_t cap = budget / n_pages + budget / n_pages / 4 + 1024;
+  cap = (cap + (1u << RB_LOG) - 1) & ~(uint64_t)((1u << RB_LOG) - 1);
+  if (cap > 0x7FFFF000ull) cap = 0x7FFFF000ull;
+  HIPC(c, c->acc_buf.ensure((size_t)NL * n_pages * cap * 4));
+  HIPC(c, c->acc_cur.ensure((size_t)NL * n_pages * 4 + 64));
+  HIPC(c, hipMemsetAsync(c->acc_cur.p, 0, (size_t)NL * n_pages * 4, c->stream));
+  c->acc_lp = c->tb.log_pages;
+  c->acc_cap = (uint32_t)cap;
+  c->acc_region_lanes = NL;
+  c->acc_budget = budget;
+  c->acc_records_ub = 0;
+  c->acc_nd0 = nd;
+  c->acc_spill_cap = std::min<uint64_t>(std::max<uint64_t>(budget, kmers_ub), 1ull << 28);
+  return SHK_OK;
+}
+
+static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub) { return count_path(c, kmers_ub) == PATH_DEFER; }
+
+// Room for the partition cursors of the next paged pass; *n_words = how many k_mark_starts clears.
+static int prepare_cursors(shk_ctx *c, bool multi, bool defer, uint32_t *n_words) {
+  const PartGeom g = part_geom(c);
+  if (defer) {  // the page regions' cursors persist; only a level-1 pass has per-launch cursors
+    HIPC(c, c->part_meta.ensure(((size_t)g.P1 + g.n_pages) * 4 + 64));
+    *n_words = g.two_level ? g.P1 : 0;
+    return SHK_OK;
+  }
   const size_t lanes = use_all_lanes(c, g, multi) ? c->n_lanes : 1;
   HIPC(c, c->part_meta.ensure((lanes * g.P1 + g.n_pages) * 4 + 64));  // same size as paged_count asks for
   *n_words = (uint32_t)(lanes * g.P1) + (g.two_level ? g.n_pages : 0);
   return SHK_OK;
 }
 
-static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed) {
+static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed, bool defer) {
   const PartGeom pg = part_geom(c);
   const uint32_t lp = pg.lp, n_pages = pg.n_pages, log_p1 = pg.log_p1, log_sub = pg.log_sub, P1 = pg.P1;
   const bool two_level = pg.two_level;
@@ -496,7 +588,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const uint32_t r1_bits = 2 * c->cfg.k >= log_p1 ? 2 * c->cfg.k - log_p1 : 0;
   const bool rec32 = use_rec32(c, pg);
   const bool multi = b.tiles != nullptr;
-  bool all_lanes = use_all_lanes(c, pg, multi);
+  bool all_lanes = use_all_lanes(c, pg, multi) && !defer;  // (deferred: always (lane, page) regions, see below)
   const uint32_t NL = c->n_lanes;
   // per-lane share of the batch's k-mers in ALL-LANES mode: blocks go round the lanes, so a lane
   // holds at most ceil(blocks / lanes) of them; half as much again for uneven read lengths
@@ -519,11 +611,12 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const uint32_t tiles_per_region = (cap1 + rs_tile - 1) / rs_tile;
   const uint32_t cap_pg =
       two_level ? (region_cap(sub_kmers_ub, n_pages, rec32 ? 0 : tiles_per_region) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u) : cap1;
-  DevBuf &buf_pg = two_level ? c->part3 : c->part;  // what k_pages reads
-  if ((uint64_t)region_lanes * P1 * cap1 * (rec32 ? 4 : 8) > 0xFFFFFFFFull)  // the scatter indexes part_buf with 32-bit byte offsets
+  DevBuf &buf_pg = defer ? c->acc_buf : (two_level ? c->part3 : c->part);  // what k_pages reads
+  if (defer && (c->acc_lp != lp || !c->acc_cur.p)) return fail(c, SHK_ERR_INVARIANT, "accumulation regions not planned");
+  if (!(defer && !two_level) && (uint64_t)region_lanes * P1 * cap1 * (rec32 ? 4 : 8) > 0xFFFFFFFFull)  // 32-bit byte offsets in the scatter
     return fail(c, SHK_ERR_INVARIANT, "partition buffer of one launch exceeds 4 GiB");
-  HIPC(c, c->part.ensure((uint64_t)region_lanes * P1 * cap1 * (rec32 ? 4 : 8)));
-  if (two_level) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * (rec32 ? 4 : 8)));
+  if (!(defer && !two_level)) HIPC(c, c->part.ensure((uint64_t)region_lanes * P1 * cap1 * (rec32 ? 4 : 8)));
+  if (two_level && !defer) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * (rec32 ? 4 : 8)));
   if (!rec32)
     HIPC(c, c->part2.ensure((uint64_t)n_pages * ((uint64_t)cap_pg + MISS_SLACK) * 8));  // k_pages miss queues
   HIPC(c, c->part_meta.ensure(((size_t)(use_all_lanes(c, pg, multi) ? NL : 1) * P1 + n_pages) * 4 + 64));
@@ -541,10 +634,14 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const bool lds32 = use_scatter32(c, pg);
   const size_t lds_rs32 = (size_t)RS32_TILE * 4 + (size_t)RS32_TILE * 2 + (size_t)S * 12;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
-  const size_t n_cursor_words = (size_t)region_lanes * P1 + (two_level ? n_pages : 0);
-  // one pass per chunk lane — or a single pass for all of them (ALL-LANES: `lane` = ~0 below)
-  for (uint32_t lane = lane_lo; lane < (all_lanes ? lane_lo + 1 : lane_hi); ++lane) {
-    if (!(prezeroed && lane == lane_lo))  // the first pass's cursors were cleared by k_mark_starts
+  // deferred: page regions and cursors are the accumulation ones and persist; only a level-1 pass
+  // has cursors of its own
+  const size_t n_cursor_words = defer ? (two_level ? P1 : 0) : (size_t)region_lanes * P1 + (two_level ? n_pages : 0);
+  const bool one_pass = all_lanes || (defer && !two_level);  // every lane's tiles in a single scatter launch
+  const uint32_t acc_wide = (uint64_t)NL * n_pages * c->acc_cap * 4 > 0xFFFFFFFFull;
+  // one pass per chunk lane — or a single pass for all of them (`lane` = ~0 below)
+  for (uint32_t lane = lane_lo; lane < (one_pass ? lane_lo + 1 : lane_hi); ++lane) {
+    if (n_cursor_words && !(prezeroed && lane == lane_lo))  // the first pass's cursors were cleared by k_mark_starts
       HIPC(c, hipMemsetAsync(cursor1, 0, n_cursor_words * 4, c->stream));
     {
       ScopedTimer t(c, SHK_K_SCATTER, /*chain=*/prezeroed && lane == lane_lo && c->chain_from_mark);
@@ -556,9 +653,14 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
           attr_set = true;
         }
-        hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT), lds_s32,
-                           c->stream, b, log_p1, all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1, (uint32_t *)c->part.p,
-                           c->d_stats, c->d_lane_bases, sp, dbg, NL);
+        if (defer && !two_level)  // straight into the accumulation regions, (lane, page) layout
+          hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
+                             lds_s32, c->stream, b, log_p1, 0xFFFFFFFFu, (unsigned int *)c->acc_cur.p, c->acc_cap,
+                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL, acc_wide);
+        else
+          hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
+                             lds_s32, c->stream, b, log_p1, all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1,
+                             (uint32_t *)c->part.p, c->d_stats, c->d_lane_bases, sp, dbg, NL, 0u);
       } else if (rec32)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, true>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
@@ -568,17 +670,23 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     }
     if (two_level) {
       ScopedTimer t(c, SHK_K_PSCAN, /*chain=*/true);  // timer slot reused: the level-2 re-scatter
-      if (rec32)
+      if (rec32 && defer)  // append to this lane's accumulation regions
+        hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs32, c->stream,
+                           (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
+                           log_sub, r1_bits, 2 * c->cfg.k, (unsigned int *)c->acc_cur.p, c->acc_cap,
+                           (uint32_t *)c->acc_buf.p, lane, c->d_stats, sp, (uint64_t)lane * n_pages,
+                           (uint64_t)NL * n_pages);
+      else if (rec32)
         hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs32, c->stream,
                            (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
                            log_sub, r1_bits, 2 * c->cfg.k, cursor_pg, cap_pg, (uint32_t *)buf_pg.p, lane,
-                           c->d_stats, sp);
+                           c->d_stats, sp, 0ull, (uint64_t)n_pages);
       else
         hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
                            (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
                            log_sub, 2 * c->cfg.k, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp);
     }
-    {
+    if (!defer) {
       ScopedTimer t(c, SHK_K_PAGES, /*chain=*/true);
       if (rec32)
         hipLaunchKernelGGL(k_pages32, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, all_lanes ? 0u : lane,
@@ -609,15 +717,31 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
 }
 
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed) {
-  HIPC(c, c->spillA.ensure(sub_kmers_ub * 16));
-  SpillRef sp = spill_ref(c->spillA, sub_kmers_ub);
+  CountPath path = count_path(c, sub_kmers_ub);
+  if (path == PATH_DEFER) {  // (the first launch of an ingest was planned before k_mark_starts)
+    int rc = acc_prepare(c, sub_kmers_ub);
+    if (rc != SHK_OK) return rc;
+    path = count_path(c, sub_kmers_ub);  // a flush may have grown the table
+    if (path == PATH_DEFER && !c->acc_cur.p) return fail(c, SHK_ERR_INVARIANT, "accumulation regions missing");
+  }
+  if (path != PATH_DEFER && c->acc_active) {  // the other paths work on the table itself
+    int rc = settle(c);
+    if (rc != SHK_OK) return rc;
+  }
+  // (deferred: the partition launches of a window and its page pass append to one spill list)
+  const uint64_t spill_cap = path == PATH_DEFER ? std::max<uint64_t>(c->acc_spill_cap, sub_kmers_ub) : sub_kmers_ub;
+  if (path == PATH_DEFER) c->acc_spill_cap = spill_cap;
+  HIPC(c, c->spillA.ensure(spill_cap * 16));
+  SpillRef sp = spill_ref(c->spillA, spill_cap);
   if (!prezeroed)
     HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
-  bool use_paged = paged_feasible(c) && !(c->cfg.flags & SHK_FLAG_FORCE_DIRECT) &&
-                   ((c->cfg.flags & SHK_FLAG_FORCE_PAGED) || paged_pays(c, sub_kmers_ub));
-  if (use_paged) {
-    int rc = paged_count(c, b, sub_kmers_ub, sp, prezeroed);
+  if (path != PATH_DIRECT) {
+    int rc = paged_count(c, b, sub_kmers_ub, sp, prezeroed, path == PATH_DEFER);
     if (rc != SHK_OK) return rc;
+    if (path == PATH_DEFER) {
+      c->acc_active = true;
+      c->acc_records_ub += sub_kmers_ub;
+    }
   } else {
     {  // validate + count bases first (encoding.rs:353-356, 374-376); k_direct tests stats->bad
       ScopedTimer t(c, SHK_K_SCAN);
@@ -631,7 +755,7 @@ static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, boo
   // Nothing is waited for here: the host looks at the launch's outcome (invalid byte, spilled
   // records, load factor) in settle(), at the latest before the next launch or at finalize.
   c->unsettled = true;
-  c->unsettled_spill_cap = sub_kmers_ub;
+  c->unsettled_spill_cap = spill_cap;
   return SHK_OK;
 }
 
@@ -655,11 +779,71 @@ static int settle_checked(shk_ctx *c) {
   return SHK_OK;
 }
 
+// Count the records that are waiting in the accumulation regions: one k_pages32 launch over every
+// lane's regions, then the cursors go back to zero.  The launch's outcome is looked at by the
+// settle that follows.
+static int flush_acc(shk_ctx *c) {
+  if (!c->acc_active) return SHK_OK;
+  const uint32_t n_pages = 1u << c->acc_lp;
+  if (c->acc_lp != c->tb.log_pages) return fail(c, SHK_ERR_INVARIANT, "table geometry changed under waiting records");
+  const uint32_t NL = c->acc_region_lanes;
+  // what the page pass spills (new keys that find their page full) goes behind what the window's
+  // partition launches may have spilled already: same list, same capacity, the counter runs on
+  const uint64_t spill_cap = c->acc_spill_cap;
+  if (c->spillA.cap < spill_cap * 16) return fail(c, SHK_ERR_INVARIANT, "spill list of the accumulation window missing");
+  SpillRef sp = spill_ref(c->spillA, spill_cap);
+  {
+    ScopedTimer t(c, SHK_K_PAGES);
+    hipLaunchKernelGGL(k_pages32, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+                       NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
+                       c->d_stats, sp);
+  }
+  HIPC(c, hipMemsetAsync(c->acc_cur.p, 0, (size_t)NL * n_pages * 4, c->stream));
+  c->acc_active = false;
+  c->acc_records_ub = 0;
+  c->unsettled = true;
+  c->unsettled_spill_cap = spill_cap;
+  return SHK_OK;
+}
+
+// Full settle: everything that was launched has been looked at and repaired, and the table holds
+// every record that was handed over (records waiting for a deferred page pass are counted first).
 static int settle(shk_ctx *c) {
+  if (c->acc_active) {
+    if (c->unsettled) {  // the partition launches that filled the regions: an invalid byte stops everything
+      int rc = read_stats(c);
+      if (rc != SHK_OK) return rc;
+      if (c->h_stats->bad != ~0ull) return settle_checked(c);  // poisons the context; nothing is counted
+    }
+    const uint64_t window_records = c->acc_records_ub;
+    int rc = flush_acc(c);  // (its spills join the partition launches' on the window's spill list)
+    if (rc != SHK_OK) return rc;
+    rc = read_stats(c);
+    if (rc != SHK_OK) return rc;
+    if (window_records)  // what the next window's budget is planned with (acc_prepare)
+    {
+      const uint64_t nd1 = c->h_stats->n_distinct;
+      c->acc_new_frac = (double)((nd1 > c->acc_nd0 ? nd1 - c->acc_nd0 : 0) + c->h_stats->spill_count) /
+                        (double)window_records;
+    }
+    return settle_checked(c);
+  }
   if (!c->unsettled) return SHK_OK;
   int rc = read_stats(c);
   if (rc != SHK_OK) return rc;
   return settle_checked(c);
+}
+
+// Between launches of an ingest: look at the last launch's outcome, but leave records that are
+// waiting for a deferred page pass where they are unless something has to be repaired.
+static int settle_light(shk_ctx *c) {
+  if (!c->unsettled) return SHK_OK;
+  if (!c->acc_active) return settle(c);
+  int rc = read_stats(c);
+  if (rc != SHK_OK) return rc;
+  if (c->h_stats->bad != ~0ull || c->h_stats->spill_count > 0) return settle(c);  // (re-reads the stats; rare)
+  c->unsettled = false;  // a clean partition launch: nothing to repair, the table was not touched
+  return SHK_OK;
 }
 
 // =============================================================================================
@@ -772,6 +956,8 @@ void shk_destroy(shk_ctx *c) {
   c->part2.release();
   c->part3.release();
   c->part_meta.release();
+  c->acc_buf.release();
+  c->acc_cur.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -793,6 +979,10 @@ int shk_reset(shk_ctx *c) {
   c->own_set = false;
   c->finalized = c->poisoned = false;
   c->unsettled = false;  // the memsets above are ordered behind any launch still in flight
+  c->acc_active = false;  // (the regions' cursors are cleared when they are planned again)
+  c->acc_records_ub = 0;
+  c->acc_lp = ~0u;
+  c->acc_new_frac = 1.0;
   c->poison_code = 0;
   c->err.clear();
   return SHK_OK;
@@ -853,7 +1043,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     // the counting of slice i.
     HIPC(c, hipEventSynchronize(c->copy_done[bsel]));  // `rebased[bsel]` consumed; data resident
     // slice i-1 (launched without a host sync) read the buffer slice i+1 is about to overwrite
-    rc = settle(c);
+    rc = settle_light(c);
     if (rc != SHK_OK) {
       (void)hipStreamSynchronize(c->copy_stream);
       return rc;
@@ -873,7 +1063,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
       return rc;
     }
   }
-  return settle(c);  // host-buffer ingest reports its errors before returning
+  return settle_light(c);  // host-buffer ingest reports its errors (an invalid byte) before returning
 }
 
 int shk_ingest_batch(shk_ctx *c, uint32_t chunk_id, const uint8_t *bases, const uint64_t *offsets,
@@ -956,6 +1146,10 @@ int shk_finalize(shk_ctx *c) {
   if (n_reads == 0 && c->n_inserted == 0 && !c->own_set)  // io.rs:578-580
     return fail(c, SHK_ERR_NO_READS,
                 "No reads were ingested. Check that input files contain valid FASTQ records.");
+  if (c->acc_active) {  // records still waiting for their page pass
+    int rcf = settle(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   const uint32_t n_cols = c->cfg.chunks;
   const uint64_t hlen = c->cfg.histo_max + 2;
   // d_hist and d_tot are zero here: they are zeroed by reset and again right after every read-back

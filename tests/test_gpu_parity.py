@@ -552,3 +552,58 @@ def test_all_lanes_uneven_blocks_overflow_to_spill(orc):
     import os
     if all(os.environ.get(v, "1") != "0" for v in ("SHK_REC32", "SHK_SCATTER32_LDS", "SHK_ALL_LANES")):
         assert cnt["n_spilled"] > 0  # (with the mode switched off by a test hook there is nothing to overflow)
+
+
+# ---- deferred page passes: small batches into a large table wait, partitioned, for one page pass -----------
+
+@pytest.mark.parametrize("k,chunks,hint,budget", [(21, 3, 4_200_000, 0), (21, 1, 4_200_000, 700_000),
+                                                  (15, 4, 0, 0), (16, 2, 300_000, 150_000), (13, 0, 0, 0)])
+def test_deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget):
+    """Default flags, batches far smaller than the table: every ingest only partitions (4-byte
+    records accumulate in (lane, page) regions), a page pass runs when the budget is used up or
+    somebody needs the table.  Mid-stream lookups must see everything ingested so far."""
+    if budget:
+        monkeypatch.setenv("SHK_DEFER_BUDGET", str(budget))
+    spec = sa.SynthSpec(genome_len=120_000, sub_per_64k=200, n_per_64k=60)
+    n_reads, step = 42_000, 1_500
+    bases, offsets = sa.synth_reads(spec, 0, n_reads)
+    ref = orc.run_batch(bases, offsets, k, chunks, 300)
+    mid_run = orc.run_batch(bases[:int(offsets[21_000])], offsets[:21_001], k, chunks, 300)
+    mid = mid_run.merged()  # (a view into mid_run: keep that alive)
+    mk, mc = mid.export()
+    probe = mk[:: max(len(mk) // 500, 1)]
+    with sa.KmerEngine(k, chunks, 300, capacity_hint=hint, flags=sa.FLAG_TIMING) as eng:
+        for a in range(0, n_reads, step):
+            b = min(a + step, n_reads)
+            eng.ingest_reads(bases[int(offsets[a]):int(offsets[b])], offsets[a:b + 1] - offsets[a])
+            if b == 21_000:  # a table read in the middle of the stream
+                got = eng.lookup(probe)
+                want = np.array([mid.get_count(int(x)) for x in probe], dtype=np.uint32)
+                assert np.array_equal(got, want)
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms()) or chunks == 0
+        c = eng.counters()
+        gk, gc = eng.export_table()
+        t = eng.timings()
+    st = ref.stats
+    assert c["n_kmers_ingested"] == st["n_kmers_ingested"] and c["n_unique_kmers"] == st["n_unique_kmers"]
+    rk, rc = ref.merged().export()
+    assert np.array_equal(gk, rk) and np.array_equal(gc, rc)
+    if "scatter" in t:  # the deferred path ran: fewer page passes than partition launches
+        assert t["pages"][1] <= t["scatter"][1]
+        if not budget and hint:  # … just the mid-stream lookup’s and finalize’s when the table is large and the budget untouched
+            assert t["pages"][1] <= 3
+
+
+def test_deferred_invalid_byte_poisons_before_anything_is_counted(orc):
+    spec = sa.SynthSpec(genome_len=50_000)
+    bases, offsets = sa.synth_reads(spec, 0, 6_000)
+    bad = bases.copy()
+    bad[int(offsets[4_500]) + 7] = ord("Z")
+    with sa.KmerEngine(15, 2, 100) as eng:
+        eng.ingest_reads(bases[:int(offsets[3_000])], offsets[:3_001])
+        with pytest.raises(sa.ShkError, match="Invalid character 'Z' in sequence. Only ACGTN allowed."):
+            eng.ingest_reads(bad[int(offsets[3_000]):], offsets[3_000:] - offsets[3_000])
+            eng.finalize()
+        with pytest.raises(sa.ShkError):
+            eng.finalize()
