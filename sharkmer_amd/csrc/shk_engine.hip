@@ -560,16 +560,22 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub) {
 
 static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub) { return count_path(c, kmers_ub) == PATH_DEFER; }
 
+// Bytes of the per-launch cursor buffer (part_meta).  One size for everybody who asks: the buffer
+// must not be reallocated between k_mark_starts (which clears cursors in it) and the partition launch.
+static size_t cursor_buf_bytes(const shk_ctx *c, const PartGeom &g, bool multi) {
+  return ((size_t)(use_all_lanes(c, g, multi) ? c->n_lanes : 1) * g.P1 + g.n_pages) * 4 + 64;
+}
+
 // Room for the partition cursors of the next paged pass; *n_words = how many k_mark_starts clears.
 static int prepare_cursors(shk_ctx *c, bool multi, bool defer, uint32_t *n_words) {
   const PartGeom g = part_geom(c);
   if (defer) {  // the page regions' cursors persist; only a level-1 pass has per-launch cursors
-    HIPC(c, c->part_meta.ensure(((size_t)g.P1 + g.n_pages) * 4 + 64));
+    HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, multi)));
     *n_words = g.two_level ? g.P1 : 0;
     return SHK_OK;
   }
   const size_t lanes = use_all_lanes(c, g, multi) ? c->n_lanes : 1;
-  HIPC(c, c->part_meta.ensure((lanes * g.P1 + g.n_pages) * 4 + 64));  // same size as paged_count asks for
+  HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, multi)));
   *n_words = (uint32_t)(lanes * g.P1) + (g.two_level ? g.n_pages : 0);
   return SHK_OK;
 }
@@ -619,7 +625,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   if (two_level && !defer) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * (rec32 ? 4 : 8)));
   if (!rec32)
     HIPC(c, c->part2.ensure((uint64_t)n_pages * ((uint64_t)cap_pg + MISS_SLACK) * 8));  // k_pages miss queues
-  HIPC(c, c->part_meta.ensure(((size_t)(use_all_lanes(c, pg, multi) ? NL : 1) * P1 + n_pages) * 4 + 64));
+  HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, pg, multi)));
   unsigned int *cursor1 = (unsigned int *)c->part_meta.p;
   unsigned int *cursor_pg = two_level ? cursor1 + P1 : cursor1;
   unsigned long long *dbg = nullptr;
