@@ -1569,12 +1569,12 @@ __device__ __forceinline__ void place_entries(uint32_t *__restrict__ sorted, con
   }
 }
 
-template <int NT, int TT>
+template <int NT, int TT, bool WIDE>
 __global__ void __launch_bounds__(NT, 4) k_scatter32(
     BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
     uint32_t cap_p, uint32_t *__restrict__ part_buf32, DevStats *__restrict__ stats,
     unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg,
-    uint32_t n_region_lanes, uint32_t wide) {
+    uint32_t n_region_lanes) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[NT / 64];
   __shared__ uint32_t red[NT / 64];
@@ -1752,11 +1752,11 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
         const uint32_t pc0 = ee.x >> 14, pc1 = two ? ee.y >> 14 : pc0;
         const uint32_t r0 = recs[ee.x & 0x3FFFu], r1 = two ? recs[ee.y & 0x3FFFu] : 0u;
         const uint32_t at0 = gbase[pc0] + 2 * i;  // record index inside the page's region
-        // (a launch covers ≤ 2^28 k-mers: byte offsets into a per-launch buffer fit 32 bits; `wide`:
+        // (a launch covers ≤ 2^28 k-mers: byte offsets into a per-launch buffer fit 32 bits; WIDE:
         // the buffer accumulates the records of many launches and needs 64-bit offsets)
         auto slot_ptr = [&](uint32_t region, uint32_t at) -> uint32_t * {
-          return wide ? part_buf32 + rec_slot64(region, n_regions, at)
-                      : reinterpret_cast<uint32_t *>(base + rec_slot(region, n_regions, at) * 4u);
+          if (WIDE) return part_buf32 + rec_slot64(region, n_regions, at);
+          return reinterpret_cast<uint32_t *>(base + rec_slot(region, n_regions, at) * 4u);
         };
         if (two && pc1 == pc0 && at0 + 2 <= cap_p && (at0 & ((1u << RB_LOG) - 1u)) != (1u << RB_LOG) - 1u) {
           const uint2 rec2 = make_uint2(r0, r1);  // (both records in one block)
