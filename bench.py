@@ -53,10 +53,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # SHK_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL collectives, owner exchange, merged
+    # histogram) with a world of one — a rehearsal of the N > 1 run on a single card
+    force_dist = world == 1 and bool(os.environ.get("SHK_BENCH_FORCE_DIST"))
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
@@ -83,7 +91,7 @@ def main():
     eng.synth_reads_device(spec, rank * n_reads, n_reads, d_bases.data_ptr(), d_offsets.data_ptr())
     n_bases = n_reads * L
 
-    if world > 1:
+    if dist is not None:
         from sharkmer_amd.dist import DistCounter
         dc = DistCounter(eng, dist, device=dev)
 
@@ -91,7 +99,7 @@ def main():
         eng.reset()
         eng.set_read_index(rank * n_reads)
         eng.ingest_reads_device(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases)
-        if world > 1:
+        if dist is not None:
             return dc.finalize_histograms()
         eng.finalize()
         return eng.histograms()
@@ -101,7 +109,7 @@ def main():
     eng.reset_timings()
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -1045,8 +1045,7 @@ __global__ void __launch_bounds__(WG) k_filter_reads(const uint8_t *__restrict__
 // W × blocks_per_owner; a block owns a fixed slice of one owner's range, counts it, reserves its
 // share of the owner's segment with ONE atomic, and writes its entries in slot order.
 // ==========================================================================================
-constexpr int OWNER_BLOCKS = 64;  // blocks per owner
-__global__ void __launch_bounds__(WG) k_owner_counts(TableRef tb, uint64_t spo,
+__global__ void __launch_bounds__(WG) k_owner_counts(TableRef tb, uint64_t spo, uint32_t OWNER_BLOCKS,
                                                      unsigned long long *__restrict__ counts) {
   __shared__ uint32_t red[WG / 64];
   const uint32_t o = blockIdx.x / OWNER_BLOCKS, j = blockIdx.x % OWNER_BLOCKS;
@@ -1064,7 +1063,7 @@ __global__ void __launch_bounds__(WG) k_compact_owners(TableRef tb, uint64_t spo
                                                        unsigned long long *__restrict__ seg_cursor,
                                                        uint64_t *__restrict__ out_keys,
                                                        uint32_t *__restrict__ out_vals, uint64_t lane_stride,
-                                                       uint32_t skip_owner) {
+                                                       uint32_t skip_owner, uint32_t OWNER_BLOCKS) {
   __shared__ uint32_t red[WG / 64];
   __shared__ uint32_t wbase[WG / 64];
   __shared__ unsigned long long blk_base;

@@ -1528,8 +1528,9 @@ int shk_owner_counts(shk_ctx *c, uint32_t n_owners, uint64_t *counts) {
   HIPC(c, c->misc.ensure((size_t)n_owners * 16));
   unsigned long long *dc = (unsigned long long *)c->misc.p;
   HIPC(c, hipMemsetAsync(dc, 0, (size_t)n_owners * 8, c->stream));
-  hipLaunchKernelGGL(k_owner_counts, dim3(n_owners * OWNER_BLOCKS), dim3(WG), 0, c->stream, c->tb,
-                     c->tb.cap / n_owners, dc);
+  const uint32_t bpo = std::min<uint32_t>(1024, std::max<uint32_t>(16, 2048 / n_owners));  // blocks per owner
+  hipLaunchKernelGGL(k_owner_counts, dim3(n_owners * bpo), dim3(WG), 0, c->stream, c->tb,
+                     c->tb.cap / n_owners, bpo, dc);
   HIPC(c, hipMemcpyAsync(counts, dc, (size_t)n_owners * 8, hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));
   return SHK_OK;
@@ -1546,9 +1547,10 @@ int shk_compact_owners(shk_ctx *c, uint32_t n_owners, const uint64_t *seg_offset
   unsigned long long *doff = (unsigned long long *)c->misc.p, *dcur = doff + n_owners;
   HIPC(c, hipMemcpyAsync(doff, seg_offsets, (size_t)n_owners * 8, hipMemcpyHostToDevice, c->stream));
   HIPC(c, hipMemsetAsync(dcur, 0, (size_t)n_owners * 8, c->stream));
-  hipLaunchKernelGGL(k_compact_owners, dim3(n_owners * OWNER_BLOCKS), dim3(WG), 0, c->stream, c->tb,
+  const uint32_t bpo = std::min<uint32_t>(1024, std::max<uint32_t>(16, 2048 / n_owners));  // blocks per owner
+  hipLaunchKernelGGL(k_compact_owners, dim3(n_owners * bpo), dim3(WG), 0, c->stream, c->tb,
                      c->tb.cap / n_owners, (const unsigned long long *)doff, dcur, (uint64_t *)d_keys,
-                     (uint32_t *)d_vals, vals_lane_stride, skip_owner < 0 ? ~0u : (uint32_t)skip_owner);
+                     (uint32_t *)d_vals, vals_lane_stride, skip_owner < 0 ? ~0u : (uint32_t)skip_owner, bpo);
   HIPC(c, hipStreamSynchronize(c->stream));  // the caller hands the buffers to a collective next
   return SHK_OK;
 }

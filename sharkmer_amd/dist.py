@@ -84,14 +84,31 @@ class DistCounter:
         if self.dense:
             return self.exchange_and_merge_dense()
         dist, W = self.dist, self.world
-        P, _, n_lanes = self._agree_on_pages()
-        counts = np.asarray(self.eng.owner_counts(W), dtype=np.int64)   # what I hold of every owner's range
-        counts[self.rank] = 0                                           # … my own range stays where it is
-        send_n = self._dev(torch.from_numpy(counts.copy()))
-        recv_n = torch.empty_like(send_n)
-        dist.all_to_all_single(recv_n, send_n)
-        recv = [int(x) for x in recv_n.cpu().tolist()]                  # what every peer holds of MY range
-        send = [int(x) for x in counts.tolist()]
+        # Geometry and entry counts in one small all_to_all: every rank sends every peer (its page
+        # count, what it holds of that peer's range).  Page counts that differ (a table grew on one
+        # rank only) show up on every rank alike: all grow to the largest and go round once more.
+        n_pages, _, n_lanes = self.eng.table_geometry()
+        if n_pages < W or n_pages % W:
+            self.eng.reserve_pages(max(n_pages, W))
+            n_pages, _, n_lanes = self.eng.table_geometry()
+        while True:
+            counts = np.asarray(self.eng.owner_counts(W), dtype=np.int64)   # what I hold of every owner's range
+            counts[self.rank] = 0                                           # … my own range stays where it is
+            msg = np.empty((W, 2), dtype=np.int64)
+            msg[:, 0] = n_pages
+            msg[:, 1] = counts
+            send_n = self._dev(torch.from_numpy(msg.reshape(-1)))
+            recv_n = torch.empty_like(send_n)
+            dist.all_to_all_single(recv_n, send_n)
+            got = recv_n.cpu().numpy().reshape(W, 2)
+            P = int(got[:, 0].max())
+            if P == n_pages and int(got[:, 0].min()) == n_pages:
+                break
+            self.eng.reserve_pages(P)
+            n_pages, _, n_lanes = self.eng.table_geometry()
+            assert n_pages == P, (n_pages, P)
+        recv = [int(x) for x in got[:, 1]]                              # what every peer holds of MY range
+        send = [int(x) for x in counts]
         keys, vals = self.eng.compact_owner_tensors(counts, self.rank)  # [sum(send)], [L, sum(send)]
         n_recv = sum(recv)
         rk = keys.new_empty(n_recv)
