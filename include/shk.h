@@ -200,6 +200,17 @@ int shk_find_oligos(shk_ctx *ctx, const uint64_t *oligos, uint32_t n_oligos, uin
 int shk_filter_reads(shk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
                      const uint64_t *primer_kmers, uint64_t n_kmers, uint8_t *out_matches);
 
+/* Batched kmers_from_ascii (src/kmer/encoding.rs:332-371) as sPCR's read threading calls it
+ * (src/pcr/threading.rs:97-101, also pcr/read_filter.rs:44): read i's canonical k-mers, in read
+ * order, are kmers[koff(i) .. koff(i) + n_kmers[i]) with koff(i) = Σ_{r<i} max(0, len_r − k + 1),
+ * the most a read can yield (an N shortens it: n_kmers[i] ≤ max(0, len_i − k + 1); the rest of the
+ * read's span is left untouched).  bad_byte[i] = 0, or the first byte outside ACGTN: such a read
+ * is the reference's Err (message of encoding.rs:353-356 with that byte) and yields no k-mers
+ * (n_kmers[i] = 0), which is how thread_reads treats it (threading.rs:99-101: skipped).
+ * kmers_cap must be ≥ koff(n_seqs).  Host buffers; the context's table is not touched. */
+int shk_kmers_from_reads(shk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
+                         uint64_t *kmers, uint64_t kmers_cap, uint32_t *n_kmers, uint8_t *bad_byte);
+
 /* ---- multi-GPU hooks (device pointers; exchanged by the caller over RCCL) ---- */
 
 /* Table geometry needed to shard by owner: n_pages (power of two),

@@ -1038,6 +1038,43 @@ __global__ void __launch_bounds__(WG) k_filter_reads(const uint8_t *__restrict__
 }
 
 // ==========================================================================================
+// K_KMERS: kmers_from_ascii (src/kmer/encoding.rs:332-371) for a batch of reads, k-mers returned in
+// read order (what thread_reads consumes, pcr/threading.rs:97-101).  Same one-thread-per-read
+// rolling form as K_FILTER; read i writes at koff[i] (host prefix of max(0, len − k + 1)).
+// ==========================================================================================
+__global__ void __launch_bounds__(WG) k_kmers_from_reads(const uint8_t *__restrict__ bases,
+                                                         const uint64_t *__restrict__ offsets,
+                                                         const uint64_t *__restrict__ koff, uint64_t n_seqs,
+                                                         int k, uint64_t *__restrict__ out,
+                                                         uint32_t *__restrict__ n_out,
+                                                         uint8_t *__restrict__ bad_byte) {
+  const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+  if (i >= n_seqs) return;
+  const uint64_t mask = (1ull << (2 * k)) - 1;
+  uint64_t fwd = 0, rev = 0;
+  int n_valid = 0;
+  uint32_t n = 0, bad = 0;
+  uint64_t *dst = out + koff[i];
+  for (uint64_t p = offsets[i], e = offsets[i + 1]; p < e; ++p) {
+    const uint32_t c = bases[p];
+    if (c == 'N') {  // encoding.rs:346-352
+      n_valid = 0;
+      continue;
+    }
+    if (!byte_is_acgtn(c)) {  // encoding.rs:353-356 → Err for the whole read
+      bad = c;
+      break;
+    }
+    const uint64_t b2 = ((c >> 1) ^ (c >> 2)) & 3u;
+    fwd = ((fwd << 2) | b2) & mask;
+    rev = (rev >> 2) | ((3 - b2) << (2 * (k - 1)));
+    if (++n_valid >= k) dst[n++] = fwd < rev ? fwd : rev;
+  }
+  n_out[i] = bad ? 0u : n;
+  bad_byte[i] = (uint8_t)bad;
+}
+
+// ==========================================================================================
 // K_OWNER_COUNTS / K_COMPACT_OWNERS: the sender side of the multi-GPU merge.  Owner o of W owns the
 // slots [o·spo, (o+1)·spo) (a contiguous page range).  Instead of shipping its range as it lies
 // in the table — EMPTY slots included, ≥ half of it — a rank ships only the occupied (key, counts)

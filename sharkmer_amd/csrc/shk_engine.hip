@@ -1450,6 +1450,54 @@ int shk_filter_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, 
   return SHK_OK;
 }
 
+int shk_kmers_from_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
+                         uint64_t *kmers, uint64_t kmers_cap, uint32_t *n_kmers, uint8_t *bad_byte) {
+  if (!c || (n_seqs && (!offsets || !n_kmers || !bad_byte))) return SHK_ERR_BAD_ARG;
+  if (n_seqs == 0) return SHK_OK;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  const uint32_t k = c->cfg.k;
+  // koff(i): every read gets room for the most k-mers it can yield
+  std::vector<uint64_t> koff(n_seqs + 1);
+  koff[0] = 0;
+  for (uint64_t i = 0; i < n_seqs; ++i) {
+    if (offsets[i + 1] < offsets[i]) return fail(c, SHK_ERR_BAD_ARG, "offsets must be non-decreasing");
+    const uint64_t len = offsets[i + 1] - offsets[i];
+    koff[i + 1] = koff[i] + (len >= k ? len - k + 1 : 0);
+  }
+  const uint64_t n_total = koff[n_seqs];
+  if (n_total > kmers_cap || (n_total && !kmers))
+    return fail(c, SHK_ERR_BAD_ARG, "kmers_cap %llu is below the %llu k-mers these reads can yield",
+                (unsigned long long)kmers_cap, (unsigned long long)n_total);
+  const uint64_t n_bases = offsets[n_seqs];
+  HIPC(c, c->in_bases.ensure(n_bases + 16));
+  HIPC(c, c->in_offsets.ensure((n_seqs + 2) * 8));
+  const uint64_t o_koff = 0, o_kmers = (n_seqs + 1) * 8, o_n = o_kmers + (n_total + 1) * 8,
+                 o_bad = o_n + n_seqs * 4;
+  HIPC(c, c->misc.ensure(o_bad + n_seqs));
+  char *m = (char *)c->misc.p;
+  {
+    int rcs = settle(c);  // the staging buffers may still feed a counting launch
+    if (rcs != SHK_OK) return rcs;
+  }
+  HIPC(c, hipStreamSynchronize(c->stream));
+  if (n_bases) HIPC(c, hipMemcpyAsync(c->in_bases.p, bases, n_bases, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(c->in_offsets.p, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(m + o_koff, koff.data(), (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedTimer t(c, SHK_K_LOOKUP);
+    hipLaunchKernelGGL(k_kmers_from_reads, dim3((uint32_t)((n_seqs + WG - 1) / WG)), dim3(WG), 0, c->stream,
+                       (const uint8_t *)c->in_bases.p, (const uint64_t *)c->in_offsets.p,
+                       (const uint64_t *)(m + o_koff), n_seqs, (int)k, (uint64_t *)(m + o_kmers),
+                       (uint32_t *)(m + o_n), (uint8_t *)(m + o_bad));
+  }
+  // a read's span is copied back whole; only its first n_kmers[i] entries mean anything
+  if (n_total) HIPC(c, hipMemcpyAsync(kmers, m + o_kmers, n_total * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipMemcpyAsync(n_kmers, m + o_n, n_seqs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipMemcpyAsync(bad_byte, m + o_bad, n_seqs, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));  // (also keeps `koff` alive until its copy ran)
+  return SHK_OK;
+}
+
 int shk_table_geometry(shk_ctx *c, uint64_t *n_pages, uint32_t *page_slots, uint32_t *n_lanes) {
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));

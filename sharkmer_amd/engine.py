@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "shk_abi_version", "shk_create", "shk_destroy", "shk_reset", "shk_last_error", "shk_ingest_batch",
     "shk_ingest_reads", "shk_set_read_index", "shk_ingest_reads_device", "shk_insert_counts", "shk_sync", "shk_finalize",
     "shk_histograms", "shk_get_counters", "shk_get_timings", "shk_reset_timings",
-    "shk_export_table", "shk_lookup", "shk_find_oligos", "shk_filter_reads", "shk_table_geometry", "shk_table_reserve_pages", "shk_owner_counts", "shk_compact_owners",
+    "shk_export_table", "shk_lookup", "shk_find_oligos", "shk_filter_reads", "shk_kmers_from_reads", "shk_table_geometry", "shk_table_reserve_pages", "shk_owner_counts", "shk_compact_owners",
     "shk_merge_entries",
     "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
     "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_synth_reads_device",
@@ -159,6 +159,7 @@ def load_library():
     L.shk_lookup.argtypes = [vp, vp, vp, u64, C.c_int]
     L.shk_find_oligos.argtypes = [vp, vp, u32, u32, u32, vp, vp, u64, C.POINTER(u64)]
     L.shk_filter_reads.argtypes = [vp, vp, vp, u64, vp, u64, vp]
+    L.shk_kmers_from_reads.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp]
     L.shk_owner_counts.argtypes = [vp, u32, vp]
     L.shk_compact_owners.argtypes = [vp, u32, vp, vp, vp, u64, C.c_int32]
     L.shk_merge_entries.argtypes = [vp, vp, vp, u64, u64]
@@ -360,6 +361,33 @@ class KmerEngine:
         self._check(self._L.shk_filter_reads(self._h, bases.ctypes.data, offsets.ctypes.data, n,
                                              pk.ctypes.data, len(pk), out.ctypes.data))
         return out[:n].astype(bool)
+
+    def kmers_from_reads(self, bases: np.ndarray, offsets: np.ndarray):
+        """Batched kmers_from_ascii (kmer/encoding.rs:332-371) in the form thread_reads uses it
+        (pcr/threading.rs:97-101) → (list of per-read uint64 arrays, bad_byte uint8 array).  A read with
+        a byte outside ACGTN has bad_byte != 0 and no k-mers."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        lens = np.diff(offsets.astype(np.int64))
+        room = np.maximum(lens - self.k + 1, 0)
+        koff = np.concatenate([[0], np.cumsum(room)]).astype(np.int64)
+        kmers = np.empty(max(int(koff[-1]), 1), dtype=np.uint64)
+        n_k = np.zeros(max(n, 1), dtype=np.uint32)
+        bad = np.zeros(max(n, 1), dtype=np.uint8)
+        self._check(self._L.shk_kmers_from_reads(self._h, bases.ctypes.data, offsets.ctypes.data, n,
+                                                 kmers.ctypes.data, int(koff[-1]), n_k.ctypes.data,
+                                                 bad.ctypes.data))
+        return [kmers[koff[i]:koff[i] + int(n_k[i])] for i in range(n)], bad[:n]
+
+    def kmers_from_ascii(self, seq) -> np.ndarray:
+        """kmers_from_ascii(seq, k) (kmer/encoding.rs:332-371) for one sequence; raises with the
+        reference's message on a byte outside ACGTN (encoding.rs:353-356)."""
+        b = np.frombuffer(seq.encode() if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
+        out, bad = self.kmers_from_reads(b, np.array([0, len(b)], dtype=np.uint64))
+        if bad[0]:
+            raise ShkError(-1, "Invalid character '%s' in sequence. Only ACGTN allowed." % chr(int(bad[0])))
+        return out[0]
 
     # -- multi-GPU hooks ---------------------------------------------------------------
     def table_geometry(self):

@@ -535,6 +535,53 @@ def test_filter_reads_matches_reference_semantics(orc, k):
     assert not none.any()                                     # test_empty_filter, read_filter.rs:62-67
 
 
+# ---- §8f row 4, second half: kmers_from_ascii in read order (what thread_reads extracts) ------------------------
+
+_KFA_CASES = ["CGTAATGCGGCGA", "CGTANATGCGGCGA", "NCGTANATGCGGCGA", "NCGTANATGCGGCGANN",
+              "NNCGTANATGCGGCGA", "TANCACN", "NTANCACNAGAAAATC", "AAAA", "ACGTACGTACGT", "", "N"]
+
+
+@pytest.mark.parametrize("k", [3, 5, 9, 11])
+def test_kmers_from_ascii_kats_on_device(orc, k):
+    """kmer/mod.rs:249-278 (test_kmers_from_ascii_matches_read_pipeline, ..._short_sequences) and the
+    vector of kmer/mod.rs:61-156, asked of the device's kmers_from_ascii."""
+    with sa.KmerEngine(k, 1, 10) as eng:
+        for seq in _KFA_CASES:
+            assert list(eng.kmers_from_ascii(seq)) == orc.kmers_from_ascii(seq, k), seq
+        if k == 9:
+            assert list(eng.kmers_from_ascii("CGTAATGCGGCG")) == orc.kmers_from_ascii("CGTAATGCGGCG", 9)
+            assert list(eng.kmers_from_ascii("ACGT")) == [] and len(eng.kmers_from_ascii("ACGTACGTA")) == 1
+        for seq, bad in [("ACGTX", "X"), ("acgt", "a"), ("ACG T", " ")]:   # encoding.rs:353-356
+            with pytest.raises(sa.ShkError) as e:
+                eng.kmers_from_ascii(seq)
+            assert f"Invalid character '{bad}' in sequence. Only ACGTN allowed." in str(e.value)
+
+
+@pytest.mark.parametrize("k", [7, 21, 31])
+def test_kmers_from_reads_batch_in_read_order(orc, k):
+    """pcr/threading.rs:97-101: per read, kmers_from_ascii's vector in order; a read with an invalid
+    byte is skipped (no k-mers, its byte reported)."""
+    spec = sa.SynthSpec(genome_len=40_000, sub_per_64k=300, n_per_64k=400)
+    bases, offsets = sa.synth_reads(spec, 0, 2_000)
+    bases = bases.copy()
+    rng = np.random.default_rng(100 + k)
+    bad_reads = {int(r): int(rng.integers(0, 150)) for r in rng.choice(2_000, size=30, replace=False)}
+    for r, pos in bad_reads.items():
+        bases[int(offsets[r]) + pos] = ord("x")
+    seqs = [bytes(bases[int(offsets[i]):int(offsets[i + 1])]) for i in range(2_000)]
+    seqs += [b"", b"ACG", b"N" * 40, b"ACGT" * 20 + b"N" + b"TTGCA" * 9]
+    bases2, offsets2 = pack(seqs)
+    with sa.KmerEngine(k, 1, 10) as eng:
+        got, bad = eng.kmers_from_reads(bases2, offsets2)
+    assert len(got) == len(seqs)
+    for i, sq in enumerate(seqs):
+        if i in bad_reads:
+            assert bad[i] == ord("x") and len(got[i]) == 0
+        else:
+            assert bad[i] == 0
+            assert list(got[i]) == orc.kmers_from_ascii(sq, k), i
+
+
 def test_all_lanes_uneven_blocks_overflow_to_spill(orc):
     """ALL-LANES mode sizes a (lane, page) region for an even share of the batch (+50 %); with
     read lengths that differ by block one lane gets several times that — the excess must take the
