@@ -2107,6 +2107,11 @@ __device__ __forceinline__ uint32_t pg_wg_sum(uint32_t v, uint32_t *scratch) {
 // idle) delta words, and every wave keeps its own miss queue (a slice of the page's miss_buf
 // region) with the fill level in a wave-uniform register — ballot/popcount, no atomics.
 constexpr uint32_t MISS_SLACK = 4096;  // extra records per page region of miss_buf (8 slices)
+constexpr uint32_t PG_DRAIN_EVERY = 4; // k_pages: steps (of 4 records per thread) between miss-queue drains
+// A wave's queue is emptied at every drain, so it never holds more than the records the wave saw
+// since the last one: a page's slice of miss_buf is capped at that, however large its region is.
+constexpr uint32_t MISS_WAVE_MAX = PG_DRAIN_EVERY * 4 * 64;
+constexpr uint32_t MISS_PAGE_MAX = (PG_WG / 64) * MISS_WAVE_MAX;
 __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
                                                  const unsigned int *__restrict__ cursor, uint32_t cap_p,
                                                  const uint64_t *__restrict__ part_buf,
@@ -2135,8 +2140,10 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
   const uint64_t n = filled;
   const uint64_t *src = part_buf + (uint64_t)page * cap_p;
   const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
-  const uint32_t slice = (uint32_t)(n / (PG_WG / 64)) + MISS_SLACK / (PG_WG / 64);
-  uint64_t *mq = miss_buf + (uint64_t)page * (cap_p + MISS_SLACK) + (uint64_t)wave * slice;
+  const uint32_t slice_n = (uint32_t)(n / (PG_WG / 64)) + MISS_SLACK / (PG_WG / 64);
+  const uint32_t slice = slice_n < MISS_WAVE_MAX ? slice_n : MISS_WAVE_MAX;
+  const uint32_t mq_stride = cap_p + MISS_SLACK < MISS_PAGE_MAX ? cap_p + MISS_SLACK : MISS_PAGE_MAX;
+  uint64_t *mq = miss_buf + (uint64_t)page * mq_stride + (uint64_t)wave * slice;
   uint32_t n_miss = 0;  // wave-uniform
   uint32_t n_new = 0;   // per thread
   // The fill cap is soft: whether this wave may still insert new keys is decided once per
@@ -2187,7 +2194,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
   // load per lane fetches two records; two such loads per step.
   const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(src);
   const uint32_t n_quads = (uint32_t)(n / (4 * PG_WG));  // steps of four records per thread
-  constexpr uint32_t DRAIN_EVERY = 4;                     // steps between miss-queue drains
+  constexpr uint32_t DRAIN_EVERY = PG_DRAIN_EVERY;        // steps between miss-queue drains
   static_assert(DRAIN_EVERY * 4 * PG_WG < 0x8000, "a 16-bit delta must not wrap between checks");
   ulonglong2 nxt[2];
   if (n_quads) {

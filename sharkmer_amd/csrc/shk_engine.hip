@@ -107,7 +107,9 @@ struct shk_ctx {
   hipEvent_t chain_ev = nullptr;  // end event of the last timer (see ScopedTimer)
   uint64_t cur_blocks = 1;        // 1000-read blocks in the batch being counted (ingest_core)
   // Deferred page passes (see count_tiles): partitioned records of several batches wait here
-  DevBuf acc_buf, acc_cur;        // page regions (4-B records, block-interleaved) and their cursors
+  DevBuf acc_buf, acc_cur;        // page regions (4-B records block-interleaved, or 8-B records lane by lane) and their cursors
+  bool acc_rec32 = true;          // which kind of record the regions were planned for
+  uint64_t acc_budget_max = 0;    // records the regions were sized for (a window's budget stays below)
   bool acc_active = false;        // the regions hold records that k_pages32 has not counted yet
   uint32_t acc_lp = 0, acc_cap = 0, acc_region_lanes = 1;  // geometry the regions were planned for
   uint64_t acc_records_ub = 0, acc_budget = 0;              // records in the regions (upper bound) / allowed
@@ -511,7 +513,11 @@ static CountPath count_path(const shk_ctx *c, uint64_t sub_kmers_ub) {
   if (!paged_feasible(c) || (c->cfg.flags & SHK_FLAG_FORCE_DIRECT)) return PATH_DIRECT;
   if ((c->cfg.flags & SHK_FLAG_FORCE_PAGED) || paged_pays(c, sub_kmers_ub)) return PATH_PAGED;
   const PartGeom g = part_geom(c);
-  if (use_scatter32(c, g) && env_int("SHK_DEFER", 1) != 0) return PATH_DEFER;
+  if (env_int("SHK_DEFER", 1) == 0) return PATH_DIRECT;
+  if (use_scatter32(c, g)) return PATH_DEFER;
+  // 8-byte records (k-mers too long for a 4-byte remainder, e.g. every table at k = 31) wait in page
+  // regions of their own kind; tables of a few pages stay with the global atomics
+  if (!use_rec32(c, g) && c->tb.log_pages >= 8) return PATH_DEFER;
   return PATH_DIRECT;
 }
 
@@ -540,16 +546,39 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub) {
   budget = std::max<uint64_t>(budget, kmers_ub);
   if (env_int("SHK_DEFER_BUDGET", 0) > 0)  // test hook: flush early and often
     budget = std::max<uint64_t>((uint64_t)env_int("SHK_DEFER_BUDGET", 0), kmers_ub);
-  const uint64_t mem_records = (uint64_t)(free_b / 2 + c->acc_buf.cap) / (4ull * NL + 1);  // lanes each get a full-size region set
-  budget = std::min(budget, std::max<uint64_t>(mem_records, kmers_ub));
-  uint64_t cap = budget / n_pages + budget / n_pages / 4 + 1024;
-  cap = (cap + (1u << RB_LOG) - 1) & ~(uint64_t)((1u << RB_LOG) - 1);
-  if (cap > 0x7FFFF000ull) cap = 0x7FFFF000ull;
-  HIPC(c, c->acc_buf.ensure((size_t)NL * n_pages * cap * 4));
+  const PartGeom g = part_geom(c);
+  const bool rec32 = use_rec32(c, g);
+  // The regions are sized ONCE per table geometry, for the largest window this table may get, and
+  // every window's budget stays below that: freeing and re-allocating tens of GB between windows
+  // stalls the host for seconds (the driver wipes VRAM that changes hands).
+  if (!(c->acc_buf.p && c->acc_lp == c->tb.log_pages && c->acc_rec32 == rec32 && c->acc_region_lanes == NL &&
+        kmers_ub <= c->acc_budget_max)) {
+    // lanes each get a full-size region set; 8-byte records also need k_pages' miss queues
+    const uint64_t rec_bytes = rec32 ? 4ull * NL + 1 : 8ull * NL + 8 + 1;
+    const uint64_t mem_records = (uint64_t)(free_b / 2 + c->acc_buf.cap) / rec_bytes;
+    // up to eight tables' worth of records while that is a few GiB, two tables' worth beyond
+    const uint64_t few_gib = (8ull << 30) / (rec32 ? 4 : 8) / NL;
+    uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), c->tb.cap * 2);
+    bmax = std::max<uint64_t>(std::min(bmax, mem_records), kmers_ub);
+    uint64_t cap = bmax / n_pages + bmax / n_pages / 4 + 1024;
+    cap = (cap + (1u << RB_LOG) - 1) & ~(uint64_t)((1u << RB_LOG) - 1);
+    if (cap > 0x7FFFF000ull) cap = 0x7FFFF000ull;
+    if (!rec32 && !g.two_level) {  // the one-level 8-byte scatter addresses a lane's regions with 32-bit byte offsets
+      const uint64_t lim = ((0xFFFFFFFFull / 8 / n_pages) >> RB_LOG) << RB_LOG;
+      if (cap > lim) cap = lim;
+      if (cap == 0) return fail(c, SHK_ERR_INVARIANT, "no room for accumulation regions");
+    }
+    c->acc_rec32 = rec32;
+    c->acc_cap = (uint32_t)cap;
+    c->acc_budget_max = bmax;
+    HIPC(c, c->acc_buf.ensure((size_t)NL * n_pages * cap * (rec32 ? 4 : 8)));
+    if (!rec32)  // k_pages' miss queues, here rather than at the first flush
+      HIPC(c, c->part2.ensure((uint64_t)n_pages * std::min<uint64_t>(cap + MISS_SLACK, MISS_PAGE_MAX) * 8));
+  }
+  budget = std::min(budget, c->acc_budget_max);
   HIPC(c, c->acc_cur.ensure((size_t)NL * n_pages * 4 + 64));
   HIPC(c, hipMemsetAsync(c->acc_cur.p, 0, (size_t)NL * n_pages * 4, c->stream));
   c->acc_lp = c->tb.log_pages;
-  c->acc_cap = (uint32_t)cap;
   c->acc_region_lanes = NL;
   c->acc_budget = budget;
   c->acc_records_ub = 0;
@@ -623,8 +652,9 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     return fail(c, SHK_ERR_INVARIANT, "partition buffer of one launch exceeds 4 GiB");
   if (!(defer && !two_level)) HIPC(c, c->part.ensure((uint64_t)region_lanes * P1 * cap1 * (rec32 ? 4 : 8)));
   if (two_level && !defer) HIPC(c, c->part3.ensure((uint64_t)n_pages * cap_pg * (rec32 ? 4 : 8)));
-  if (!rec32)
-    HIPC(c, c->part2.ensure((uint64_t)n_pages * ((uint64_t)cap_pg + MISS_SLACK) * 8));  // k_pages miss queues
+  if (!rec32 && !defer)
+    HIPC(c, c->part2.ensure((uint64_t)n_pages * std::min<uint64_t>((uint64_t)cap_pg + MISS_SLACK, MISS_PAGE_MAX) * 8));  // k_pages miss queues
+  if (defer && rec32 != c->acc_rec32) return fail(c, SHK_ERR_INVARIANT, "accumulation regions planned for the other record size");
   HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, pg, multi)));
   unsigned int *cursor1 = (unsigned int *)c->part_meta.p;
   unsigned int *cursor_pg = two_level ? cursor1 + P1 : cursor1;
@@ -643,7 +673,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   // deferred: page regions and cursors are the accumulation ones and persist; only a level-1 pass
   // has cursors of its own
   const size_t n_cursor_words = defer ? (two_level ? P1 : 0) : (size_t)region_lanes * P1 + (two_level ? n_pages : 0);
-  const bool one_pass = all_lanes || (defer && !two_level);  // every lane's tiles in a single scatter launch
+  const bool one_pass = all_lanes || (defer && !two_level && rec32);  // every lane's tiles in a single scatter launch
   const uint32_t acc_wide = (uint64_t)NL * n_pages * c->acc_cap * 4 > 0xFFFFFFFFull;
   // one pass per chunk lane — or a single pass for all of them (`lane` = ~0 below)
   for (uint32_t lane = lane_lo; lane < (one_pass ? lane_lo + 1 : lane_hi); ++lane) {
@@ -676,6 +706,11 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       } else if (rec32)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, true>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
+      else if (defer && !two_level)  // straight into this lane's accumulation regions (8-byte records)
+        hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, false>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
+                           b, log_p1, lane, (unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
+                           (void *)((uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap), c->d_stats,
+                           c->d_lane_bases, sp, dbg);
       else
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, false>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
@@ -693,6 +728,11 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
                            (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
                            log_sub, r1_bits, 2 * c->cfg.k, cursor_pg, cap_pg, (uint32_t *)buf_pg.p, lane,
                            c->d_stats, sp, 0ull, (uint64_t)n_pages);
+      else if (defer)  // append to this lane's accumulation regions (8-byte records)
+        hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
+                           (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
+                           log_sub, 2 * c->cfg.k, (unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
+                           (uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap, lane, c->d_stats, sp);
       else
         hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
                            (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
@@ -804,11 +844,20 @@ static int flush_acc(shk_ctx *c) {
   const uint64_t spill_cap = c->acc_spill_cap;
   if (c->spillA.cap < spill_cap * 16) return fail(c, SHK_ERR_INVARIANT, "spill list of the accumulation window missing");
   SpillRef sp = spill_ref(c->spillA, spill_cap);
-  {
+  if (c->acc_rec32) {
     ScopedTimer t(c, SHK_K_PAGES);
     hipLaunchKernelGGL(k_pages32, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
                        NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
                        c->d_stats, sp);
+  } else {  // 8-byte records: one page pass per lane over that lane's regions
+    HIPC(c, c->part2.ensure((uint64_t)n_pages * std::min<uint64_t>((uint64_t)c->acc_cap + MISS_SLACK, MISS_PAGE_MAX) * 8));  // (planned with the regions)
+    for (uint32_t lane = 0; lane < NL; ++lane) {
+      ScopedTimer t(c, SHK_K_PAGES);
+      hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
+                         (const unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
+                         (const uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap,
+                         (uint64_t *)c->part2.p, c->d_stats, sp);
+    }
   }
   HIPC(c, hipMemsetAsync(c->acc_cur.p, 0, (size_t)NL * n_pages * 4, c->stream));
   c->acc_active = false;

@@ -604,11 +604,28 @@ def test_all_lanes_uneven_blocks_overflow_to_spill(orc):
 # ---- deferred page passes: small batches into a large table wait, partitioned, for one page pass -----------
 
 @pytest.mark.parametrize("k,chunks,hint,budget", [(21, 3, 4_200_000, 0), (21, 1, 4_200_000, 700_000),
-                                                  (15, 4, 0, 0), (16, 2, 300_000, 150_000), (13, 0, 0, 0)])
+                                                  (15, 4, 0, 0), (16, 2, 300_000, 150_000), (13, 0, 0, 0),
+                                                  # k-mers too long for a 4-byte remainder: 8-byte records wait
+                                                  (31, 3, 1_100_000, 0), (31, 1, 1_100_000, 400_000),
+                                                  (27, 2, 2_200_000, 250_000)])
 def test_deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget):
-    """Default flags, batches far smaller than the table: every ingest only partitions (4-byte
+    """Default flags, batches far smaller than the table: every ingest only partitions (the
     records accumulate in (lane, page) regions), a page pass runs when the budget is used up or
     somebody needs the table.  Mid-stream lookups must see everything ingested so far."""
+    _deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget)
+
+
+@pytest.mark.parametrize("k,chunks,hint,budget,lvl1", [(31, 2, 1_100_000, 0, 3), (29, 3, 1_100_000, 300_000, 5),
+                                                       (21, 2, 4_200_000, 500_000, 4)])
+def test_deferred_page_passes_two_level(orc, monkeypatch, k, chunks, hint, budget, lvl1):
+    """The same with the super-page + re-scatter partition forced: the level-2 pass appends to the
+    waiting page regions (8-byte records for k = 31 / 29, 4-byte ones for k = 21)."""
+    monkeypatch.setenv("SHK_TWO_LEVEL_MIN_PAGES", "4")
+    monkeypatch.setenv("SHK_LEVEL1_LOG", str(lvl1))
+    _deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget)
+
+
+def _deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget):
     if budget:
         monkeypatch.setenv("SHK_DEFER_BUDGET", str(budget))
     spec = sa.SynthSpec(genome_len=120_000, sub_per_64k=200, n_per_64k=60)
@@ -639,7 +656,7 @@ def test_deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget):
     if "scatter" in t:  # the deferred path ran: fewer page passes than partition launches
         assert t["pages"][1] <= t["scatter"][1]
         if not budget and hint:  # … just the mid-stream lookup’s and finalize’s when the table is large and the budget untouched
-            assert t["pages"][1] <= 3
+            assert t["pages"][1] <= 3 * max(chunks, 1)  # (8-byte records: one page launch per lane and pass)
 
 
 def test_deferred_invalid_byte_poisons_before_anything_is_counted(orc):

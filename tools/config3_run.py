@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] at full size: 100 M synthetic 150-bp reads, k=31, one MI355X, the input
+streamed in batches.  The reads are generated on the device once (15 GB, outside the timed region);
+`--mode device` then counts them batch by batch from HBM, `--mode host` first moves them to pinned
+host memory and counts them from there (the engine slices each batch and overlaps the PCIe copy of
+the next slice with the counting of the current one).  Checked through size-independent properties
+(the CPU oracle would need hours): 120 k-mers per read, Σ freq·count = k-mer occurrences, Σ freq =
+distinct.  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sharkmer_amd as sa  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=100_000_000)
+ap.add_argument("--k", type=int, default=31)
+ap.add_argument("--genome", type=int, default=300_000_000)
+ap.add_argument("--batch", type=int, default=4_000_000)
+ap.add_argument("--chunks", type=int, default=1)
+ap.add_argument("--mode", choices=("device", "host"), default="device")
+ap.add_argument("--histo-max", type=int, default=10000)
+a = ap.parse_args()
+
+L = 150
+spec = sa.SynthSpec(genome_len=a.genome, read_len=L)
+n_batches = (a.reads + a.batch - 1) // a.batch
+d_all = torch.empty(a.reads * L, dtype=torch.uint8, device="cuda:0")
+d_off = torch.empty(a.batch + 1, dtype=torch.int64, device="cuda:0")
+eng = sa.KmerEngine(a.k, a.chunks, a.histo_max, device=0, capacity_hint=a.genome, flags=sa.FLAG_TIMING)
+t0 = time.time()
+for b in range(n_batches):
+    first = b * a.batch
+    n = min(a.batch, a.reads - first)
+    eng.synth_reads_device(spec, first, n, d_all.data_ptr() + first * L, d_off.data_ptr())
+eng.sync()
+torch.cuda.synchronize()
+print(f"generated {a.reads} reads in {time.time() - t0:.2f} s", flush=True)
+# (the last batch may be shorter: its offsets are the same prefix of multiples of L)
+eng.synth_reads_device(spec, 0, a.batch, d_all.data_ptr(), d_off.data_ptr())
+eng.sync()
+
+h_all = None
+if a.mode == "host":
+    t0 = time.time()
+    h_all = torch.empty(a.reads * L, dtype=torch.uint8, pin_memory=True)
+    h_all.copy_(d_all)
+    torch.cuda.synchronize()
+    del d_all
+    h_np = h_all.numpy()
+    offs = (np.arange(a.batch + 1, dtype=np.uint64) * L)
+    print(f"moved to pinned host memory in {time.time() - t0:.2f} s", flush=True)
+
+eng.reset_timings()
+t0 = time.time()
+for b in range(n_batches):
+    first = b * a.batch
+    n = min(a.batch, a.reads - first)
+    if a.mode == "device":
+        eng.ingest_reads_device(d_all.data_ptr() + first * L, d_off.data_ptr(), n, n * L)
+    else:
+        eng.ingest_reads(h_np[first * L:(first + n) * L], offs[:n + 1])
+    if b % 5 == 4:
+        print(f"  batch {b + 1}/{n_batches} submitted at {time.time() - t0:.2f} s", flush=True)
+eng.finalize()
+eng.sync()
+dt = time.time() - t0
+h = eng.histograms()
+c = eng.counters()
+tm = eng.timings()
+per_read = L - a.k + 1
+last = h[-1].astype(object)
+ok = (c["n_kmers_ingested"] == per_read * a.reads
+      and sum(int(f) * i for i, f in enumerate(last)) == per_read * a.reads
+      and int(h[-1].sum()) == c["n_unique_kmers"]
+      and all(int(h[j].sum()) >= int(h[j - 1].sum()) for j in range(1, len(h))))
+print(json.dumps({"workload": f"{a.reads} reads x {L} bp, k={a.k}, genome {a.genome}, batches of {a.batch}, "
+                              f"chunks={a.chunks}, input from {a.mode} memory",
+                  "seconds": round(dt, 3), "gbases_per_s": round(a.reads * L / dt / 1e9, 2),
+                  "n_unique_kmers": int(c["n_unique_kmers"]), "n_spilled": int(c.get("n_spilled", 0)),
+                  "properties_ok": bool(ok), "peak_bin": int(np.argmax(h[-1][2:]) + 2),
+                  "kernel_ms": {k: round(v[0], 1) for k, v in tm.items() if v[0] > 0}}), flush=True)
+eng.close()
+assert ok
