@@ -335,6 +335,37 @@ def test_config3_shape_k31_properties():
     assert np.array_equal(finals[0], finals[1])
 
 
+def test_config3_full_size_properties():
+    """BASELINE.json configs[2] at its full size — 100 M reads of 150 bp, k=31, a 300 Mb genome (a
+    2^30-slot table), streamed in batches of 4 M reads — generated on the device and counted from
+    HBM (tools/config3_run.py is the timed twin of this, incl. the host-streamed variant).  The
+    oracle would need hours: size-independent properties only."""
+    n, L, k, batch = 100_000_000, 150, 31, 4_000_000
+    spec = sa.SynthSpec(genome_len=300_000_000, read_len=L)
+    with sa.KmerEngine(k, 1, 10000, capacity_hint=300_000_000) as eng:
+        d_bases = eng.alloc_device(batch * L * 2)      # two batches in flight at most
+        d_off = eng.alloc_device((batch + 1) * 8)
+        try:
+            for b in range(n // batch):
+                buf = d_bases + (b & 1) * batch * L
+                eng.synth_reads_device(spec, b * batch, batch, buf, d_off)
+                eng.ingest_reads_device(buf, d_off, batch, batch * L)
+            eng.finalize()
+            h = eng.histograms()
+            c = eng.counters()
+        finally:
+            eng.sync()
+            eng.free_device(d_bases)
+            eng.free_device(d_off)
+    assert c["n_reads_ingested"] == n and c["n_bases_ingested"] == n * L
+    assert c["n_kmers_ingested"] == (L - k + 1) * n
+    col = h[0].astype(object)
+    assert sum(int(f) * i for i, f in enumerate(col)) == (L - k + 1) * n   # Σ freq·count = occurrences
+    assert int(h[0].sum()) == c["n_unique_kmers"]                           # Σ freq = distinct
+    assert c["n_unique_kmers"] <= 300_000_000 - k + 1                       # error-free reads of one genome
+    assert 30 <= int(np.argmax(h[0][2:]) + 2) <= 50                         # coverage peak: 50 × 120/150 = 40
+
+
 # ---- shapes that stress the paged path's LDS sort and page regions -------------------------------------
 
 @pytest.mark.parametrize("flags", FLAGSETS)
