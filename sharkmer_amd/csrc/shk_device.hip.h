@@ -83,7 +83,7 @@ struct SpillRef {
 // multiply finaliser.  Page = top log_pages bits, in-page home slot = the next 12.
 // tools/hash_eval.py: page occupancy and slot collisions match a Poisson process on random,
 // AT-rich, tandem-repeat and sequential keys (without the finaliser sequential keys collide).
-constexpr uint32_t MAX_LOG_PAGES = 19;  // log_pages + PAGE_LOG ≤ 32 hash bits
+constexpr uint32_t MAX_LOG_PAGES = 20;  // page bits + the 11 home-bucket bits ≤ 32 hash bits; 2^33 slots ≈ 103 GB
 // mix_key: a BIJECTION of the 2k-bit key space (multiply by an odd constant mod 2^2k, fold the
 // upper half down, multiply again: every step is invertible), so the position of a key in the
 // table — page = top log_pages bits, home bucket = next 11 bits — together with the remaining
@@ -115,8 +115,9 @@ __device__ __forceinline__ uint64_t page_of(uint32_t h, uint32_t log_pages) {
 // Home slots are bucket-aligned (multiples of 4): a key is almost always found inside the 32-B
 // bucket its probe sequence starts in, which k_pages reads with two 16-B LDS loads.
 __device__ __forceinline__ uint32_t slot_of(uint32_t h, uint32_t log_pages) {
-  return (h >> (32 - PAGE_LOG - log_pages)) & (PAGE_SLOTS - 4);
+  return ((h >> (32 - (PAGE_LOG - 2) - log_pages)) & (PAGE_SLOTS / 4 - 1)) << 2;  // the 11 bits below the page bits
 }
+static_assert(MAX_LOG_PAGES + PAGE_LOG - 2 <= 32, "page + home-bucket bits come out of 32 hash bits");
 
 __device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
   uint32_t s = a + b;

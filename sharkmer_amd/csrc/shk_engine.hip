@@ -294,17 +294,26 @@ SpillRef spill_ref(DevBuf &b, uint64_t cap) {
   return s;
 }
 
-// After a counting launch: re-insert spilled records into a grown table until none remain.
+// After a counting launch: re-insert the spilled records one by one (global atomics, exact) until none
+// remain.  Most spills need no bigger table — a record whose key sits too far from home for a tag, a
+// page region that overflowed on skewed input — so the first round inserts into the table as it
+// is unless every spilled record being a new key would take the load past 1/2; what spills again
+// found its page full, and from then on the table at least doubles per round.
 int drain_spill(shk_ctx *c, uint64_t spill_cap) {
   DevBuf *cur = &c->spillA, *nxt = &c->spillB;
-  while (c->h_stats->spill_count > 0) {
+  for (uint32_t round = 0; c->h_stats->spill_count > 0; ++round) {
     uint64_t n = c->h_stats->spill_count;
     if (n > spill_cap)
       return fail(c, SHK_ERR_INVARIANT, "spill list overflow (%llu > %llu)", (unsigned long long)n,
                   (unsigned long long)spill_cap);
     c->n_spilled += n;
-    // grow at least ×2, and enough for every spilled record to be a new key at load ≤ 1/2
-    uint32_t lp = std::max(c->tb.log_pages + 1, log_pages_for((c->h_stats->n_distinct + n) * 2));
+    uint32_t lp = log_pages_for((c->h_stats->n_distinct + n) * 2);
+    if (round > 0) {
+      if (c->tb.log_pages >= MAX_LOG_PAGES)
+        return fail(c, SHK_ERR_NOMEM, "table full: %llu distinct k-mers do not fit 2^%u pages",
+                    (unsigned long long)c->h_stats->n_distinct, MAX_LOG_PAGES);
+      lp = std::max(lp, c->tb.log_pages + 1);
+    }
     int rc = grow_to(c, lp);
     if (rc != SHK_OK) return rc;
     HIPC(c, nxt->ensure(n * 16));

@@ -366,6 +366,44 @@ def test_config3_full_size_properties():
     assert 30 <= int(np.argmax(h[0][2:]) + 2) <= 50                         # coverage peak: 50 × 120/150 = 40
 
 
+def test_config4_share_on_a_table_of_2_33_slots(orc):
+    """BASELINE.json configs[3]'s table on one GPU: a 3 Gb genome is a 2^33-slot table (2^20 pages,
+    the most the geometry allows: page bits + 11 home-bucket bits out of 32 hash bits; 103 GB), the
+    partition has two full levels (1024 × 1024) and everything is counted by deferred page passes.
+    24 M reads of one GPU's share; properties, plus point lookups (the global-memory probe must find
+    what the page workgroups inserted) bounded from below by an oracle count of the first reads."""
+    n, L, k, batch = 24_000_000, 150, 21, 4_000_000
+    spec = sa.SynthSpec(genome_len=3_000_000_000, read_len=L)
+    hb, ho = sa.synth_reads(spec, 0, 3_000)
+    first = orc.run_batch(hb, ho, k, 1, 100)
+    fk, fc = first.merged().export()
+    with sa.KmerEngine(k, 1, 1000, capacity_hint=3_000_000_000) as eng:
+        assert eng.table_geometry()[0] == 1 << 20
+        d_bases = eng.alloc_device(batch * L)
+        d_off = eng.alloc_device((batch + 1) * 8)
+        try:
+            for b in range(n // batch):
+                eng.synth_reads_device(spec, b * batch, batch, d_bases, d_off)
+                eng.ingest_reads_device(d_bases, d_off, batch, batch * L)
+            eng.finalize()
+            h = eng.histograms()
+            c = eng.counters()
+            got = eng.lookup(fk)
+        finally:
+            eng.sync()
+            eng.free_device(d_bases)
+            eng.free_device(d_off)
+    assert c["n_kmers_ingested"] == (L - k + 1) * n and c["n_grows"] == 0
+    col = h[0].astype(object)
+    assert sum(int(f) * i for i, f in enumerate(col)) == (L - k + 1) * n
+    assert int(h[0].sum()) == c["n_unique_kmers"]
+    # coverage 1.04 of k-mer starts: distinct ≈ G·(1 − e^(−1.04)) — random placement, so within 1 %
+    expect = 3e9 * (1 - np.exp(-(L - k + 1) * n / 3e9))
+    assert abs(c["n_unique_kmers"] - expect) < 0.01 * expect
+    assert (got >= fc).all()                     # every k-mer of the first reads is there, at least that often
+    assert (got < fc + 30).all()                 # … and not wildly more (coverage ≈ 1)
+
+
 # ---- shapes that stress the paged path's LDS sort and page regions -------------------------------------
 
 @pytest.mark.parametrize("flags", FLAGSETS)
