@@ -56,6 +56,26 @@ struct DevBuf {  // grow-only device scratch
   }
 };
 
+struct HostBuf {  // grow-only pinned host scratch
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 struct TimedEvent {
   int kid;
   hipEvent_t a, b;
@@ -88,6 +108,7 @@ struct shk_ctx {
   // scratch
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_done[2] = {nullptr, nullptr};
+  HostBuf h_rebased[2];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
   DevBuf in_bases, in_offsets, in_bases2, in_offsets2, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
   // host counters
   std::vector<uint64_t> lane_reads;
@@ -1014,6 +1035,8 @@ void shk_destroy(shk_ctx *c) {
   c->in_offsets.release();
   c->in_bases2.release();
   c->in_offsets2.release();
+  c->h_rebased[0].release();
+  c->h_rebased[1].release();
   if (c->copy_done[0]) (void)hipEventDestroy(c->copy_done[0]);
   if (c->copy_done[1]) (void)hipEventDestroy(c->copy_done[1]);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -1089,7 +1112,6 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     HIPC(c, hipEventCreateWithFlags(&c->copy_done[0], hipEventDisableTiming));
     HIPC(c, hipEventCreateWithFlags(&c->copy_done[1], hipEventDisableTiming));
   }
-  std::vector<uint64_t> rebased[2];
   auto issue_copy = [&](size_t i) -> int {
     const int bsel = (int)(i & 1);
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
@@ -1098,10 +1120,11 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     DevBuf &dof = bsel ? c->in_offsets2 : c->in_offsets;
     HIPC(c, db.ensure(nb + 64));
     HIPC(c, dof.ensure((ns + 1) * 8));
-    rebased[bsel].resize(ns + 1);  // device code indexes the staged copy from 0
-    for (uint64_t j = 0; j <= ns; ++j) rebased[bsel][j] = offsets[r0 + j] - o0;
+    HIPC(c, c->h_rebased[bsel].ensure((ns + 1) * 8));  // (free: the copy that read it last has completed, see below)
+    uint64_t *rebased = (uint64_t *)c->h_rebased[bsel].p;  // device code indexes the staged copy from 0
     if (nb) HIPC(c, hipMemcpyAsync(db.p, bases + o0, nb, hipMemcpyHostToDevice, c->copy_stream));
-    HIPC(c, hipMemcpyAsync(dof.p, rebased[bsel].data(), (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
+    for (uint64_t j = 0; j <= ns; ++j) rebased[j] = offsets[r0 + j] - o0;  // (while the bases are on their way)
+    HIPC(c, hipMemcpyAsync(dof.p, rebased, (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
     HIPC(c, hipEventRecord(c->copy_done[bsel], c->copy_stream));
     return SHK_OK;
   };
