@@ -2465,23 +2465,29 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     }
     drain();
     __syncthreads();
-    // this pass's counts → the page's counts (saturating), four slots per lane
-    for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG) {
-      const uint4 d = reinterpret_cast<const uint4 *>(dl)[j];
-      if (d.x | d.y | d.z | d.w) {
-        uint4 v = reinterpret_cast<const uint4 *>(gv)[j];
-        v.x = sat_add_u32(v.x, d.x);
-        v.y = sat_add_u32(v.y, d.y);
-        v.z = sat_add_u32(v.z, d.z);
-        v.w = sat_add_u32(v.w, d.w);
-        reinterpret_cast<uint4 *>(gv)[j] = v;
-      }
+    // this pass's counts → the page's counts (saturating), four slots per lane and step; all of a
+    // thread's loads are issued before the first is used, and the LDS counts go back to zero on the
+    // way (the next chunk lane counts from zero)
+    {
+      constexpr int WB = PAGE_SLOTS / 4 / PG_WG;
+      uint4 d[WB], v[WB];
+#pragma unroll
+      for (int u = 0; u < WB; ++u) d[u] = reinterpret_cast<const uint4 *>(dl)[threadIdx.x + u * PG_WG];
+#pragma unroll
+      for (int u = 0; u < WB; ++u)
+        if (d[u].x | d[u].y | d[u].z | d[u].w) v[u] = reinterpret_cast<const uint4 *>(gv)[threadIdx.x + u * PG_WG];
+#pragma unroll
+      for (int u = 0; u < WB; ++u)
+        if (d[u].x | d[u].y | d[u].z | d[u].w) {
+          v[u].x = sat_add_u32(v[u].x, d[u].x);
+          v[u].y = sat_add_u32(v[u].y, d[u].y);
+          v[u].z = sat_add_u32(v[u].z, d[u].z);
+          v[u].w = sat_add_u32(v[u].w, d[u].w);
+          reinterpret_cast<uint4 *>(gv)[threadIdx.x + u * PG_WG] = v[u];
+          reinterpret_cast<uint4 *>(dl)[threadIdx.x + u * PG_WG] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
     __syncthreads();
-    if (lane + 1 < lane_hi) {  // the next lane counts from zero
-      for (uint32_t i = threadIdx.x; i < PAGE_SLOTS; i += PG_WG) dl[i] = 0;
-      __syncthreads();
-    }
   }
   __syncthreads();
   const uint32_t nnew = pg_wg_sum(n_new, dl);
