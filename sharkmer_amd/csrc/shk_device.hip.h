@@ -2086,8 +2086,8 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
 // In LDS a page is 8192 keys (64 KiB) + 8192 sixteen-bit DELTAS of this pass (16 KiB, two per
 // word) = 80 KiB, so two page workgroups share a CU.  The deltas are folded into the page's
 // 32-bit counts in HBM when the workgroup leaves (saturating, counting.rs:82-85) — and earlier
-// for any slot whose delta reaches 2^15, which is checked at every miss-queue drain: between two
-// checks a slot gains at most DRAIN_EVERY·4·PG_WG = 8192 < 2^15, so a delta never wraps.
+// for any slot whose delta reaches 2^15, which a sweep checks every SWEEP_EVERY steps: between two
+// sweeps a slot gains at most SWEEP_EVERY·4·PG_WG = 24576 on top of < 2^15, so a delta never wraps.
 __device__ __forceinline__ void delta_add(uint32_t *dl, uint32_t slot) {
   atomicAdd(&dl[slot >> 1], 1u << (16 * (slot & 1)));
 }
@@ -2108,7 +2108,10 @@ __device__ __forceinline__ uint32_t pg_wg_sum(uint32_t v, uint32_t *scratch) {
 // idle) delta words, and every wave keeps its own miss queue (a slice of the page's miss_buf
 // region) with the fill level in a wave-uniform register — ballot/popcount, no atomics.
 constexpr uint32_t MISS_SLACK = 4096;  // extra records per page region of miss_buf (8 slices)
-constexpr uint32_t PG_DRAIN_EVERY = 4; // k_pages: steps (of 4 records per thread) between miss-queue drains
+#ifndef SHK_PG_DRAIN_EVERY
+#define SHK_PG_DRAIN_EVERY 4
+#endif
+constexpr uint32_t PG_DRAIN_EVERY = SHK_PG_DRAIN_EVERY; // k_pages: steps (of 4 records per thread) between miss-queue drains
 // A wave's queue is emptied at every drain, so it never holds more than the records the wave saw
 // since the last one: a page's slice of miss_buf is capped at that, however large its region is.
 constexpr uint32_t MISS_WAVE_MAX = PG_DRAIN_EVERY * 4 * 64;
@@ -2196,7 +2199,10 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
   const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(src);
   const uint32_t n_quads = (uint32_t)(n / (4 * PG_WG));  // steps of four records per thread
   constexpr uint32_t DRAIN_EVERY = PG_DRAIN_EVERY;        // steps between miss-queue drains
-  static_assert(DRAIN_EVERY * 4 * PG_WG < 0x8000, "a 16-bit delta must not wrap between checks");
+  // 16-bit deltas: a sweep moves every delta ≥ 2^15 to the 32-bit counts in HBM, so a slot starts an
+  // interval below 2^15 and gains at most SWEEP_EVERY·4·PG_WG in it (+ the tail of < 4·PG_WG records)
+  constexpr uint32_t SWEEP_EVERY = 12;
+  static_assert(0x7FFF + SWEEP_EVERY * 4 * PG_WG + 4 * PG_WG <= 0xFFFF, "a 16-bit delta must not wrap between sweeps");
   ulonglong2 nxt[2];
   if (n_quads) {
     nxt[0] = src2[threadIdx.x];
@@ -2236,10 +2242,14 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
     }
     // drain after each of the first DRAIN_EVERY steps (an empty page misses on every first
     // occurrence, and on its repeats until it is inserted), then every DRAIN_EVERY steps
+    // (no barrier: the queue is the wave's own, and a key another wave is inserting right now is at
+    // worst missed once more and found by the general probe)
     if (quad < DRAIN_EVERY || (quad % DRAIN_EVERY) == DRAIN_EVERY - 1 || quad + 1 == n_quads) {
       for (uint32_t j = lane_id; j < n_miss; j += 64) insert(mq[j]);  // this wave's own queue
       n_miss = 0;
       update_may_insert();
+    }
+    if ((quad % SWEEP_EVERY) == SWEEP_EVERY - 1) {
       __syncthreads();
       // deltas >= 2^15 go to the 32-bit counts in HBM now (a slot gains < 2^15 between checks)
       for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 2; j += PG_WG) {
