@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Experiment: k_pages time on an empty table (every first occurrence misses) vs on a table that
 already holds every key (second pass over the same reads, no reset).  Shows what miss handling costs."""
+import os
+import sys
+
 import torch
-import sharkmer_amd as sa
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sharkmer_amd as sa  # noqa: E402
 
 n_reads, L = 1_000_000, 150
 spec = sa.SynthSpec(genome_len=3_000_000, read_len=L)
