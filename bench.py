@@ -217,7 +217,7 @@ def main():
         }
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
