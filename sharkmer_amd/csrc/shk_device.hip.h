@@ -1842,9 +1842,12 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
 // packed bases" (the fan-out is small here, so 4 Ki-record tiles already give long runs).
 // Costs one more 8-B read + 8-B write per k-mer occurrence.
 // ------------------------------------------------------------------------------------------
-constexpr int RS_NT = 256;
+#ifndef SHK_RS_NT
+#define SHK_RS_NT 512  // (8 records per thread; with 256 threads the 8-byte re-scatter of config 3 took 58 ms instead of 50)
+#endif
+constexpr int RS_NT = SHK_RS_NT;
 constexpr int RS_TILE = 4096;              // records per tile: they stay in LDS (32 KiB) for the write-out
-constexpr int RS_SPAN = RS_TILE / RS_NT;   // 16 records per thread
+constexpr int RS_SPAN = RS_TILE / RS_NT;   // records per thread
 __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
     const uint64_t *__restrict__ src_buf, const unsigned int *__restrict__ src_cursor, uint32_t src_cap,
     uint32_t tiles_per_region, uint32_t log_pages, uint32_t log_sub, uint32_t key_bits,
@@ -1962,15 +1965,23 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
 // R1 = 2k - log_p1 bits of the mixed key (its super-page is the region it sits in); the page inside
 // the super-page is its top log_sub bits, and what goes on to k_pages32 is the rest.  Runs are packed
 // (no padding), two entries per lane leave as one 8-B store when they share a page.
-constexpr int RS32_TILE = 8192;                // records per tile: 32 KiB in LDS
-constexpr int RS32_SPAN = RS32_TILE / RS_NT;   // 32 records per thread
-__global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
+#ifndef SHK_RS32_TILE
+#define SHK_RS32_TILE 8192
+#endif
+#ifndef SHK_RS32_NT
+#define SHK_RS32_NT 512  // (16 records per thread; 256 threads × 32 records: re-scatter 0.64 → 0.43 ms on a 30 Mb genome)
+#endif
+constexpr int RS32_TILE = SHK_RS32_TILE;       // records per tile (4 B each in LDS)
+constexpr int RS32_NT = SHK_RS32_NT;
+constexpr int RS32_SPAN = RS32_TILE / RS32_NT;   // 32 records per thread
+static_assert(RS32_TILE <= 65536 && RS32_SPAN % 4 == 0, "16-bit entries; four records per load");
+__global__ void __launch_bounds__(RS32_NT) k_part_rescatter32(
     const uint32_t *__restrict__ src_buf, const unsigned int *__restrict__ src_cursor, uint32_t src_cap,
     uint32_t tiles_per_region, uint32_t log_sub, uint32_t r1_bits, uint32_t key_bits,
     unsigned int *__restrict__ dst_cursor, uint32_t dst_cap, uint32_t *__restrict__ dst_buf, uint32_t lane,
     DevStats *__restrict__ stats, SpillRef sp, uint64_t dst_region_base, uint64_t n_dst_total) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
-  __shared__ uint32_t wsum[RS_NT / 64];
+  __shared__ uint32_t wsum[RS32_NT / 64];
   if (stats->bad != ~0ull) return;
   const uint32_t S = 1u << log_sub;  // pages per super-page
   const uint32_t region = blockIdx.x / tiles_per_region, tile = blockIdx.x % tiles_per_region;
@@ -1984,14 +1995,14 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
   uint32_t *cnt = sh + RS32_TILE + RS32_TILE / 2;                           // S
   uint32_t *tstart = cnt + S;                                               // S
   uint32_t *gbase = tstart + S;                                             // S
-  for (uint32_t i = threadIdx.x; i < S; i += RS_NT) cnt[i] = 0;
+  for (uint32_t i = threadIdx.x; i < S; i += RS32_NT) cnt[i] = 0;
   __syncthreads();
   // ---- rank: (page-in-super-page, rank) per record, in registers; four records per 16-B load ----
   const uint32_t rbits2 = r1_bits - log_sub;  // record bits that go on to the page workgroup
   uint32_t pr[RS32_SPAN];
 #pragma unroll
   for (int q = 0; q < RS32_SPAN / 4; ++q) {
-    const uint32_t i = (uint32_t)(q * RS_NT + threadIdx.x) * 4;
+    const uint32_t i = (uint32_t)(q * RS32_NT + threadIdx.x) * 4;
     uint32_t rr[4] = {0, 0, 0, 0};
     if (i + 4 <= n) {  // (four records at a multiple of four never straddle a block)
       const uint4 v = *reinterpret_cast<const uint4 *>(src_buf + rec_slot64(region, n_src_regions, r0 + i));
@@ -2014,7 +2025,7 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
   __syncthreads();
   // ---- exclusive scan of the counts; reservation in the final page regions ---------------------
   {
-    const uint32_t per = S / RS_NT ? S / RS_NT : 1;
+    const uint32_t per = S / RS32_NT ? S / RS32_NT : 1;
     uint32_t lo = threadIdx.x * per, sacc = 0;
     if (lo < S)
       for (uint32_t i = 0; i < per; ++i) sacc += cnt[lo + i];
@@ -2022,7 +2033,7 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
     const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const uint32_t part = (ln < wv && ln < (uint32_t)(RS_NT / 64)) ? wsum[ln] : 0u;
+    const uint32_t part = (ln < wv && ln < (uint32_t)(RS32_NT / 64)) ? wsum[ln] : 0u;
     const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(part), 63);
     uint32_t run = woff + inc - sacc;
     if (lo < S)
@@ -2032,14 +2043,14 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
       }
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < S; i += RS_NT) {
+  for (uint32_t i = threadIdx.x; i < S; i += RS32_NT) {
     const uint32_t c1 = cnt[i];
     gbase[i] = (c1 ? atomicAdd(&dst_cursor[dst_region_base + ((uint64_t)region << log_sub) + i], c1) : 0u) - tstart[i];
   }
   // ---- place: entry = record index inside the tile -----------------------------------------------
 #pragma unroll
   for (int q = 0; q < RS32_SPAN / 4; ++q) {
-    const uint32_t i = (uint32_t)(q * RS_NT + threadIdx.x) * 4;
+    const uint32_t i = (uint32_t)(q * RS32_NT + threadIdx.x) * 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const uint32_t v = pr[4 * q + r];
@@ -2059,7 +2070,7 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter32(
       sp.counts[j] = 1u;
     }
   };
-  for (uint32_t i = threadIdx.x; 2 * i < n; i += RS_NT) {
+  for (uint32_t i = threadIdx.x; 2 * i < n; i += RS32_NT) {
     const uint32_t ee = sorted2[i];
     const bool two = 2 * i + 1 < n;
     const uint32_t ra = recs[ee & 0xFFFFu], rb = two ? recs[ee >> 16] : 0u;

@@ -747,14 +747,22 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     }
     if (two_level) {
       ScopedTimer t(c, SHK_K_PSCAN, /*chain=*/true);  // timer slot reused: the level-2 re-scatter
+      if (rec32 && lds_rs32 > 64 * 1024) {  // > 64 KiB of dynamic LDS has to be asked for
+        static bool rs_attr_set = false;
+        if (!rs_attr_set) {
+          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_rescatter32),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
+          rs_attr_set = true;
+        }
+      }
       if (rec32 && defer)  // append to this lane's accumulation regions
-        hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs32, c->stream,
+        hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS32_NT), lds_rs32, c->stream,
                            (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
                            log_sub, r1_bits, 2 * c->cfg.k, (unsigned int *)c->acc_cur.p, c->acc_cap,
                            (uint32_t *)c->acc_buf.p, lane, c->d_stats, sp, (uint64_t)lane * n_pages,
                            (uint64_t)NL * n_pages);
       else if (rec32)
-        hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs32, c->stream,
+        hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS32_NT), lds_rs32, c->stream,
                            (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
                            log_sub, r1_bits, 2 * c->cfg.k, cursor_pg, cap_pg, (uint32_t *)buf_pg.p, lane,
                            c->d_stats, sp, 0ull, (uint64_t)n_pages);
