@@ -108,6 +108,7 @@ struct shk_ctx {
   // scratch
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_done[2] = {nullptr, nullptr};
+  bool lds_attr_scatter = false, lds_attr_rescatter = false;  // hipFuncSetAttribute done for this context's device
   HostBuf h_rebased[2];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
   DevBuf in_bases, in_offsets, in_bases2, in_offsets2, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
   // host counters
@@ -713,13 +714,12 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       ScopedTimer t(c, SHK_K_SCATTER, /*chain=*/prezeroed && lane == lane_lo && c->chain_from_mark);
       c->chain_from_mark = false;
       if (rec32 && lds32) {
-        static bool attr_set = false;  // > 64 KiB of dynamic LDS has to be asked for
-        if (!attr_set) {
+        if (!c->lds_attr_scatter) {  // > 64 KiB of dynamic LDS has to be asked for, once per device (= per context)
           HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
           HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
-          attr_set = true;
+          c->lds_attr_scatter = true;
         }
         if (defer && !two_level && acc_wide)  // straight into the accumulation regions, (lane, page) layout
           hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, true>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
@@ -748,11 +748,10 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     if (two_level) {
       ScopedTimer t(c, SHK_K_PSCAN, /*chain=*/true);  // timer slot reused: the level-2 re-scatter
       if (rec32 && lds_rs32 > 64 * 1024) {  // > 64 KiB of dynamic LDS has to be asked for
-        static bool rs_attr_set = false;
-        if (!rs_attr_set) {
+        if (!c->lds_attr_rescatter) {
           HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_rescatter32),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
-          rs_attr_set = true;
+          c->lds_attr_rescatter = true;
         }
       }
       if (rec32 && defer)  // append to this lane's accumulation regions
