@@ -30,6 +30,44 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_all_cores(orc, hb, ho, k, histo_max, n_bases):
+    """The CPU oracle on every host core (at most 16, a one-GPU box's share): contiguous shards of
+    the reads counted in threads (ctypes releases the GIL), then merged sequentially."""
+    from concurrent.futures import ThreadPoolExecutor
+    T = max(1, min(os.cpu_count() or 1, 16))
+    n = len(ho) - 1
+    cuts = [n * i // T for i in range(T + 1)]
+
+    def one(i):
+        a, b = cuts[i], cuts[i + 1]
+        return orc.run_batch(hb[int(ho[a]):int(ho[b])], ho[a:b + 1] - ho[a], k, 0, histo_max)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(T) as ex:
+        runs = list(ex.map(one, range(T)))
+    dst = runs[0].merged()
+    for r in runs[1:]:
+        dst.extend(r.merged())
+    h = orc.Histogram.from_kmer_counts(dst, histo_max)
+    n_unique = h.get_n_unique_kmers()
+    dt = time.perf_counter() - t0
+    del runs
+    return {"value": round(n_bases / dt / 1e9, 5), "unit": "Gbases/s", "cores": T, "kind": "port",
+            "sample": f"the same batch sharded over {T} threads, tables merged sequentially, one histogram "
+                      f"({n_unique} distinct k-mers)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,7 +218,7 @@ def main():
         path_roof = {"alg_bytes_per_step": int(b_alg), "device_ms_per_step": round(path_ms, 4),
                      "achieved_GBps": round(b_alg / (path_ms * 1e-3) / 1e9, 1) if path_ms else None,
                      "frac": round(b_alg / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if path_ms else None}
-        cpu = None
+        cpu = cpu_all = None
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             ns = args.cpu_sample_reads or n_reads
@@ -192,6 +230,11 @@ def main():
                    "kind": "port",
                    "sample": f"{ns} reads x {L} bp of the step batch (rank 0 shard), "
                              f"single-threaded C restatement of sharkmer's counting path"}
+            cpu["cpu_model"] = cpu_model()
+            # context only: the same restatement on all host cores — reads sharded over
+            # threads, the per-thread tables merged one after the other (KmerCounts::extend), one
+            # histogram of the merged table.  The reference itself counts on one thread.
+            cpu_all = cpu_all_cores(orc, hb, ho, args.k, args.histo_max, ns * L)
             if world == 1 and ns == n_reads:
                 exact = bool(np.array_equal(hist, ref.histograms()))
                 cpu["histogram_bit_exact"] = exact
@@ -209,7 +252,7 @@ def main():
                                    f"step = reset + count + histogram emit, input resident in HBM",
                        "reads_per_gpu": n_reads, "k": args.k, "chunks": args.chunks,
                        "genome": genome, "path": args.path},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "roofline_path": path_roof, "kernels": per_kernel,
             "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in tim.items()},
             "table": {"capacity": cnt["table_capacity"], "n_unique": cnt["n_unique_kmers"],
