@@ -808,6 +808,10 @@ struct HistoTotals {
 };
 
 constexpr int HISTO_WG = 1024;  // few, large workgroups: the flush of a workgroup's bins is what contends
+// KEYS = false: occupancy is read off the counts — a slot holds a key exactly when its counts are not
+// all zero, unless a key was inserted with count 0 (shk_insert_counts can; the host then asks for
+// KEYS = true) — so the scan reads 4 B per slot and lane instead of 8 + 4.
+template <bool KEYS>
 __global__ void __launch_bounds__(HISTO_WG) k_histo(TableRef tb, uint64_t slot0, uint64_t slot1,
                                               uint64_t histo_max, uint32_t n_cols,
                                               uint32_t lds_bins,
@@ -824,14 +828,18 @@ __global__ void __launch_bounds__(HISTO_WG) k_histo(TableRef tb, uint64_t slot0,
   // all loads issued before any is consumed (slot0/slot1 are multiples of PAGE_SLOTS)
   for (uint64_t s = slot0 + ((uint64_t)blockIdx.x * HISTO_WG + threadIdx.x) * 4; s < slot1;
        s += (uint64_t)gridDim.x * HISTO_WG * 4) {
-    ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(tb.keys + s);
-    ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(tb.keys + s + 2);
     uint32_t cum[4] = {0, 0, 0, 0};
-    const bool occ[4] = {ka.x != EMPTY, ka.y != EMPTY, kb.x != EMPTY, kb.y != EMPTY};
-    if (!(occ[0] | occ[1] | occ[2] | occ[3])) continue;
+    bool occ[4] = {true, true, true, true};
+    if (KEYS) {
+      const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(tb.keys + s);
+      const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(tb.keys + s + 2);
+      occ[0] = ka.x != EMPTY, occ[1] = ka.y != EMPTY, occ[2] = kb.x != EMPTY, occ[3] = kb.y != EMPTY;
+      if (!(occ[0] | occ[1] | occ[2] | occ[3])) continue;
+    }
     for (uint32_t l = 0; l < tb.n_lanes; ++l) {
       uint4 v4 = *reinterpret_cast<const uint4 *>(tb.vals + (uint64_t)l * tb.cap + s);
       const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+      if (!KEYS && tb.n_lanes == 1 && !(v4.x | v4.y | v4.z | v4.w)) break;  // four empty slots
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (!occ[q]) continue;
@@ -848,7 +856,7 @@ __global__ void __launch_bounds__(HISTO_WG) k_histo(TableRef tb, uint64_t slot0,
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (!occ[q]) continue;
+      if (KEYS ? !occ[q] : cum[q] == 0) continue;
       n_unique++;
       n_hashed += cum[q];
       sat |= (cum[q] == 0xFFFFFFFFu);

@@ -108,6 +108,7 @@ struct shk_ctx {
   // scratch
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_done[2] = {nullptr, nullptr};
+  bool zero_count_keys = false;   // some key may have been inserted with count 0 (shk_insert_counts, merges): k_histo reads the keys
   bool lds_attr_scatter = false, lds_attr_rescatter = false;  // hipFuncSetAttribute done for this context's device
   HostBuf h_rebased[2];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
   DevBuf in_bases, in_offsets, in_bases2, in_offsets2, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
@@ -1077,6 +1078,7 @@ int shk_reset(shk_ctx *c) {
   c->n_reads_read = c->n_bases_read = 0;
   c->n_inserted = 0;
   c->own_set = false;
+  c->zero_count_keys = false;
   c->finalized = c->poisoned = false;
   c->unsettled = false;  // the memsets above are ordered behind any launch still in flight
   c->acc_active = false;  // (the regions' cursors are cleared when they are planned again)
@@ -1204,9 +1206,11 @@ int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, cons
   HIPC(c, hipSetDevice(c->cfg.device));
   c->finalized = false;
   const uint64_t kmax = c->cfg.k >= 32 ? ~0ull : ((1ull << (2 * c->cfg.k)) - 1);
-  for (uint64_t i = 0; i < n; ++i)
+  for (uint64_t i = 0; i < n; ++i) {
     if (kmers[i] > kmax) return fail(c, SHK_ERR_BAD_ARG, "kmer %llu does not fit k=%u",
                                      (unsigned long long)kmers[i], c->cfg.k);
+    if (counts[i] == 0) c->zero_count_keys = true;  // counting.rs:152-154 creates the entry all the same
+  }
   int rc = ensure_capacity(c, n);
   if (rc != SHK_OK) return rc;
   c->n_inserted += n;
@@ -1263,9 +1267,14 @@ int shk_finalize(shk_ctx *c) {
   if (n_cols && (uint64_t)lds_bins * n_cols * 4 > 65536) lds_bins = 65536 / 4 / n_cols;
   {
     ScopedTimer t(c, SHK_K_HISTO);
-    hipLaunchKernelGGL(k_histo, dim3(grid_for(s1 - s0, HISTO_WG * 16, 256)), dim3(HISTO_WG),
-                       (size_t)lds_bins * n_cols * 4, c->stream, c->tb, s0, s1, c->cfg.histo_max,
-                       n_cols, lds_bins, c->d_hist, c->d_tot);
+    if (c->zero_count_keys)  // a key may sit in the table with count 0: occupancy has to come from the keys
+      hipLaunchKernelGGL(k_histo<true>, dim3(grid_for(s1 - s0, HISTO_WG * 16, 256)), dim3(HISTO_WG),
+                         (size_t)lds_bins * n_cols * 4, c->stream, c->tb, s0, s1, c->cfg.histo_max,
+                         n_cols, lds_bins, c->d_hist, c->d_tot);
+    else
+      hipLaunchKernelGGL(k_histo<false>, dim3(grid_for(s1 - s0, HISTO_WG * 16, 256)), dim3(HISTO_WG),
+                         (size_t)lds_bins * n_cols * 4, c->stream, c->tb, s0, s1, c->cfg.histo_max,
+                         n_cols, lds_bins, c->d_hist, c->d_tot);
   }
   // One copy brings back the whole control block (launch outcome, totals, non-N base counts,
   // histogram), and one host sync serves both the last counting launch and the scan: the scan
@@ -1635,6 +1644,7 @@ int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, co
     if (rcs != SHK_OK) return rcs;
   }
   c->finalized = false;
+  c->zero_count_keys = true;  // (a peer's table may hold keys inserted with count 0: keep reading the keys)
   const uint64_t n_slots = (p1 - p0) << PAGE_LOG;
   // worst case every peer key is new here
   HIPC(c, c->spillA.ensure(n_slots * c->n_lanes * 16));
@@ -1700,6 +1710,7 @@ int shk_merge_entries(shk_ctx *c, const void *d_keys, const void *d_vals, uint64
     if (rcs != SHK_OK) return rcs;
   }
   c->finalized = false;
+  c->zero_count_keys = true;  // (a peer's table may hold keys inserted with count 0: keep reading the keys)
   HIPC(c, c->spillA.ensure(n * c->n_lanes * 16));  // worst case every entry spills on every lane
   SpillRef sp = spill_ref(c->spillA, n * c->n_lanes);
   HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));

@@ -84,6 +84,20 @@ def test_histogram_kat():
         assert list(eng.histograms()[0]) == [0, 0, 0, 0, 0, 2, 0, 1, 0, 0, 0, 2]
 
 
+def test_insert_with_count_zero_keeps_the_key():
+    """counting.rs:152-154: insert(kmer, 0) creates the entry, so it is a unique k-mer of the table
+    (counting.rs:258-260) that sits in no histogram bin (move_count(0, 0) is a no-op, histogram.rs:51-55)
+    — the reference's own invariant io.rs:1120-1132 then fails.  The histogram scan must take
+    occupancy from the keys here, not from the counts."""
+    with sa.KmerEngine(11, 1, 10) as eng:
+        eng.insert([1, 20, 2, 11], [0, 5, 0, 11])
+        assert list(eng.lookup([1, 20, 2, 11, 7])) == [0, 5, 0, 11, 0]
+        with pytest.raises(sa.ShkError, match="unique kmers in the histogram"):
+            eng.finalize()
+        ks, cs = eng.export_table()
+        assert sorted(zip(ks.tolist(), cs.tolist())) == [(1, 0), (2, 0), (11, 11), (20, 5)]
+
+
 def test_insert_accumulates_and_saturates():
     """counting.rs:384-399."""
     with sa.KmerEngine(5, 1, 10) as eng:
