@@ -826,8 +826,41 @@ __global__ void __launch_bounds__(HISTO_WG) k_histo(TableRef tb, uint64_t slot0,
   unsigned long long n_unique = 0, n_hashed = 0, n_lane = 0, sat = 0;
   // four consecutive slots per thread per step: keys as 2×16 B, each lane's counts as 16 B,
   // all loads issued before any is consumed (slot0/slot1 are multiples of PAGE_SLOTS)
-  for (uint64_t s = slot0 + ((uint64_t)blockIdx.x * HISTO_WG + threadIdx.x) * 4; s < slot1;
-       s += (uint64_t)gridDim.x * HISTO_WG * 4) {
+  const uint64_t stride = (uint64_t)gridDim.x * HISTO_WG * 4;
+  uint64_t s = slot0 + ((uint64_t)blockIdx.x * HISTO_WG + threadIdx.x) * 4;
+  if (!KEYS && tb.n_lanes == 1 && n_cols <= 1) {
+    // One chunk lane, counts only: a step is a single 16-B load, far too little in flight for a scan
+    // — four steps' loads are issued together.
+    auto one = [&](const uint4 &v4) {
+      const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (v[q] == 0) continue;
+        n_lane += v[q];
+        n_unique++;
+        n_hashed += v[q];
+        sat |= (v[q] == 0xFFFFFFFFu);
+        if (n_cols) {
+          const uint64_t bin = v[q] <= histo_max ? v[q] : histo_max + 1;
+          if (bin < lds_bins)
+            atomicAdd(&lh[(uint32_t)bin], 1u);
+          else
+            atomicAdd(&hist[bin], 1ull);
+        }
+      }
+    };
+    for (; s + 3 * stride < slot1; s += 4 * stride) {
+      const uint4 a0 = *reinterpret_cast<const uint4 *>(tb.vals + s);
+      const uint4 a1 = *reinterpret_cast<const uint4 *>(tb.vals + s + stride);
+      const uint4 a2 = *reinterpret_cast<const uint4 *>(tb.vals + s + 2 * stride);
+      const uint4 a3 = *reinterpret_cast<const uint4 *>(tb.vals + s + 3 * stride);
+      one(a0);
+      one(a1);
+      one(a2);
+      one(a3);
+    }
+  }
+  for (; s < slot1; s += stride) {
     uint32_t cum[4] = {0, 0, 0, 0};
     bool occ[4] = {true, true, true, true};
     if (KEYS) {
@@ -836,21 +869,28 @@ __global__ void __launch_bounds__(HISTO_WG) k_histo(TableRef tb, uint64_t slot0,
       occ[0] = ka.x != EMPTY, occ[1] = ka.y != EMPTY, occ[2] = kb.x != EMPTY, occ[3] = kb.y != EMPTY;
       if (!(occ[0] | occ[1] | occ[2] | occ[3])) continue;
     }
-    for (uint32_t l = 0; l < tb.n_lanes; ++l) {
-      uint4 v4 = *reinterpret_cast<const uint4 *>(tb.vals + (uint64_t)l * tb.cap + s);
-      const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-      if (!KEYS && tb.n_lanes == 1 && !(v4.x | v4.y | v4.z | v4.w)) break;  // four empty slots
+    for (uint32_t l0 = 0; l0 < tb.n_lanes; l0 += 4) {  // four lanes' counts in flight together
+      uint4 vv[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (!occ[q]) continue;
-        n_lane += v[q];
-        cum[q] = sat_add_u32(cum[q], v[q]);
-        if (l < n_cols && cum[q] > 0) {
-          uint64_t bin = cum[q] <= histo_max ? cum[q] : histo_max + 1;
-          if (bin < lds_bins)
-            atomicAdd(&lh[l * lds_bins + (uint32_t)bin], 1u);
-          else
-            atomicAdd(&hist[(uint64_t)l * hlen + bin], 1ull);
+      for (int j = 0; j < 4; ++j)
+        if (l0 + j < tb.n_lanes) vv[j] = *reinterpret_cast<const uint4 *>(tb.vals + (uint64_t)(l0 + j) * tb.cap + s);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t l = l0 + j;
+        if (l >= tb.n_lanes) break;
+        const uint32_t v[4] = {vv[j].x, vv[j].y, vv[j].z, vv[j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!occ[q]) continue;
+          n_lane += v[q];
+          cum[q] = sat_add_u32(cum[q], v[q]);
+          if (l < n_cols && cum[q] > 0) {
+            uint64_t bin = cum[q] <= histo_max ? cum[q] : histo_max + 1;
+            if (bin < lds_bins)
+              atomicAdd(&lh[l * lds_bins + (uint32_t)bin], 1u);
+            else
+              atomicAdd(&hist[(uint64_t)l * hlen + bin], 1ull);
+          }
         }
       }
     }
