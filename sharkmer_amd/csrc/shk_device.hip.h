@@ -2394,8 +2394,14 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
   uint32_t *gv = nullptr;  // this lane's counts of the page (set per lane below)
   // page keys → tags, counting occupied slots on the way
   uint32_t my_occ = 0;
-  for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 2; i += PG_WG) {
-    const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(gk)[i];
+  constexpr int LD = PAGE_SLOTS / 2 / PG_WG;  // 16-B loads per thread: all issued before the first is used
+  ulonglong2 pv[LD];
+#pragma unroll
+  for (int u = 0; u < LD; ++u) pv[u] = reinterpret_cast<const ulonglong2 *>(gk)[threadIdx.x + u * PG_WG];
+#pragma unroll
+  for (int u = 0; u < LD; ++u) {
+    const uint32_t i = threadIdx.x + u * PG_WG;
+    const ulonglong2 v = pv[u];
     const uint64_t kv[2] = {v.x, v.y};
     uint32_t tg[2];
 #pragma unroll
