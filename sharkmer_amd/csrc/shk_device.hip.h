@@ -2048,12 +2048,18 @@ __global__ void __launch_bounds__(RS32_NT) k_part_rescatter32(
   // ---- rank: (page-in-super-page, rank) per record, in registers; four records per 16-B load ----
   const uint32_t rbits2 = r1_bits - log_sub;  // record bits that go on to the page workgroup
   uint32_t pr[RS32_SPAN];
+  uint4 pre[RS32_SPAN / 4];  // this thread's full quads, all loads issued before the first is used
+#pragma unroll
+  for (int q = 0; q < RS32_SPAN / 4; ++q) {
+    const uint32_t i = (uint32_t)(q * RS32_NT + threadIdx.x) * 4;
+    if (i + 4 <= n) pre[q] = *reinterpret_cast<const uint4 *>(src_buf + rec_slot64(region, n_src_regions, r0 + i));
+  }
 #pragma unroll
   for (int q = 0; q < RS32_SPAN / 4; ++q) {
     const uint32_t i = (uint32_t)(q * RS32_NT + threadIdx.x) * 4;
     uint32_t rr[4] = {0, 0, 0, 0};
     if (i + 4 <= n) {  // (four records at a multiple of four never straddle a block)
-      const uint4 v = *reinterpret_cast<const uint4 *>(src_buf + rec_slot64(region, n_src_regions, r0 + i));
+      const uint4 v = pre[q];
       rr[0] = v.x, rr[1] = v.y, rr[2] = v.z, rr[3] = v.w;
       *reinterpret_cast<uint4 *>(recs + i) = v;
     } else {
