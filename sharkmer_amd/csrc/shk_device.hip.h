@@ -1747,6 +1747,10 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
         x.r_lo = (uint32_t)r0;
         x.r_hi = (uint32_t)(r0 >> 32);
       }
+      // (two copies of the loop: with 32-bit records — k = 21 on 1024 pages — page and record are
+      // simply the two words of the mixed key)
+      auto walk = [&](auto rb32_t) {
+      constexpr bool RB32 = decltype(rb32_t)::value;
 #pragma unroll
       for (int q = 0; q < SPAN / 8; ++q) {
         uint64_t w = 0;
@@ -1764,13 +1768,17 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
           const uint64_t fwd = ((uint64_t)x.f_hi << 32) | x.f_lo;
           const uint64_t rev = (((uint64_t)x.r_hi << 32) | x.r_lo) >> (64 - 2 * k);
           const uint64_t y = mix_key(rev < fwd ? rev : fwd, 2 * k);
-          pcs[r] = (c & 4u) ? (uint32_t)(y >> rbits) : P + (threadIdx.x & 7u);
-          recs[(q * 8 + r) * NT + threadIdx.x] = (uint32_t)y & rmask;  // transposed: no bank conflicts
+          const uint32_t page = RB32 ? (uint32_t)(y >> 32) : (uint32_t)(y >> rbits);
+          pcs[r] = (c & 4u) ? page : P + (threadIdx.x & 7u);
+          recs[(q * 8 + r) * NT + threadIdx.x] = RB32 ? (uint32_t)y : (uint32_t)y & rmask;  // transposed: no bank conflicts
           rks[r] = atomicAdd(&cnt[pcs[r]], 1u);  // rank < 2^14
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) pr[q * 8 + r] = pcs[r] >= P ? 0xFFFFFFFFu : (pcs[r] << 16) | rks[r];
       }
+      };
+      if (rbits == 32) walk(std::true_type{});
+      else walk(std::false_type{});
     }
     __syncthreads();
     STAMP(2);
