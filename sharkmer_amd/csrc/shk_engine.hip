@@ -514,7 +514,7 @@ static bool use_rec32(const shk_ctx *c, const PartGeom &g) {
 constexpr int SC32_NT = 1024, SC32_TT = 16384;  // k_scatter32: 64 KiB of records + 64 KiB of entries in LDS,
 constexpr size_t SC32_LDS_MAX = 160 * 1024 - 1024;  // one workgroup per CU (its static LDS is < 1 KiB)
 static size_t scatter32_lds(uint32_t P1) {
-  return (size_t)SC32_TT * 8 + ((size_t)(SC32_TT + HALO) / 16 + 2) * 4 + (size_t)P1 * 12;
+  return (size_t)SC32_TT * 8 + ((size_t)(SC32_TT + HALO) / 16 + 2) * 4 + (size_t)P1 * 12 + 32;  // (+ the walk's 8 spare counters when P1 < 8)
 }
 // records-in-LDS scatter (k_scatter32: one 1024-thread workgroup per CU) when its LDS footprint fits
 static bool use_scatter32(const shk_ctx *c, const PartGeom &g) {
@@ -695,7 +695,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   HIPC(c, c->misc.ensure((size_t)G * 64));
   dbg = (unsigned long long *)c->misc.p;
 #endif
-  const size_t lds_sorted = (size_t)sort_region_bytes(P1) + (size_t)PACK_WORDS * 8 + (size_t)P1 * 12;
+  const size_t lds_sorted = (size_t)sort_region_bytes(P1) + (size_t)PACK_WORDS * 8 + (size_t)P1 * 12 + 32;  // (+ the walk's 8 spare counters when P1 < 8)
   const uint32_t S = 1u << log_sub;
   const size_t lds_rs = (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12;
   const size_t lds_s32 = scatter32_lds(P1);
