@@ -84,6 +84,40 @@ def test_histogram_kat():
         assert list(eng.histograms()[0]) == [0, 0, 0, 0, 0, 2, 0, 1, 0, 0, 0, 2]
 
 
+def test_reset_reopens_an_empty_context(orc):
+    """shk_reset: the context is as new (table, counters, read index, histogram) whatever was in it, and
+    whatever is called first afterwards — a read of the table, an insert, an ingest."""
+    spec = sa.SynthSpec(genome_len=40_000, sub_per_64k=200, n_per_64k=50)
+    bases, offsets = sa.synth_reads(spec, 0, 6_000)
+    ref = orc.run_batch(bases, offsets, 15, 3, 50)
+    rk, rc = ref.merged().export()
+    with sa.KmerEngine(15, 3, 50, capacity_hint=60_000) as eng:
+        for first in ("lookup", "insert", "ingest", "export", "finalize"):
+            eng.ingest_reads(bases[:int(offsets[2_500])], offsets[:2_501])   # something to forget
+            if first != "ingest":
+                eng.finalize()
+            eng.reset()
+            if first == "lookup":
+                assert not eng.lookup(rk[:200]).any()
+            elif first == "insert":
+                eng.insert([int(rk[0])], [3])
+                assert list(eng.lookup(rk[:2])) == [3, 0]
+                eng.reset()
+            elif first == "export":
+                ks, cs = eng.export_table()
+                assert len(ks) == 0
+            elif first == "finalize":
+                with pytest.raises(sa.ShkError, match="No reads were ingested"):
+                    eng.finalize()
+            eng.ingest_reads(bases, offsets)
+            eng.finalize()
+            assert np.array_equal(eng.histograms(), ref.histograms()), first
+            c = eng.counters()
+            assert c["n_kmers_ingested"] == ref.stats["n_kmers_ingested"] and c["n_reads_ingested"] == 6_000
+            gk, gc = eng.export_table()
+            assert np.array_equal(gk, rk) and np.array_equal(gc, rc), first
+
+
 def test_insert_with_count_zero_keeps_the_key():
     """counting.rs:152-154: insert(kmer, 0) creates the entry, so it is a unique k-mer of the table
     (counting.rs:258-260) that sits in no histogram bin (move_count(0, 0) is a no-op, histogram.rs:51-55)
