@@ -1654,9 +1654,12 @@ __device__ __forceinline__ void place_entries(uint32_t *__restrict__ sorted, con
   }
 }
 
-template <int NT, int TT, bool WIDE>
+// LOGP: the fan-out as a compile-time constant (0 = log_parts_ at run time).  1024 partitions — one per
+// thread — is what every table from 8 M slots up gets (one level up to 4096 pages aside), so the
+// scan, reserve and place phases are specialised for it.
+template <int NT, int TT, bool WIDE, int LOGP = 0>
 __global__ void __launch_bounds__(NT, 4) k_scatter32(
-    BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
+    BatchRef b, uint32_t log_parts_, uint32_t lane_filter, unsigned int *__restrict__ cursor,
     uint32_t cap_p, uint32_t *__restrict__ part_buf32, DevStats *__restrict__ stats,
     unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg,
     uint32_t n_region_lanes) {
@@ -1671,6 +1674,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   static_assert(TILE_T % TT == 0 && TT % (8 * NT) == 0 && 4 * TT >= TT + HALO + 4 * ((TT + HALO) / 16), "tile shape");
   constexpr int SPAN = TT / NT;
   constexpr int GROUPS = (TT + HALO) / 16;
+  const uint32_t log_parts = LOGP ? (uint32_t)LOGP : log_parts_;
   const uint32_t P = 1u << log_parts;
   uint8_t *codes = reinterpret_cast<uint8_t *>(sh);  // staged tile; dead once the walk is over
   uint32_t *sorted = sh;                             // TT entries; aliases codes

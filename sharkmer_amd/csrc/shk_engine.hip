@@ -720,20 +720,30 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
           HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
+          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, false, 10>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
+          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, true, 10>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
           c->lds_attr_scatter = true;
         }
         if (defer && !two_level && acc_wide)  // straight into the accumulation regions, (lane, page) layout
-          hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, true>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
+          { if (log_p1 == 10) hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, true, 10>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
                              lds_s32, c->stream, b, log_p1, 0xFFFFFFFFu, (unsigned int *)c->acc_cur.p, c->acc_cap,
-                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL);
+                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); else hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, true>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
+                             lds_s32, c->stream, b, log_p1, 0xFFFFFFFFu, (unsigned int *)c->acc_cur.p, c->acc_cap,
+                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); }
         else if (defer && !two_level)
-          hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
+          { if (log_p1 == 10) hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false, 10>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
                              lds_s32, c->stream, b, log_p1, 0xFFFFFFFFu, (unsigned int *)c->acc_cur.p, c->acc_cap,
-                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL);
+                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); else hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
+                             lds_s32, c->stream, b, log_p1, 0xFFFFFFFFu, (unsigned int *)c->acc_cur.p, c->acc_cap,
+                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); }
         else
-          hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
+          { if (log_p1 == 10) hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false, 10>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
                              lds_s32, c->stream, b, log_p1, all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1,
-                             (uint32_t *)c->part.p, c->d_stats, c->d_lane_bases, sp, dbg, NL);
+                             (uint32_t *)c->part.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); else hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
+                             lds_s32, c->stream, b, log_p1, all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1,
+                             (uint32_t *)c->part.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); }
       } else if (rec32)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, true>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
