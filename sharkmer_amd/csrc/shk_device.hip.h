@@ -1657,7 +1657,9 @@ __device__ __forceinline__ void place_entries(uint32_t *__restrict__ sorted, con
 // LOGP: the fan-out as a compile-time constant (0 = log_parts_ at run time).  1024 partitions — one per
 // thread — is what every table from 8 M slots up gets (one level up to 4096 pages aside), so the
 // scan, reserve and place phases are specialised for it.
-template <int NT, int TT, bool WIDE, int LOGP = 0>
+// ALL: ALL-LANES mode (lane_filter = ~0) as a compile-time constant: with one lane and LOGP the number
+// of regions is an immediate and rec_slot a shift and an or.
+template <int NT, int TT, bool WIDE, int LOGP = 0, bool ALL = false>
 __global__ void __launch_bounds__(NT, 4) k_scatter32(
     BatchRef b, uint32_t log_parts_, uint32_t lane_filter, unsigned int *__restrict__ cursor,
     uint32_t cap_p, uint32_t *__restrict__ part_buf32, DevStats *__restrict__ stats,
@@ -1669,7 +1671,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   __shared__ unsigned long long lane_nn[64];  // ALL-LANES mode: non-N bases per chunk lane (n_lanes ≤ 64 here)
   // lane_filter = ~0: ALL-LANES mode — one pass over the tiles of every chunk lane; region and cursor
   // index = lane · P + page (n_region_lanes · P regions, block-interleaved together)
-  const bool all_lanes = lane_filter == 0xFFFFFFFFu;
+  constexpr bool all_lanes = ALL;  // (the host picks the variant from lane_filter == ~0)
   if (all_lanes && threadIdx.x < 64) lane_nn[threadIdx.x] = 0;
   static_assert(TILE_T % TT == 0 && TT % (8 * NT) == 0 && 4 * TT >= TT + HALO + 4 * ((TT + HALO) / 16), "tile shape");
   constexpr int SPAN = TT / NT;

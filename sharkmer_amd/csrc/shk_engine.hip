@@ -641,6 +641,39 @@ static int prepare_cursors(shk_ctx *c, bool multi, bool defer, uint32_t *n_words
   return SHK_OK;
 }
 
+// k_scatter32 is compiled in eight variants — 64-bit offsets into the accumulation buffer or not; the
+// fan-out of 1024 (one partition per thread: what every table from 8 M slots up gets) as a compile-time
+// constant or any fan-out at run time; one chunk lane or all of them in one pass — and asks for more
+// than 64 KiB of dynamic LDS, which has to be allowed per function and device.
+template <bool W, int LP, bool A>
+static hipError_t scatter32_variant(shk_ctx *c, bool set_attr, uint32_t G, size_t lds, const BatchRef &b, uint32_t log_p1,
+                                    uint32_t lane_filter, unsigned int *cursor, uint32_t cap, uint32_t *buf, SpillRef sp,
+                                    unsigned long long *dbg, uint32_t NL) {
+  if (set_attr)
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, W, LP, A>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX);
+  hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, W, LP, A>), dim3(G), dim3(SC32_NT), lds, c->stream, b, log_p1,
+                     lane_filter, cursor, cap, buf, c->d_stats, c->d_lane_bases, sp, dbg, NL);
+  return hipSuccess;
+}
+static int launch_scatter32(shk_ctx *c, bool wide, uint32_t G, size_t lds, const BatchRef &b, uint32_t log_p1,
+                            uint32_t lane_filter, unsigned int *cursor, uint32_t cap, uint32_t *buf, SpillRef sp,
+                            unsigned long long *dbg, uint32_t NL) {
+  const bool all = lane_filter == 0xFFFFFFFFu, p10 = log_p1 == 10;
+  auto each = [&](bool set_attr, bool w, bool p, bool a) -> hipError_t {
+#define SHK_V(W, LP, A) scatter32_variant<W, LP, A>(c, set_attr, G, lds, b, log_p1, lane_filter, cursor, cap, buf, sp, dbg, NL)
+    if (w) return p ? (a ? SHK_V(true, 10, true) : SHK_V(true, 10, false)) : (a ? SHK_V(true, 0, true) : SHK_V(true, 0, false));
+    return p ? (a ? SHK_V(false, 10, true) : SHK_V(false, 10, false)) : (a ? SHK_V(false, 0, true) : SHK_V(false, 0, false));
+#undef SHK_V
+  };
+  if (!c->lds_attr_scatter) {
+    for (int v = 0; v < 8; ++v) HIPC(c, each(true, v & 1, v & 2, v & 4));
+    c->lds_attr_scatter = true;
+  }
+  HIPC(c, each(false, wide, p10, all));
+  return SHK_OK;
+}
+
 static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed, bool defer) {
   const PartGeom pg = part_geom(c);
   const uint32_t lp = pg.lp, n_pages = pg.n_pages, log_p1 = pg.log_p1, log_sub = pg.log_sub, P1 = pg.P1;
@@ -715,35 +748,14 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       ScopedTimer t(c, SHK_K_SCATTER, /*chain=*/prezeroed && lane == lane_lo && c->chain_from_mark);
       c->chain_from_mark = false;
       if (rec32 && lds32) {
-        if (!c->lds_attr_scatter) {  // > 64 KiB of dynamic LDS has to be asked for, once per device (= per context)
-          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
-          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
-          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, false, 10>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
-          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, true, 10>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
-          c->lds_attr_scatter = true;
-        }
-        if (defer && !two_level && acc_wide)  // straight into the accumulation regions, (lane, page) layout
-          { if (log_p1 == 10) hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, true, 10>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
-                             lds_s32, c->stream, b, log_p1, 0xFFFFFFFFu, (unsigned int *)c->acc_cur.p, c->acc_cap,
-                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); else hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, true>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
-                             lds_s32, c->stream, b, log_p1, 0xFFFFFFFFu, (unsigned int *)c->acc_cur.p, c->acc_cap,
-                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); }
-        else if (defer && !two_level)
-          { if (log_p1 == 10) hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false, 10>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
-                             lds_s32, c->stream, b, log_p1, 0xFFFFFFFFu, (unsigned int *)c->acc_cur.p, c->acc_cap,
-                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); else hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
-                             lds_s32, c->stream, b, log_p1, 0xFFFFFFFFu, (unsigned int *)c->acc_cur.p, c->acc_cap,
-                             (uint32_t *)c->acc_buf.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); }
+        int rcl;
+        if (defer && !two_level)  // straight into the accumulation regions, (lane, page) layout
+          rcl = launch_scatter32(c, acc_wide != 0, std::min<uint32_t>(G, c->n_cus), lds_s32, b, log_p1, 0xFFFFFFFFu,
+                                 (unsigned int *)c->acc_cur.p, c->acc_cap, (uint32_t *)c->acc_buf.p, sp, dbg, NL);
         else
-          { if (log_p1 == 10) hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false, 10>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
-                             lds_s32, c->stream, b, log_p1, all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1,
-                             (uint32_t *)c->part.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); else hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false>), dim3(std::min<uint32_t>(G, c->n_cus)), dim3(SC32_NT),
-                             lds_s32, c->stream, b, log_p1, all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1,
-                             (uint32_t *)c->part.p, c->d_stats, c->d_lane_bases, sp, dbg, NL); }
+          rcl = launch_scatter32(c, false, std::min<uint32_t>(G, c->n_cus), lds_s32, b, log_p1,
+                                 all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1, (uint32_t *)c->part.p, sp, dbg, NL);
+        if (rcl != SHK_OK) return rcl;
       } else if (rec32)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, true>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
