@@ -89,8 +89,13 @@ constexpr uint32_t MAX_LOG_PAGES = 20;  // page bits + the 11 home-bucket bits â
 // table â€” page = top log_pages bits, home bucket = next 11 bits â€” together with the remaining
 // low bits identifies the key.  The 4-byte-record path of the paged counter ships only those
 // low bits and rebuilds a key with unmix_key when it has to.
-constexpr uint64_t MIX_M1 = 0x9E3779B97F4A7C15ull, MIX_M2 = 0xD6E8FEB86659FD93ull;
-constexpr uint64_t MIX_M1_INV = 0xF1DE83E19937733Dull, MIX_M2_INV = 0xCFEE444D8B59A89Bull;  // mod 2^64
+// The multipliers are 32-bit odd numbers on purpose: a 64-bit product by one of them is one
+// v_mad_u64_u32 + one v_mul_lo_u32 instead of the four instructions a 64-bit constant costs, in a
+// kernel (k_scatter32) that is bound by VALU issue; tools/hash_eval.py shows the same Poisson-like
+// page and bucket occupancy as with 64-bit constants.
+constexpr uint64_t MIX_M1 = 0x9E3779B1ull, MIX_M2 = 0x85EBCA6Bull;
+constexpr uint64_t MIX_M1_INV = 0xCFA4A56B0E8B2F51ull, MIX_M2_INV = 0x000A7324A5CB9243ull;  // mod 2^64
+static_assert((MIX_M1 * MIX_M1_INV) == 1ull && (MIX_M2 * MIX_M2_INV) == 1ull, "inverses mod 2^64");
 __host__ __device__ __forceinline__ uint64_t mix_key(uint64_t x, uint32_t bits) {
   const uint64_t mask = ~0ull >> (64 - bits);
   x = (x * MIX_M1) & mask;

@@ -4,7 +4,7 @@ occupancy spread and home-bucket overflow against a Poisson process, plus the bi
 on random, AT-rich, tandem-repeat and sequential keys.  CPU only (numpy restatement of the device
 formula: multiply by an odd constant mod 2^2k, fold the upper half down, multiply again)."""
 import numpy as np
-M1=np.uint64(0x9E3779B97F4A7C15); M2=np.uint64(0xD6E8FEB86659FD93)
+M1=np.uint64(0x9E3779B1); M2=np.uint64(0x85EBCA6B)
 def mix(x,bits):
     mask=np.uint64((1<<bits)-1)
     s=np.uint64((bits+1)//2)
