@@ -265,14 +265,17 @@ __device__ __forceinline__ void stage_prefetch(const BatchRef &b, uint64_t t0, S
   }
 }
 
-template <bool VALIDATE, int NT = WG, bool PACK = false, int TT = TILE_T>
+// NOBYTES (k_scatter32): no code byte per base at all — the first pass writes the 2-bit packed stream
+// straight from its registers, the second one 16-bit word of "k-mer ends here" bits per group
+// (okbits); `lds` then only holds the group masks.  The walk reads one word + one half-word per thread.
+template <bool VALIDATE, int NT = WG, bool PACK = false, int TT = TILE_T, bool NOBYTES = false>
 __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, uint64_t t1,
                                                uint8_t *lds, DevStats *stats,
                                                const StageRegs<NT, TT> &pre, uint32_t *packed = nullptr,
-                                               uint32_t *rcpacked = nullptr) {
+                                               uint32_t *rcpacked = nullptr, uint16_t *okbits = nullptr) {
   constexpr int TILE_GROUPS = StageRegs<NT, TT>::GROUPS;  // (shadow the file-scope constants: this
   constexpr int TILE_LDS = TT + HALO;                      // function stages tiles of TT positions)
-  uint32_t *gmask = reinterpret_cast<uint32_t *>(lds + TILE_LDS);  // nmask16 | smask16<<16
+  uint32_t *gmask = reinterpret_cast<uint32_t *>(NOBYTES ? lds : lds + TILE_LDS);  // nmask16 | smask16<<16
   const int64_t p0 = (int64_t)t0 - HALO;
   uint32_t n_non_n = 0;
 #pragma unroll
@@ -346,7 +349,8 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
       uint32_t lo = b.startbits[0];
       f = (lo << (uint32_t)(-p)) & 0xFFFFu;
     }
-    *reinterpret_cast<uint4 *>(lds + m * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (NOBYTES) packed[m] = pack16(make_uint4(w[0], w[1], w[2], w[3]));
+    else *reinterpret_cast<uint4 *>(lds + m * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     gmask[m] = nmask | (f << 16);
     __builtin_amdgcn_sched_barrier(0);  // one group at a time: interleaving the unrolled
   }                                     // iterations costs > 100 VGPRs
@@ -357,7 +361,12 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
   // walks need no end-of-tile test.  PACK: the 2-bit packed streams are written on the way.
   const int k = b.k;
   const int n_lds = (int)(t1 - t0) + HALO;  // LDS positions below this may end a k-mer
-  if (PACK) {
+  if (NOBYTES) {
+    if (threadIdx.x < 2) {  // the stream's pad words; halo groups never end a k-mer
+      packed[TILE_GROUPS + threadIdx.x] = 0;
+      okbits[threadIdx.x] = 0;
+    }
+  } else if (PACK) {
     for (int m = threadIdx.x; m < 2 + 2; m += NT) {  // halo groups 0,1 and the streams' pad words
       if (m < 2) {
         const uint32_t v = pack16(*reinterpret_cast<const uint4 *>(lds + m * 16));
@@ -393,7 +402,9 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
     uint32_t ok = ~(uint32_t)((N | S) >> 32) & 0xFFFFu;  // m ≥ 2: ≥ 32 ≥ k-1 bases of history
     const int lim = n_lds - m * 16;                       // positions of this group below t1
     if (lim < 16) ok = lim > 0 ? ok & ((1u << lim) - 1u) : 0u;
-    if (PACK || ok) {
+    if (NOBYTES) {
+      okbits[m] = (uint16_t)ok;
+    } else if (PACK || ok) {
       uint4 c4 = *reinterpret_cast<const uint4 *>(lds + m * 16);
       if (PACK) {
         const uint32_t v = pack16(c4);
@@ -1683,7 +1694,9 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   constexpr int GROUPS = (TT + HALO) / 16;
   const uint32_t log_parts = LOGP ? (uint32_t)LOGP : log_parts_;
   const uint32_t P = 1u << log_parts;
-  uint8_t *codes = reinterpret_cast<uint8_t *>(sh);  // staged tile; dead once the walk is over
+  uint8_t *codes = reinterpret_cast<uint8_t *>(sh);  // the stage's group masks (GROUPS words), then the
+  uint16_t *okbits = reinterpret_cast<uint16_t *>(sh + GROUPS + 2);  // "k-mer ends here" bits, 16 per group; dead once the walk is over
+  static_assert(SPAN == 16, "the walk reads one packed word and one okbits half-word per thread");
   uint32_t *sorted = sh;                             // TT entries; aliases codes
   uint32_t *recs = sh + TT;                          // TT records: thread t's i-th end position at i·NT + t
   uint32_t *packed = recs + TT;                      // GROUPS + 2 words
@@ -1720,7 +1733,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
 #endif
     for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
     {
-      const uint32_t nn = stage_tile<true, NT, true, TT>(b, s0, s1, codes, stats, pre, packed, nullptr);
+      const uint32_t nn = stage_tile<true, NT, true, TT, true>(b, s0, s1, codes, stats, pre, packed, nullptr, okbits);
       if (all_lanes) {  // this tile's lane: wave sum, one LDS add per wave
         uint32_t v = nn;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -1768,10 +1781,14 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
       constexpr uint64_t MKC = KC ? (1ull << (2 * KC)) - 1 : 0;
       const int kk = KC ? KC : k;
       const uint32_t mlo = KC ? (uint32_t)MKC : mask_lo, mhi = KC ? (uint32_t)(MKC >> 32) : mask_hi;
+      // this thread's sixteen end positions are exactly group 2 + threadIdx.x of the staged tile: their
+      // bases are one word of the packed stream (first base on top), their "a k-mer ends here" bits one
+      // half-word (never set at or beyond the tile's end)
+      const uint32_t pw = packed[2 + threadIdx.x];
+      const uint32_t okw = okbits[2 + threadIdx.x];
+      (void)jend;
 #pragma unroll
       for (int q = 0; q < SPAN / 8; ++q) {
-        uint64_t w = 0;
-        if (jemit + q * 8 < jend) w = *reinterpret_cast<const uint64_t *>(codes + jemit + q * 8);
         // Straight-line on purpose: every lane mixes and issues its LDS add (end positions without
         // a k-mer — bit 2 clear; never set at or beyond the tile's end — count into a spare
         // counter behind cnt[P-1]), and the eight returned ranks are only looked at after the
@@ -1780,7 +1797,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
         uint32_t pcs[8], rks[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          const uint32_t c = (uint32_t)(w >> (8 * r)) & 0xFF;
+          const uint32_t c = ((pw >> (30 - 2 * (q * 8 + r))) & 3u) | (((okw >> (q * 8 + r)) & 1u) << 2);
           roll_step(x, c & 3u, mlo, mhi);
           const uint64_t fwd = ((uint64_t)x.f_hi << 32) | x.f_lo;
           const uint64_t rev = (((uint64_t)x.r_hi << 32) | x.r_lo) >> (64 - 2 * kk);
