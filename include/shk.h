@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SHK_ABI_VERSION 1
+#define SHK_ABI_VERSION 2
 
 #define SHK_OK 0
 #define SHK_ERR_INVALID_CHAR (-1) /* kmer/encoding.rs:353-356 */
@@ -58,8 +58,28 @@ typedef struct shk_config {
   uint64_t histo_max;  /* 0 < histo_max ≤ 1_000_000 (cli.rs:668-673) */
   int32_t device;      /* HIP device ordinal */
   uint32_t flags;      /* SHK_FLAG_* */
-  uint64_t table_capacity_hint; /* expected distinct k-mers; 0 = start small and grow */
-  uint64_t reserved[4];
+  uint64_t table_capacity_hint; /* expected distinct k-mers this context will hold; 0 = start small and grow.
+                                   A multi-device context (n_devices > 1) splits it over its devices */
+  /* OWNER SHARE ("alternative when local tables do not fit"): with n_owners = W > 1 (a
+   * power of two ≤ 64) the context holds only the k-mers whose owner — the top log2(W) bits of the
+   * engine's bijective key mix — is owner_id: 1/W of the key space, so W contexts (one per GPU) together
+   * hold every k-mer exactly once and no table is ever exchanged.  shk_ingest_* on such a context counts
+   * the owned k-mers of the reads it is given and drops the rest; the shk_xchg_* entry points below
+   * partition a batch's records by owner for an exchange between the W contexts instead.  Read/base
+   * counters count every read handed over; k-mer counters and histograms cover the owned share
+   * (histogram bins are additive across shares: KmerCounts::extend over disjoint key sets,
+   * counting.rs:157-166, io.rs:1023-1028).  0 or 1: the whole key space. */
+  uint32_t n_owners;
+  uint32_t owner_id;
+  /* MULTI-DEVICE CONTEXT (SURVEY.md §8b `n_devices, device_ids`): n_devices > 1 makes ONE context that
+   * spans device_ids[0..n_devices) (a power of two ≤ 64 devices; an id may repeat — the test rigs put
+   * several shares on one card): one owner share per device, host batches of 1000 reads dealt round-robin
+   * to the devices with their global read index (io.rs:340-361), records exchanged by owner between the
+   * devices during ingest, one histogram sum at finalize.  `device` is ignored then.  0 or 1: one device. */
+  uint32_t n_devices;
+  uint32_t reserved32;
+  const int32_t *device_ids;
+  uint64_t reserved[1];
 } shk_config;
 
 /* io.rs:545-552 and counting.rs:254-260 totals, plus device-side facts */
@@ -242,6 +262,55 @@ int shk_compact_owners(shk_ctx *ctx, uint32_t n_owners, const uint64_t *seg_offs
 int shk_merge_entries(shk_ctx *ctx, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride);
 /* Restrict finalize's histogram scan to pages [p0,p1) (owner shard). */
 int shk_set_owned_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1);
+
+/* ---- key-space-partitioned ingest: the exchange between owner shares (device pointers) -------------
+ *
+ * One round, on every one of the W contexts (cfg.n_owners = W, cfg.owner_id = its rank):
+ *   1. shk_xchg_scatter_device: the rank's batch (≤ SHK_XCHG_MAX_BASES bases, resident in HBM) is
+ *      validated, its canonical k-mers (kmers_from_ascii, encoding.rs:332-371) extracted and their 4-byte
+ *      records written, grouped by owner, into the context's exchange buffer: owner o's SEGMENT is
+ *      d_records + o·layout.segment_records (u32 records) with its fill levels at d_cursors + o·layout.regions
+ *      (u32 words) — one contiguous piece each, so "send every peer its segment" is one all-to-all with
+ *      equal splits (or W−1 peer copies).  The call returns when the kernel is done: *n_foreign_spilled
+ *      is the fill of the context's foreign spill list (records that overflowed a region on skewed input;
+ *      shk_xchg_spill), an invalid byte is reported here (SHK_ERR_INVALID_CHAR) and poisons the context.
+ *   2. the caller moves segment o to rank o (RCCL all_to_all / hipMemcpyPeer), rank r's own segment
+ *      needs no copy;
+ *   3. shk_xchg_absorb on every received segment (and the own one): level-2 partition of its records into
+ *      the context's (lane, page) regions, where they wait for the page pass like any deferred batch.
+ *      Asynchronous on the context's stream (shk_stream): the segment must stay untouched until the
+ *      stream has passed the call.
+ * Foreign spills: shk_xchg_spill exposes the list (k-mer, chunk lane, count triples of any owner);
+ * every rank hands every other rank's list to shk_insert_device (which drops what the context does
+ * not own) and then calls shk_xchg_spill_clear.  All of it is exact for any input.
+ * Needs 4-byte records at the exchange geometry: 2k − layout.log_p1 ≤ 32 (k ≤ 21 at the default
+ * fan-out of 1024); otherwise SHK_ERR_STATE — merge the tables at finalize instead (shk_merge_*). */
+#define SHK_XCHG_MAX_BASES (1ull << 28)
+typedef struct shk_xchg_layout {
+  uint32_t n_owners;        /* W */
+  uint32_t n_lanes;         /* chunk lanes (max(chunks, 1)) */
+  uint32_t log_p1;          /* level-1 fan-out bits, owner bits included */
+  uint32_t regions;         /* regions per owner segment: n_lanes << (log_p1 − log2 W), ordered [lane][super-page] */
+  uint32_t region_cap;      /* records per region (a multiple of 1024); the regions of a segment are
+                               block-interleaved: record j of region g at ((j>>10)·regions + g)<<10 | (j & 1023) */
+  uint32_t reserved;
+  uint64_t segment_records; /* regions · region_cap */
+} shk_xchg_layout;
+/* layout_bases: what the segments are sized for — every rank of a round passes the same number
+ * (≥ its n_bases; e.g. the round's batch size), so that all come out with the same layout; 0 = n_bases. */
+int shk_xchg_scatter_device(shk_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_seqs,
+                            uint64_t n_bases, uint64_t layout_bases, void **d_records, void **d_cursors,
+                            shk_xchg_layout *layout, uint64_t *n_foreign_spilled);
+int shk_xchg_absorb(shk_ctx *ctx, const void *d_records, const void *d_cursors, const shk_xchg_layout *layout);
+int shk_xchg_spill(shk_ctx *ctx, void **d_kmers, void **d_lanes, void **d_counts, uint64_t *n);
+int shk_xchg_spill_clear(shk_ctx *ctx);
+/* KmerCounts::insert (counting.rs:152-154) from device memory with a chunk lane per record:
+ * saturating add of d_counts[i] to d_kmers[i] in lane d_lanes[i]; k-mers the context does not own
+ * are dropped.  Synchronous. */
+int shk_insert_device(shk_ctx *ctx, const void *d_kmers, const void *d_lanes, const void *d_counts, uint64_t n);
+/* The context's HIP stream (hipStream_t): device work queued by the calls above is ordered on it, so
+ * a host that runs its collectives on the same stream needs no host-side synchronisation. */
+void *shk_stream(shk_ctx *ctx);
 
 /* ---- pinned staging buffers for streaming hosts -------------------------------- */
 void *shk_alloc_pinned(size_t bytes);

@@ -54,6 +54,12 @@ struct TableRef {
   uint32_t log_pages;
   uint32_t n_lanes;
   uint32_t key_bits;  // 2k
+  // OWNER SHARE (key-space-partitioned ingest, SURVEY.md §8e "alternative when local tables do not
+  // fit"): the table is the slice of owner `owner_id` — the pages whose top `owner_bits` bits of the
+  // GLOBAL page index (top owner_bits + log_pages bits of the mixed key) equal owner_id — of a virtual
+  // table of 2^(owner_bits + log_pages) pages.  owner_bits = 0: the whole key space (owner_id = 0).
+  uint32_t owner_bits;
+  uint32_t owner_id;
   uint32_t pad_;
 };
 
@@ -75,6 +81,7 @@ struct SpillRef {
   uint32_t *lanes;
   uint32_t *counts;
   uint64_t cap;
+  unsigned long long *count;  // the list's fill counter; nullptr = DevStats::spill_count (k_scatter32 only looks at this)
 };
 
 // ---- hashing.  Results never depend on it — only speed does, and on gfx950
@@ -123,6 +130,23 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t h, uint32_t log_pages) {
   return ((h >> (32 - (PAGE_LOG - 2) - log_pages)) & (PAGE_SLOTS / 4 - 1)) << 2;  // the 11 bits below the page bits
 }
 static_assert(MAX_LOG_PAGES + PAGE_LOG - 2 <= 32, "page + home-bucket bits come out of 32 hash bits");
+// Where a key lives in a table that may be an owner share: page (as a slot base in the LOCAL arrays),
+// home slot, and whether this table owns the key at all.
+struct Home {
+  uint64_t base;
+  uint32_t slot;
+  bool owned;
+};
+__device__ __forceinline__ Home home_of(const TableRef &tb, uint64_t key) {
+  const uint32_t h = hash64(key, tb.key_bits);
+  const uint32_t lpg = tb.log_pages + tb.owner_bits;  // page bits of the virtual global table
+  const uint64_t gp = page_of(h, lpg);
+  Home r;
+  r.owned = (uint32_t)(gp >> tb.log_pages) == tb.owner_id;
+  r.base = (gp & ((1ull << tb.log_pages) - 1ull)) << PAGE_LOG;
+  r.slot = slot_of(h, lpg);
+  return r;
+}
 
 __device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
   uint32_t s = a + b;
@@ -702,10 +726,10 @@ __global__ void __launch_bounds__(WG) k_scan(BatchRef b, DevStats *__restrict__ 
 __device__ __forceinline__ void count_one(const TableRef &tb, uint64_t key, uint32_t lane,
                                           DevStats *stats, const SpillRef &sp,
                                           uint32_t &n_new) {
-  uint32_t h = hash64(key, tb.key_bits);
-  uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
+  const Home hm = home_of(tb, key);
+  if (!hm.owned) return;  // another owner's k-mer (owner share: foreign records are dropped)
   bool inserted = false;
-  int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
+  int64_t s = find_or_insert(tb.keys, hm.base, hm.slot, key, inserted);
   if (s < 0) {
     unsigned long long i = atomicAdd(&stats->spill_count, 1ull);
     if (i < sp.cap) {
@@ -765,10 +789,10 @@ __global__ void __launch_bounds__(WG) k_insert(const uint64_t *__restrict__ kmer
     uint64_t key = kmers[i];
     uint32_t lane = lanes ? lanes[i] : lane0;
     uint32_t cnt = counts ? counts[i] : 1u;
-    uint32_t h = hash64(key, tb.key_bits);
-    uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
+    const Home hm = home_of(tb, key);
+    if (!hm.owned) continue;
     bool inserted = false;
-    int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
+    int64_t s = find_or_insert(tb.keys, hm.base, hm.slot, key, inserted);
     if (s < 0) {
       unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
       if (j < sp.cap) {
@@ -794,10 +818,9 @@ __global__ void __launch_bounds__(WG) k_grow(TableRef oldt, TableRef newt) {
        i += (uint64_t)gridDim.x * WG) {
     uint64_t key = oldt.keys[i];
     if (key == EMPTY) continue;
-    uint32_t h = hash64(key, newt.key_bits);
-    uint64_t base = page_of(h, newt.log_pages) << PAGE_LOG;
+    const Home hm = home_of(newt, key);
     bool inserted = false;
-    int64_t s = find_or_insert(newt.keys, base, slot_of(h, newt.log_pages), key, inserted);
+    int64_t s = find_or_insert(newt.keys, hm.base, hm.slot, key, inserted);
     // s >= 0 by construction (child pages cannot overflow)
     for (uint32_t l = 0; l < oldt.n_lanes; ++l)
       newt.vals[(uint64_t)l * newt.cap + (uint64_t)s] = oldt.vals[(uint64_t)l * oldt.cap + i];
@@ -968,9 +991,9 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t kmer, int k) {
 }
 
 __device__ __forceinline__ uint32_t merged_count(const TableRef &tb, uint64_t key) {
-  uint32_t h = hash64(key, tb.key_bits);
-  uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
-  int64_t s = find_slot(tb.keys, base, slot_of(h, tb.log_pages), key);
+  const Home hm = home_of(tb, key);
+  if (!hm.owned) return 0u;
+  int64_t s = find_slot(tb.keys, hm.base, hm.slot, key);
   if (s < 0) return 0;
   uint32_t cum = 0;
   for (uint32_t l = 0; l < tb.n_lanes; ++l) cum = sat_add_u32(cum, tb.vals[(uint64_t)l * tb.cap + s]);
@@ -1215,10 +1238,10 @@ __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t n_slots, uin
        i += (uint64_t)gridDim.x * WG) {
     uint64_t key = pkeys[i];
     if (key == EMPTY) continue;
-    uint32_t h = hash64(key, tb.key_bits);
-    uint64_t base = page_of(h, tb.log_pages) << PAGE_LOG;
+    const Home hm = home_of(tb, key);
+    if (!hm.owned) continue;
     bool inserted = false;
-    int64_t s = find_or_insert(tb.keys, base, slot_of(h, tb.log_pages), key, inserted);
+    int64_t s = find_or_insert(tb.keys, hm.base, hm.slot, key, inserted);
     if (s < 0) {
       // page full: one spill record per non-zero lane
       for (uint32_t l = 0; l < tb.n_lanes; ++l) {
@@ -1675,12 +1698,26 @@ __device__ __forceinline__ void place_entries(uint32_t *__restrict__ sorted, con
 // scan, reserve and place phases are specialised for it.
 // ALL: ALL-LANES mode (lane_filter = ~0) as a compile-time constant: with one lane and LOGP the number
 // of regions is an immediate and rec_slot a shift and an or.
-template <int NT, int TT, bool WIDE, int LOGP = 0, bool ALL = false>
+// OWN (with ALL): the OWNER layout of key-space-partitioned ingest.  The fan-out 2^log_parts covers the
+// virtual global table: the top log_w bits of a partition index are the record's OWNER, the rest its
+// super-page inside the owner's share.  Regions and cursors are ordered [owner][lane][super-page], every
+// owner's regions block-interleave among themselves only, so that what one owner gets — its seg_recs
+// records' worth of regions and their cursor words — is ONE contiguous piece of each array (what crosses
+// the link in a multi-GPU run).  keep = an owner id: records of every other owner are dropped in the walk
+// and there is a single segment (seg_recs = 0); keep = ~0: all owners' records are kept.
+struct OwnerCfg {
+  uint32_t log_w;     // owner bits (≤ log_parts)
+  uint32_t keep;      // owner id to keep, or ~0 = all
+  uint32_t seg_recs;  // records per owner segment (0: one segment only)
+  uint32_t pad;
+};
+template <int NT, int TT, bool WIDE, int LOGP = 0, bool ALL = false, bool OWN = false>
 __global__ void __launch_bounds__(NT, 4) k_scatter32(
     BatchRef b, uint32_t log_parts_, uint32_t lane_filter, unsigned int *__restrict__ cursor,
     uint32_t cap_p, uint32_t *__restrict__ part_buf32, DevStats *__restrict__ stats,
     unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg,
-    uint32_t n_region_lanes) {
+    uint32_t n_region_lanes, OwnerCfg own) {
+  static_assert(!OWN || (ALL && !WIDE), "the owner layout is an all-lanes, per-launch layout");
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[NT / 64];
   __shared__ uint32_t red[NT / 64];
@@ -1716,6 +1753,14 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   const uint32_t rbits = 2u * (uint32_t)k - log_parts;  // ≤ 32: bits of a record
   const uint32_t rmask = (uint32_t)(0xFFFFFFFFull >> (32 - rbits));
   const uint32_t n_regions = (all_lanes ? n_region_lanes : 1u) * P;
+  // owner layout
+  const uint32_t log_p1w = OWN ? log_parts - own.log_w : 0u;  // super-page bits inside an owner's share
+  const uint32_t p1w_mask = (1u << log_p1w) - 1u;
+  const uint32_t n_grp = n_region_lanes << log_p1w;           // regions of one owner segment
+  const uint32_t keep_mask = own.keep == 0xFFFFFFFFu ? 0u : 0xFFFFFFFFu;
+  // cursor word / region-in-segment of partition i for this tile's lane; owner segment of partition i
+  auto own_grp = [&](uint32_t i, uint32_t ln) -> uint32_t { return (ln << log_p1w) | (i & p1w_mask); };
+  auto own_seg = [&](uint32_t i) -> uint32_t { return own.seg_recs ? i >> log_p1w : 0u; };
 
   // iteration over sub-tiles: (macro tile t = [t0,t1) of chunk lane `lane`, sub-tile index sub)
   uint64_t t = blockIdx.x, t0, t1;
@@ -1803,7 +1848,9 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
           const uint64_t rev = (((uint64_t)x.r_hi << 32) | x.r_lo) >> (64 - 2 * kk);
           const uint64_t y = mix_key(rev < fwd ? rev : fwd, 2 * kk);
           const uint32_t page = RB32 ? (uint32_t)(y >> 32) : (uint32_t)(y >> rbits);
-          pcs[r] = (c & 4u) ? page : P + (threadIdx.x & 7u);
+          bool emit = (c & 4u) != 0u;
+          if (OWN) emit = emit && ((((page >> log_p1w) ^ own.keep) & keep_mask) == 0u);  // a foreign owner's record: dropped
+          pcs[r] = emit ? page : P + (threadIdx.x & 7u);
           recs[(q * 8 + r) * NT + threadIdx.x] = RB32 ? (uint32_t)y : (uint32_t)y & rmask;  // transposed: no bank conflicts
           rks[r] = atomicAdd(&cnt[pcs[r]], 1u);  // rank < 2^14
         }
@@ -1854,7 +1901,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
       gres[r] = 0;
       if (i < P) {
         const uint32_t c1 = cnt[i];
-        if (c1) gres[r] = atomicAdd(&cursor[rbase + i], c1);
+        if (c1) gres[r] = atomicAdd(&cursor[OWN ? own_seg(i) * n_grp + own_grp(i, lane) : rbase + i], c1);
       }
     }
     __syncthreads();  // codes are dead from here: `sorted` may overwrite them; tstart is complete
@@ -1873,7 +1920,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
       char *const base = reinterpret_cast<char *>(part_buf32);
       auto spill_rec = [&](uint32_t pc, uint32_t rec) {  // the page's region is full (skewed input)
         const uint64_t km = unmix_key(((uint64_t)pc << rbits) | rec, 2 * k);
-        const unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
+        const unsigned long long j = atomicAdd(OWN && sp.count ? sp.count : &stats->spill_count, 1ull);
         if (j < sp.cap) {
           sp.keys[j] = km;
           sp.lanes[j] = lane;
@@ -1889,19 +1936,21 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
         const uint32_t at0 = gbase[pc0] + 2 * i;  // record index inside the page's region
         // (a launch covers ≤ 2^28 k-mers: byte offsets into a per-launch buffer fit 32 bits; WIDE:
         // the buffer accumulates the records of many launches and needs 64-bit offsets)
-        auto slot_ptr = [&](uint32_t region, uint32_t at) -> uint32_t * {
-          if (WIDE) return part_buf32 + rec_slot64(region, n_regions, at);
-          return reinterpret_cast<uint32_t *>(base + rec_slot(region, n_regions, at) * 4u);
+        auto slot_ptr = [&](uint32_t pc, uint32_t at) -> uint32_t * {
+          if (OWN)  // segment of pc's owner, then the block-interleave among that owner's regions
+            return reinterpret_cast<uint32_t *>(base + (own_seg(pc) * own.seg_recs + rec_slot(own_grp(pc, lane), n_grp, at)) * 4u);
+          if (WIDE) return part_buf32 + rec_slot64(rbase + pc, n_regions, at);
+          return reinterpret_cast<uint32_t *>(base + rec_slot(rbase + pc, n_regions, at) * 4u);
         };
         if (two && pc1 == pc0 && at0 + 2 <= cap_p && (at0 & ((1u << RB_LOG) - 1u)) != (1u << RB_LOG) - 1u) {
           const uint2 rec2 = make_uint2(r0, r1);  // (both records in one block)
-          __builtin_memcpy(slot_ptr(rbase + pc0, at0), &rec2, 8);
+          __builtin_memcpy(slot_ptr(pc0, at0), &rec2, 8);
         } else {
-          if (at0 < cap_p) *slot_ptr(rbase + pc0, at0) = r0;
+          if (at0 < cap_p) *slot_ptr(pc0, at0) = r0;
           else spill_rec(pc0, r0);
           if (two) {
             const uint32_t at1 = gbase[pc1] + 2 * i + 1;
-            if (at1 < cap_p) *slot_ptr(rbase + pc1, at1) = r1;
+            if (at1 < cap_p) *slot_ptr(pc1, at1) = r1;
             else spill_rec(pc1, r1);
           }
         }
@@ -2076,18 +2125,25 @@ static_assert(RS32_TILE <= 65536 && RS32_SPAN % 4 == 0, "16-bit entries; four re
 __global__ void __launch_bounds__(RS32_NT) k_part_rescatter32(
     const uint32_t *__restrict__ src_buf, const unsigned int *__restrict__ src_cursor, uint32_t src_cap,
     uint32_t tiles_per_region, uint32_t log_sub, uint32_t r1_bits, uint32_t key_bits,
-    unsigned int *__restrict__ dst_cursor, uint32_t dst_cap, uint32_t *__restrict__ dst_buf, uint32_t lane,
-    DevStats *__restrict__ stats, SpillRef sp, uint64_t dst_region_base, uint64_t n_dst_total) {
+    unsigned int *__restrict__ dst_cursor, uint32_t dst_cap, uint32_t *__restrict__ dst_buf, uint32_t lane_,
+    DevStats *__restrict__ stats, SpillRef sp, uint64_t dst_region_base_, uint64_t n_dst_total,
+    uint32_t log_src_lane, uint32_t region_hi, uint64_t dst_lane_stride) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[RS32_NT / 64];
   if (stats->bad != ~0ull) return;
   const uint32_t S = 1u << log_sub;  // pages per super-page
-  const uint32_t region = blockIdx.x / tiles_per_region, tile = blockIdx.x % tiles_per_region;
-  const uint32_t filled = src_cursor[region] < src_cap ? src_cursor[region] : src_cap;
+  // Source regions: one per super-page, or — the owner layout of k_scatter32 — [lane][super-page] with
+  // 2^log_src_lane super-pages per lane (log_src_lane = 31: a single lane, lane_).  `region` below is the
+  // super-page inside this table's share; region_hi carries the owner bits above it for a key rebuild.
+  const uint32_t src_region = blockIdx.x / tiles_per_region, tile = blockIdx.x % tiles_per_region;
+  const uint32_t lane = lane_ + (src_region >> log_src_lane);
+  const uint32_t region = src_region & ((1u << log_src_lane) - 1u);
+  const uint64_t dst_region_base = dst_region_base_ + (uint64_t)(src_region >> log_src_lane) * dst_lane_stride;
+  const uint32_t filled = src_cursor[src_region] < src_cap ? src_cursor[src_region] : src_cap;
   const uint32_t r0 = tile * RS32_TILE;
   if (r0 >= filled) return;
   const uint32_t n = filled - r0 < (uint32_t)RS32_TILE ? filled - r0 : (uint32_t)RS32_TILE;
-  const uint32_t n_src_regions = gridDim.x / tiles_per_region;  // level-1 regions (super-pages)
+  const uint32_t n_src_regions = gridDim.x / tiles_per_region;  // level-1 regions of the source buffer
   uint32_t *recs = sh;                                                      // RS32_TILE records
   uint16_t *sorted = reinterpret_cast<uint16_t *>(sh + RS32_TILE);          // RS32_TILE entries
   uint32_t *cnt = sh + RS32_TILE + RS32_TILE / 2;                           // S
@@ -2102,7 +2158,7 @@ __global__ void __launch_bounds__(RS32_NT) k_part_rescatter32(
 #pragma unroll
   for (int q = 0; q < RS32_SPAN / 4; ++q) {
     const uint32_t i = (uint32_t)(q * RS32_NT + threadIdx.x) * 4;
-    if (i + 4 <= n) pre[q] = *reinterpret_cast<const uint4 *>(src_buf + rec_slot64(region, n_src_regions, r0 + i));
+    if (i + 4 <= n) pre[q] = *reinterpret_cast<const uint4 *>(src_buf + rec_slot64(src_region, n_src_regions, r0 + i));
   }
 #pragma unroll
   for (int q = 0; q < RS32_SPAN / 4; ++q) {
@@ -2114,7 +2170,7 @@ __global__ void __launch_bounds__(RS32_NT) k_part_rescatter32(
       *reinterpret_cast<uint4 *>(recs + i) = v;
     } else {
       for (int r = 0; r < 4; ++r)
-        if (i + r < n) recs[i + r] = rr[r] = src_buf[rec_slot64(region, n_src_regions, r0 + i + r)];
+        if (i + r < n) recs[i + r] = rr[r] = src_buf[rec_slot64(src_region, n_src_regions, r0 + i + r)];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -2166,7 +2222,7 @@ __global__ void __launch_bounds__(RS32_NT) k_part_rescatter32(
   const uint32_t *sorted2 = reinterpret_cast<const uint32_t *>(sorted);
   const uint32_t rmask2 = rbits2 >= 32 ? 0xFFFFFFFFu : ((1u << rbits2) - 1u);
   auto spill_rec = [&](uint32_t rec) {  // the page's region is full: the whole key takes the spill path
-    const uint64_t key = unmix_key(((uint64_t)region << r1_bits) | rec, key_bits);
+    const uint64_t key = unmix_key(((uint64_t)(region_hi | region) << r1_bits) | rec, key_bits);
     const unsigned long long j = atomicAdd(&stats->spill_count, 1ull);
     if (j < sp.cap) {
       sp.keys[j] = key;
@@ -2277,7 +2333,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
   // general probe of one record into the LDS page: find the key or insert it, add one
   auto insert = [&](uint64_t key) {
     if (key == EMPTY) return;  // padding record of an odd (tile, page) run
-    uint32_t sl = slot_of(hash64(key, tb.key_bits), tb.log_pages);
+    uint32_t sl = slot_of(hash64(key, tb.key_bits), tb.log_pages + tb.owner_bits);
     for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
       uint64_t cur = keys[sl];
       if (cur == EMPTY) {
@@ -2333,7 +2389,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
       nxt[1] = src2[ib + PG_WG];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ss[q] = slot_of(hash64(kk[q], tb.key_bits), tb.log_pages);
+    for (int q = 0; q < 4; ++q) ss[q] = slot_of(hash64(kk[q], tb.key_bits), tb.log_pages + tb.owner_bits);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       ba[q] = *reinterpret_cast<const ulonglong2 *>(&keys[ss[q]]);
@@ -2444,8 +2500,9 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     if (any == 0) return;  // nothing for this page in any lane: leave it untouched in HBM
   }
   uint32_t lane = lane_lo;
-  const uint32_t bits = tb.key_bits, R = bits - tb.log_pages, fpb = R - 11;
+  const uint32_t bits = tb.key_bits, R = bits - (tb.log_pages + tb.owner_bits), fpb = R - 11;
   const uint32_t fpmask = (1u << fpb) - 1u;
+  const uint64_t gpage = ((uint64_t)tb.owner_id << tb.log_pages) | page;  // page index in the virtual global table (owner share)
   uint64_t *gk = tb.keys + ((uint64_t)page << PAGE_LOG);
   uint32_t *gv = nullptr;  // this lane's counts of the page (set per lane below)
   // page keys → tags, counting occupied slots on the way
@@ -2490,7 +2547,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     may_insert = w < room;
   };
   auto spill = [&](uint32_t rec) {
-    const uint64_t key = unmix_key(((uint64_t)page << R) | rec, bits);
+    const uint64_t key = unmix_key((gpage << R) | rec, bits);
     unsigned long long i = atomicAdd(&stats->spill_count, 1ull);
     if (i < sp.cap) {
       sp.keys[i] = key;
@@ -2510,7 +2567,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
         const uint32_t prev = atomicCAS(&tags[sl], TAG_EMPTY, fp3 | d);
         if (prev == TAG_EMPTY) {
           n_new++;
-          gk[sl] = unmix_key(((uint64_t)page << R) | rec, bits);
+          gk[sl] = unmix_key((gpage << R) | rec, bits);
           cur = fp3 | d;
         } else {
           cur = prev;

@@ -27,6 +27,10 @@ static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub);
 static int settle(shk_ctx *c);
 static int settle_light(shk_ctx *c);
 static int flush_acc(shk_ctx *c);
+static uint64_t acc_records_est(const shk_ctx *c, uint64_t kmers_ub);
+struct XchgOut;
+static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo);
+static int xchg_prepare_cursors(shk_ctx *c, uint32_t *n_words);
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -84,9 +88,13 @@ struct TimedEvent {
 
 }  // namespace
 
+struct shk_group;
 struct shk_ctx {
   shk_config cfg{};
+  shk_group *group = nullptr;  // a multi-device context (cfg.n_devices > 1): everything lives in the group
   uint32_t n_lanes = 1;
+  // owner share (cfg.n_owners > 1): this context holds the k-mers of owner `owner_id` only
+  uint32_t n_owners = 1, owner_bits = 0, owner_id = 0;
   uint32_t n_cus = 256;  // compute units of the device (multiProcessorCount)
   hipStream_t stream = nullptr;
   // table
@@ -109,9 +117,11 @@ struct shk_ctx {
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_done[2] = {nullptr, nullptr};
   bool zero_count_keys = false;   // some key may have been inserted with count 0 (shk_insert_counts, merges): k_histo reads the keys
-  bool lds_attr_scatter = false, lds_attr_rescatter = false;  // hipFuncSetAttribute done for this context's device
+  bool lds_attr_scatter = false, lds_attr_rescatter = false, lds_attr_scatter_own = false;  // hipFuncSetAttribute done for this context's device
   HostBuf h_rebased[2];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
   DevBuf in_bases, in_offsets, in_bases2, in_offsets2, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
+  DevBuf xbuf, xspill;            // owner layout: the level-1 records of a launch by [owner][lane][super-page]; the foreign spill list
+  uint64_t xspill_cap = 0;
   // host counters
   std::vector<uint64_t> lane_reads;
   uint64_t n_reads_read = 0, n_bases_read = 0;
@@ -119,6 +129,7 @@ struct shk_ctx {
   uint64_t own_p0 = 0, own_p1 = 0;  // owned page range for finalize (0,0 = all)
   bool own_set = false;
   bool finalized = false, poisoned = false;
+  bool hist_ready = false;  // finalize got as far as the histograms and totals (then failed an invariant, io.rs:1042-1047: the reference has its histo_vecs by then)
   bool unsettled = false;  // a counting launch whose outcome the host has not looked at yet
   uint64_t unsettled_spill_cap = 0;
   int poison_code = 0;
@@ -254,6 +265,8 @@ int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out) {
   t.log_pages = log_pages;
   t.n_lanes = c->n_lanes;
   t.key_bits = 2 * c->cfg.k;
+  t.owner_bits = c->owner_bits;
+  t.owner_id = c->owner_id;
   t.cap = (uint64_t)PAGE_SLOTS << log_pages;
   HIPC(c, hipMalloc((void **)&t.keys, t.cap * sizeof(uint64_t)));
   hipError_t e = hipMalloc((void **)&t.vals, t.cap * sizeof(uint32_t) * t.n_lanes);
@@ -294,9 +307,9 @@ int grow_to(shk_ctx *c, uint32_t new_log_pages) {
   return SHK_OK;
 }
 
-uint32_t log_pages_for(uint64_t want_slots) {
+uint32_t log_pages_for(uint64_t want_slots, uint32_t owner_bits = 0) {
   uint32_t lp = 0;
-  while (((uint64_t)PAGE_SLOTS << lp) < want_slots && lp < MAX_LOG_PAGES) lp++;
+  while (((uint64_t)PAGE_SLOTS << lp) < want_slots && lp + owner_bits < MAX_LOG_PAGES) lp++;
   return lp;
 }
 
@@ -304,7 +317,7 @@ uint32_t log_pages_for(uint64_t want_slots) {
 int ensure_capacity(shk_ctx *c, uint64_t expect_new) {
   uint64_t need = (c->h_stats->n_distinct + expect_new) * 2;
   if (need <= c->tb.cap) return SHK_OK;
-  return grow_to(c, log_pages_for(need));
+  return grow_to(c, log_pages_for(need, c->owner_bits));
 }
 
 SpillRef spill_ref(DevBuf &b, uint64_t cap) {
@@ -330,11 +343,11 @@ int drain_spill(shk_ctx *c, uint64_t spill_cap) {
       return fail(c, SHK_ERR_INVARIANT, "spill list overflow (%llu > %llu)", (unsigned long long)n,
                   (unsigned long long)spill_cap);
     c->n_spilled += n;
-    uint32_t lp = log_pages_for((c->h_stats->n_distinct + n) * 2);
+    uint32_t lp = log_pages_for((c->h_stats->n_distinct + n) * 2, c->owner_bits);
     if (round > 0) {
-      if (c->tb.log_pages >= MAX_LOG_PAGES)
+      if (c->tb.log_pages + c->owner_bits >= MAX_LOG_PAGES)
         return fail(c, SHK_ERR_NOMEM, "table full: %llu distinct k-mers do not fit 2^%u pages",
-                    (unsigned long long)c->h_stats->n_distinct, MAX_LOG_PAGES);
+                    (unsigned long long)c->h_stats->n_distinct, MAX_LOG_PAGES - c->owner_bits);
       lp = std::max(lp, c->tb.log_pages + 1);
     }
     int rc = grow_to(c, lp);
@@ -362,13 +375,13 @@ constexpr uint64_t MAX_SUB_BASES = 1ull << 28;  // bases per counting launch (bo
 // (drain_batch, io.rs:356-358); lane_fixed < 0: stripe by running read index
 // (read i → chunk (i/1000) % n_chunks, io.rs:340-343,355-361).
 int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_seqs,
-                uint64_t n_bases, int64_t lane_fixed) {
+                uint64_t n_bases, int64_t lane_fixed, XchgOut *xo = nullptr) {
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
   {
     int rc0 = settle_light(c);  // the previous launch's spill list / scratch must be done with
     if (rc0 != SHK_OK) return rc0;
   }
-  c->finalized = false;
+  c->finalized = c->hist_ready = false;
   c->chain_from_mark = false;
   const uint64_t g0 = c->n_reads_read;
   const uint32_t NL = c->n_lanes;
@@ -388,7 +401,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   }
   if (lane_fixed < 0) c->n_reads_read += n_seqs;  // explicit-lane batches do not advance striping
   c->n_bases_read += n_bases;
-  if (n_seqs == 0 || n_bases == 0) return SHK_OK;
+  if (n_seqs == 0 || n_bases == 0) return xo ? xchg_scatter_launch(c, BatchRef{}, 0, xo) : SHK_OK;
 
   // 1. read-start bitmap (+ tile list when the batch spans several chunk lanes)
   const size_t sb_words = (size_t)(n_bases / 32 + 3);
@@ -407,15 +420,19 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   const uint64_t tiles_per_sub = MAX_SUB_BASES / TILE_T;
   {
     const uint64_t first_kmers_ub = std::min(tiles_per_sub, n_tiles_ub) * TILE_T;
-    int rc = ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : first_kmers_ub / 4);
+    int rc = ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : (first_kmers_ub / 4) >> c->owner_bits);
     if (rc != SHK_OK) return rc;
   }
   c->cur_blocks = n_blocks;
   uint32_t n_cursor_words = 0;
-  {
+  if (xo) {  // exchange round: level-1 scatter only, every owner's records (shk_xchg_scatter_device)
+    if (n_tiles_ub > tiles_per_sub) return fail(c, SHK_ERR_BAD_ARG, "an exchange batch takes at most %llu bases", (unsigned long long)MAX_SUB_BASES);
+    int rc = xchg_prepare_cursors(c, &n_cursor_words);
+    if (rc != SHK_OK) return rc;
+  } else {
     const uint64_t first_kmers_ub = std::min(tiles_per_sub, n_tiles_ub) * TILE_T;
     const bool defer = first_launch_defers(c, first_kmers_ub);
-    int rc = defer ? acc_prepare(c, first_kmers_ub) : (c->acc_active ? settle(c) : SHK_OK);  // (may flush: launch + settle)
+    int rc = defer ? acc_prepare(c, acc_records_est(c, first_kmers_ub)) : (c->acc_active ? settle(c) : SHK_OK);  // (may flush: launch + settle)
     if (rc == SHK_OK) rc = prepare_cursors(c, striped && n_blocks > 1, defer && first_launch_defers(c, first_kmers_ub), &n_cursor_words);
     if (rc != SHK_OK) return rc;
   }
@@ -441,6 +458,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   b.lane0 = lane_fixed >= 0 ? (uint32_t)lane_fixed : (striped ? (uint32_t)((g0 / 1000) % NL) : 0u);
   b.k = (int)c->cfg.k;
 
+  if (xo) return xchg_scatter_launch(c, b, n_tiles_ub * TILE_T, xo);
   // 3. count, in sub-ranges of tiles
   for (uint64_t ta = 0; ta < n_tiles_ub; ta += tiles_per_sub) {
     uint64_t tn = std::min(tiles_per_sub, n_tiles_ub - ta);
@@ -451,7 +469,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
       int rcs = settle_light(c);
       if (rcs != SHK_OK) return rcs;
     }
-    int rc = ta ? ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : sub_kmers_ub / 4) : SHK_OK;
+    int rc = ta ? ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : (sub_kmers_ub / 4) >> c->owner_bits) : SHK_OK;
     if (rc != SHK_OK) return rc;
     rc = count_tiles(c, b, sub_kmers_ub, /*prezeroed=*/ta == 0);
     if (rc != SHK_OK) return rc;
@@ -468,7 +486,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
 // touched page is read and written once per pass.
 static bool paged_feasible(const shk_ctx *c) {
   // one level up to MAX_PARTS pages, two levels (super-pages of ≤ MAX_PARTS pages) beyond
-  return c->tb.log_pages <= 20 && c->n_lanes <= 16;
+  return c->tb.log_pages + c->owner_bits <= 20 && c->n_lanes <= 16;
 }
 static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
   return c->tb.log_pages >= 8 && sub_kmers_ub >= c->tb.cap / 2;
@@ -487,18 +505,25 @@ static uint32_t region_cap(uint64_t n_records_ub, uint64_t n_regions, uint64_t p
 // super-page (2^log_sub consecutive pages), level 2 (k_part_rescatter) by page.
 struct PartGeom {
   uint32_t lp, n_pages, log_p1, log_sub, P1;
+  uint32_t lw, lpg;  // owner bits; page bits of the virtual global table (lp + lw)
   bool two_level;
   uint32_t cursor_words() const { return P1 + (two_level ? n_pages : 0); }
 };
+// An owner share (lw > 0) is the slice of one owner of a virtual table of 2^(lp + lw) pages: the
+// partition levels are laid over THAT table — level 1 fans out over its top log_p1 bits, owner bits
+// included, so that the same pass serves the exchange between owners — and always in the two-level
+// form (log_sub may be 0).
 static PartGeom part_geom(const shk_ctx *c) {
   PartGeom g{};
   g.lp = c->tb.log_pages;
+  g.lw = c->owner_bits;
+  g.lpg = g.lp + g.lw;
   g.n_pages = 1u << g.lp;
   const uint32_t lvl1_log = (uint32_t)env_int("SHK_LEVEL1_LOG", 10);                      // test hooks: force
   const uint32_t two_level_min = (uint32_t)env_int("SHK_TWO_LEVEL_MIN_PAGES", MAX_PARTS);  // the two-level path
-  g.two_level = g.n_pages > std::min<uint32_t>(two_level_min, (uint32_t)MAX_PARTS);
-  g.log_p1 = g.two_level ? std::min(lvl1_log, g.lp) : g.lp;
-  g.log_sub = g.lp - g.log_p1;
+  g.two_level = g.lw > 0 || g.n_pages > std::min<uint32_t>(two_level_min, (uint32_t)MAX_PARTS);
+  g.log_p1 = g.two_level ? std::max(std::min(lvl1_log, g.lpg), g.lw) : g.lpg;
+  g.log_sub = g.lpg - g.log_p1;
   g.P1 = 1u << g.log_p1;
   return g;
 }
@@ -507,7 +532,7 @@ static PartGeom part_geom(const shk_ctx *c) {
 // 11 ≤ 2k - log_pages ≤ 32 (the low bits of the mixed key below the page bits); with two levels
 // the level-1 record, 2k - log_p1 bits, must fit as well.
 static bool use_rec32(const shk_ctx *c, const PartGeom &g) {
-  const uint32_t rbits = 2 * c->cfg.k >= g.lp ? 2 * c->cfg.k - g.lp : 0;
+  const uint32_t rbits = 2 * c->cfg.k >= g.lpg ? 2 * c->cfg.k - g.lpg : 0;
   const uint32_t r1_bits = 2 * c->cfg.k >= g.log_p1 ? 2 * c->cfg.k - g.log_p1 : 0;
   return rbits >= 11 && rbits <= 32 && r1_bits <= 32 && env_int("SHK_REC32", 1) != 0;
 }
@@ -526,6 +551,19 @@ static bool use_scatter32(const shk_ctx *c, const PartGeom &g) {
 static bool use_all_lanes(const shk_ctx *c, const PartGeom &g, bool multi) {
   return multi && !g.two_level && use_scatter32(c, g) && c->n_lanes <= 64 && env_int("SHK_ALL_LANES", 1) != 0;
 }
+// The OWNER LAYOUT route (xl_count): ONE level-1 scatter for the tiles of every chunk lane into regions
+// ordered [owner][lane][super-page], then ONE level-2 pass per owner segment into the waiting (lane, page)
+// regions.  It is what an owner share always takes, and what a whole-key-space context takes for a
+// deferred two-level pass over several lanes (instead of a scatter + re-scatter per lane).
+static bool xl_feasible(const shk_ctx *c, const PartGeom &g) {
+  return g.two_level && use_scatter32(c, g) && (1u << g.log_sub) <= (uint32_t)MAX_PARTS && c->n_lanes <= 64 &&
+         g.lpg <= MAX_LOG_PAGES;
+}
+static bool xl_route(const shk_ctx *c, const PartGeom &g, bool multi, bool defer) {
+  if (!xl_feasible(c, g)) return false;
+  if (g.lw > 0) return true;
+  return defer && multi && env_int("SHK_XL", 1) != 0;
+}
 
 // Which way a counting launch goes.
 //   PATH_PAGED  : partition, then count every page in LDS right away — pays when the batch is at
@@ -543,6 +581,8 @@ static bool paged_feasible(const shk_ctx *c);
 static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub);
 static CountPath count_path(const shk_ctx *c, uint64_t sub_kmers_ub) {
   if (!paged_feasible(c) || (c->cfg.flags & SHK_FLAG_FORCE_DIRECT)) return PATH_DIRECT;
+  if (c->owner_bits)  // an owner share: the owner layout + deferred page passes, or global atomics (both drop foreign k-mers)
+    return xl_feasible(c, part_geom(c)) && env_int("SHK_DEFER", 1) != 0 ? PATH_DEFER : PATH_DIRECT;
   if ((c->cfg.flags & SHK_FLAG_FORCE_PAGED) || paged_pays(c, sub_kmers_ub)) return PATH_PAGED;
   const PartGeom g = part_geom(c);
   if (env_int("SHK_DEFER", 1) == 0) return PATH_DIRECT;
@@ -624,19 +664,23 @@ static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub) { return count_pa
 // Bytes of the per-launch cursor buffer (part_meta).  One size for everybody who asks: the buffer
 // must not be reallocated between k_mark_starts (which clears cursors in it) and the partition launch.
 static size_t cursor_buf_bytes(const shk_ctx *c, const PartGeom &g, bool multi) {
-  return ((size_t)(use_all_lanes(c, g, multi) ? c->n_lanes : 1) * g.P1 + g.n_pages) * 4 + 64;
+  const bool lanes = use_all_lanes(c, g, multi) || xl_feasible(c, g);  // (the owner layout: n_lanes · P1 words, whatever the number of segments)
+  return ((size_t)(lanes ? c->n_lanes : 1) * g.P1 + g.n_pages) * 4 + 64;
 }
 
 // Room for the partition cursors of the next paged pass; *n_words = how many k_mark_starts clears.
 static int prepare_cursors(shk_ctx *c, bool multi, bool defer, uint32_t *n_words) {
   const PartGeom g = part_geom(c);
+  HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, multi)));
+  if (defer && xl_route(c, g, multi, defer)) {  // one segment's cursors: [lane][super-page of the share]
+    *n_words = c->n_lanes << (g.log_p1 - g.lw);
+    return SHK_OK;
+  }
   if (defer) {  // the page regions' cursors persist; only a level-1 pass has per-launch cursors
-    HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, multi)));
     *n_words = g.two_level ? g.P1 : 0;
     return SHK_OK;
   }
   const size_t lanes = use_all_lanes(c, g, multi) ? c->n_lanes : 1;
-  HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, multi)));
   *n_words = (uint32_t)(lanes * g.P1) + (g.two_level ? g.n_pages : 0);
   return SHK_OK;
 }
@@ -653,7 +697,7 @@ static hipError_t scatter32_variant(shk_ctx *c, bool set_attr, uint32_t G, size_
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, W, LP, A>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX);
   hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, W, LP, A>), dim3(G), dim3(SC32_NT), lds, c->stream, b, log_p1,
-                     lane_filter, cursor, cap, buf, c->d_stats, c->d_lane_bases, sp, dbg, NL);
+                     lane_filter, cursor, cap, buf, c->d_stats, c->d_lane_bases, sp, dbg, NL, OwnerCfg{});
   return hipSuccess;
 }
 static int launch_scatter32(shk_ctx *c, bool wide, uint32_t G, size_t lds, const BatchRef &b, uint32_t log_p1,
@@ -674,8 +718,213 @@ static int launch_scatter32(shk_ctx *c, bool wide, uint32_t G, size_t lds, const
   return SHK_OK;
 }
 
+// ---- the owner layout -------------------------------------------------------------------------------
+struct XlPlan {
+  uint32_t log_p1w, n_grp, cap1, n_seg;  // super-page bits of a share; regions per segment; records per region; segments
+  uint64_t seg_recs;                     // records per segment
+};
+// Geometry of one launch's level-1 buffer: every (lane, partition) region gets the per-lane share of the
+// launch's k-mers (blocks of 1000 reads go round the lanes) + 50 % for uneven read lengths + 25 % + slack;
+// what still overflows takes the spill path.
+static XlPlan xl_plan(const shk_ctx *c, const PartGeom &g, uint64_t sub_kmers_ub, bool keep_all) {
+  XlPlan x{};
+  const uint32_t NL = c->n_lanes;
+  x.log_p1w = g.log_p1 - g.lw;
+  x.n_grp = NL << x.log_p1w;
+  uint64_t lane_kmers_ub = sub_kmers_ub;
+  if (NL > 1) {
+    const uint64_t nb = std::max<uint64_t>(c->cur_blocks, 1);
+    const uint64_t per_lane_blocks = (nb + NL - 1) / NL;
+    lane_kmers_ub = std::min<uint64_t>(sub_kmers_ub, sub_kmers_ub / nb * per_lane_blocks * 3 / 2 + 2 * TILE_T);
+  }
+  x.cap1 = (region_cap(lane_kmers_ub, g.P1, 0) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
+  x.n_seg = keep_all ? 1u << g.lw : 1u;
+  x.seg_recs = (uint64_t)x.n_grp * x.cap1;
+  return x;
+}
+
+template <int LP>
+static hipError_t scatter32_own_variant(shk_ctx *c, bool set_attr, uint32_t G, size_t lds, const BatchRef &b, uint32_t log_p1,
+                                        unsigned int *cursor, uint32_t cap, uint32_t *buf, SpillRef sp, uint32_t NL, OwnerCfg own) {
+  if (set_attr)
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter32<SC32_NT, SC32_TT, false, LP, true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX);
+  hipLaunchKernelGGL((k_scatter32<SC32_NT, SC32_TT, false, LP, true, true>), dim3(G), dim3(SC32_NT), lds, c->stream, b, log_p1,
+                     0xFFFFFFFFu, cursor, cap, buf, c->d_stats, c->d_lane_bases, sp, (unsigned long long *)nullptr, NL, own);
+  return hipSuccess;
+}
+
+// Level-1 scatter of b's tiles into the owner layout (c->xbuf, cursors at the start of c->part_meta).
+// keep_all: every owner's records, one segment per owner, overflow to the foreign spill list; otherwise
+// only this context's own records, one segment, overflow to `sp`.
+static int xl_scatter(shk_ctx *c, const BatchRef &b, const PartGeom &g, const XlPlan &x, SpillRef sp, bool keep_all,
+                      bool prezeroed) {
+  const uint32_t NL = c->n_lanes;
+  const uint64_t total = (uint64_t)x.n_seg * x.seg_recs;
+  if (total * 4 > 0xFFFFFFFFull)
+    return fail(c, SHK_ERR_INVARIANT, "level-1 buffer of one launch exceeds 4 GiB (%llu records)", (unsigned long long)total);
+  HIPC(c, c->xbuf.ensure(total * 4));
+  unsigned int *cursor = (unsigned int *)c->part_meta.p;
+  const size_t n_words = (size_t)x.n_seg * x.n_grp;
+  if (c->part_meta.cap < n_words * 4) return fail(c, SHK_ERR_INVARIANT, "cursor buffer too small for the owner layout");
+  if (!prezeroed) HIPC(c, hipMemsetAsync(cursor, 0, n_words * 4, c->stream));
+  if (!c->lds_attr_scatter_own) {
+    HIPC(c, scatter32_own_variant<0>(c, true, 0, 0, b, 0, nullptr, 0, nullptr, sp, NL, OwnerCfg{}));
+    HIPC(c, scatter32_own_variant<10>(c, true, 0, 0, b, 0, nullptr, 0, nullptr, sp, NL, OwnerCfg{}));
+    c->lds_attr_scatter_own = true;
+  }
+  OwnerCfg own{};
+  own.log_w = g.lw;
+  own.keep = keep_all ? 0xFFFFFFFFu : c->owner_id;
+  own.seg_recs = keep_all ? (uint32_t)x.seg_recs : 0u;
+  const uint32_t G = std::min<uint32_t>(grid_for(b.tile_count, 1, (uint32_t)env_int("SHK_PART_G", 512)), c->n_cus);
+  const size_t lds = scatter32_lds(g.P1);
+  {
+    ScopedTimer t(c, SHK_K_SCATTER, /*chain=*/prezeroed && c->chain_from_mark);
+    c->chain_from_mark = false;
+    if (g.log_p1 == 10)
+      HIPC(c, scatter32_own_variant<10>(c, false, G, lds, b, g.log_p1, cursor, x.cap1, (uint32_t *)c->xbuf.p, sp, NL, own));
+    else
+      HIPC(c, scatter32_own_variant<0>(c, false, G, lds, b, g.log_p1, cursor, x.cap1, (uint32_t *)c->xbuf.p, sp, NL, own));
+  }
+  return SHK_OK;
+}
+
+// Level-2 pass over ONE owner segment (this context's share: `regions` = [lane][super-page] regions of
+// `cap1` records each, fill levels in src_cursor) into the waiting (lane, page) regions.
+static int xl_absorb(shk_ctx *c, const PartGeom &g, const uint32_t *src_buf, const unsigned int *src_cursor, uint32_t cap1,
+                     uint32_t n_grp, SpillRef sp) {
+  const uint32_t NL = c->n_lanes, n_pages = g.n_pages;
+  const uint32_t log_p1w = g.log_p1 - g.lw;
+  if (n_grp != NL << log_p1w) return fail(c, SHK_ERR_BAD_ARG, "segment has %u regions, this context expects %u", n_grp, NL << log_p1w);
+  if (!c->acc_cur.p || c->acc_lp != g.lp || !c->acc_rec32 || c->acc_region_lanes != NL)
+    return fail(c, SHK_ERR_INVARIANT, "accumulation regions not planned for the owner layout");
+  const uint32_t r1_bits = 2 * c->cfg.k - g.log_p1;
+  const uint32_t S = 1u << g.log_sub;
+  const size_t lds_rs32 = (size_t)RS32_TILE * 4 + (size_t)RS32_TILE * 2 + (size_t)S * 12;
+  if (lds_rs32 > 64 * 1024 && !c->lds_attr_rescatter) {
+    HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_rescatter32),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
+    c->lds_attr_rescatter = true;
+  }
+  const uint32_t tiles_per_region = (cap1 + (uint32_t)RS32_TILE - 1) / (uint32_t)RS32_TILE;
+  ScopedTimer t(c, SHK_K_PSCAN, /*chain=*/true);
+  hipLaunchKernelGGL(k_part_rescatter32, dim3(n_grp * tiles_per_region), dim3(RS32_NT), lds_rs32, c->stream, src_buf, src_cursor,
+                     cap1, tiles_per_region, g.log_sub, r1_bits, 2 * c->cfg.k, (unsigned int *)c->acc_cur.p, c->acc_cap,
+                     (uint32_t *)c->acc_buf.p, 0u, c->d_stats, sp, 0ull, (uint64_t)NL * n_pages, log_p1w,
+                     c->owner_id << log_p1w, (uint64_t)n_pages);
+  HIPC(c, hipGetLastError());
+  return SHK_OK;
+}
+
+// One deferred counting launch on the owner-layout route: scatter (own records only), then absorb.
+static int xl_count(shk_ctx *c, const BatchRef &b, const PartGeom &g, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed) {
+  const XlPlan x = xl_plan(c, g, sub_kmers_ub, /*keep_all=*/false);
+  int rc = xl_scatter(c, b, g, x, sp, /*keep_all=*/false, prezeroed);
+  if (rc != SHK_OK) return rc;
+  return xl_absorb(c, g, (const uint32_t *)c->xbuf.p, (const unsigned int *)c->part_meta.p, x.cap1, x.n_grp, sp);
+}
+
+// ---- exchange rounds between owner shares (shk_xchg_*) ------------------------------------------------
+struct XchgOut {
+  uint64_t layout_bases;  // in: what every rank sizes its segments for (0: this batch)
+  void *d_records, *d_cursors;
+  shk_xchg_layout lay;
+  uint64_t n_foreign;
+};
+// The exchange layout depends only on (layout_bases, n_lanes, geometry), never on the batch at hand: every
+// rank of a round must come out with the same segment size.
+static XlPlan xchg_plan(const shk_ctx *c, const PartGeom &g, uint64_t layout_bases) {
+  XlPlan x{};
+  const uint32_t NL = c->n_lanes;
+  x.log_p1w = g.log_p1 - g.lw;
+  x.n_grp = NL << x.log_p1w;
+  const uint64_t B = (layout_bases + TILE_T - 1) / TILE_T * TILE_T;
+  const uint64_t lane_kmers_ub = NL > 1 ? std::min<uint64_t>(B, B / NL * 3 / 2 + 262144) : B;
+  x.cap1 = (region_cap(lane_kmers_ub, g.P1, 0) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
+  x.n_seg = 1u << g.lw;
+  x.seg_recs = (uint64_t)x.n_grp * x.cap1;
+  return x;
+}
+static int xchg_check(shk_ctx *c, const PartGeom &g) {
+  if (!c->owner_bits) return fail(c, SHK_ERR_STATE, "not an owner share (shk_config.n_owners ≤ 1)");
+  if (!xl_feasible(c, g) || count_path(c, 0) != PATH_DEFER)
+    return fail(c, SHK_ERR_STATE,
+                "the owner exchange needs 4-byte records (2k - %u ≤ 32) and ≤ 16 chunk lanes at this table geometry; "
+                "merge the tables at finalize instead", g.log_p1);
+  return SHK_OK;
+}
+static int xchg_prepare_cursors(shk_ctx *c, uint32_t *n_words) {
+  const PartGeom g = part_geom(c);
+  int rc = xchg_check(c, g);
+  if (rc != SHK_OK) return rc;
+  HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, true)));
+  *n_words = c->n_lanes * g.P1;  // every segment's cursors
+  return SHK_OK;
+}
+static SpillRef xspill_ref(shk_ctx *c) {
+  SpillRef sp = spill_ref(c->xspill, c->xspill_cap);
+  sp.count = &c->d_stats->scratch[0];
+  return sp;
+}
+static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo) {
+  const PartGeom g = part_geom(c);
+  int rc = xchg_check(c, g);
+  if (rc != SHK_OK) return rc;
+  const uint64_t lb = xo->layout_bases ? xo->layout_bases : std::max<uint64_t>(kmers_ub, TILE_T);
+  if (kmers_ub > (lb + TILE_T - 1) / TILE_T * TILE_T) return fail(c, SHK_ERR_BAD_ARG, "batch larger than the exchange layout it is to use");
+  const XlPlan x = xchg_plan(c, g, lb);
+  // the foreign spill list: whatever it holds already stays (the caller drains it between rounds)
+  const uint64_t pending = c->h_stats->scratch[0];
+  const uint64_t want_cap = pending + std::max<uint64_t>(kmers_ub, 1);
+  if (want_cap > c->xspill_cap) {
+    DevBuf nb;
+    HIPC(c, nb.ensure(want_cap * 16));
+    const uint64_t ncap = nb.cap / 16;
+    if (pending) {  // (rare: skewed input two rounds in a row without a drain)
+      SpillRef o = spill_ref(c->xspill, c->xspill_cap), n = spill_ref(nb, ncap);
+      HIPC(c, hipMemcpyAsync(n.keys, o.keys, pending * 8, hipMemcpyDeviceToDevice, c->stream));
+      HIPC(c, hipMemcpyAsync(n.lanes, o.lanes, pending * 4, hipMemcpyDeviceToDevice, c->stream));
+      HIPC(c, hipMemcpyAsync(n.counts, o.counts, pending * 4, hipMemcpyDeviceToDevice, c->stream));
+      HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    c->xspill.release();
+    c->xspill = nb;
+    c->xspill_cap = ncap;
+  }
+  if (kmers_ub) {
+    rc = xl_scatter(c, b, g, x, xspill_ref(c), /*keep_all=*/true, /*prezeroed=*/true);
+    if (rc != SHK_OK) return rc;
+  } else {  // an empty batch still takes part in the round: all-zero cursors
+    HIPC(c, c->xbuf.ensure((uint64_t)x.n_seg * x.seg_recs * 4));
+    HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, true)));
+    HIPC(c, hipMemsetAsync(c->part_meta.p, 0, (size_t)x.n_seg * x.n_grp * 4, c->stream));
+  }
+  rc = read_stats(c);  // (synchronises: the segments are complete when this call returns)
+  if (rc != SHK_OK) return rc;
+  if (c->h_stats->bad != ~0ull) {
+    c->poisoned = true;
+    c->poison_code = SHK_ERR_INVALID_CHAR;
+    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%c' in sequence. Only ACGTN allowed.", (char)(c->h_stats->bad & 0xFF));
+  }
+  if (c->h_stats->scratch[0] > c->xspill_cap) return fail(c, SHK_ERR_INVARIANT, "foreign spill list overflow");
+  xo->d_records = c->xbuf.p;
+  xo->d_cursors = c->part_meta.p;
+  xo->lay.n_owners = c->n_owners;
+  xo->lay.n_lanes = c->n_lanes;
+  xo->lay.log_p1 = g.log_p1;
+  xo->lay.regions = x.n_grp;
+  xo->lay.region_cap = x.cap1;
+  xo->lay.reserved = 0;
+  xo->lay.segment_records = x.seg_recs;
+  xo->n_foreign = c->h_stats->scratch[0];
+  return SHK_OK;
+}
+
 static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed, bool defer) {
   const PartGeom pg = part_geom(c);
+  if (xl_route(c, pg, b.tiles != nullptr, defer)) return xl_count(c, b, pg, sub_kmers_ub, sp, prezeroed);
+  if (pg.lw) return fail(c, SHK_ERR_INVARIANT, "an owner share has no paged path besides the owner layout");
   const uint32_t lp = pg.lp, n_pages = pg.n_pages, log_p1 = pg.log_p1, log_sub = pg.log_sub, P1 = pg.P1;
   const bool two_level = pg.two_level;
   const uint32_t g_cap = (uint32_t)env_int("SHK_PART_G", 512);
@@ -782,12 +1031,12 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
                            (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
                            log_sub, r1_bits, 2 * c->cfg.k, (unsigned int *)c->acc_cur.p, c->acc_cap,
                            (uint32_t *)c->acc_buf.p, lane, c->d_stats, sp, (uint64_t)lane * n_pages,
-                           (uint64_t)NL * n_pages);
+                           (uint64_t)NL * n_pages, 31u, 0u, 0ull);
       else if (rec32)
         hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS32_NT), lds_rs32, c->stream,
                            (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
                            log_sub, r1_bits, 2 * c->cfg.k, cursor_pg, cap_pg, (uint32_t *)buf_pg.p, lane,
-                           c->d_stats, sp, 0ull, (uint64_t)n_pages);
+                           c->d_stats, sp, 0ull, (uint64_t)n_pages, 31u, 0u, 0ull);
       else if (defer)  // append to this lane's accumulation regions (8-byte records)
         hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
                            (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
@@ -828,10 +1077,19 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   return SHK_OK;
 }
 
+// Records a launch of ≤ kmers_ub k-mer occurrences adds to the waiting regions: all of them, or — an
+// owner share keeps the k-mers of one owner in W, owners being hash bits — about 1/W of them (+ 1/8 +
+// slack; a region that overflows all the same spills, exactly).
+static uint64_t acc_records_est(const shk_ctx *c, uint64_t kmers_ub) {
+  if (!c->owner_bits) return kmers_ub;
+  const uint64_t share = kmers_ub >> c->owner_bits;
+  return std::min<uint64_t>(kmers_ub, share + share / 8 + 65536);
+}
+
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed) {
   CountPath path = count_path(c, sub_kmers_ub);
   if (path == PATH_DEFER) {  // (the first launch of an ingest was planned before k_mark_starts)
-    int rc = acc_prepare(c, sub_kmers_ub);
+    int rc = acc_prepare(c, acc_records_est(c, sub_kmers_ub));
     if (rc != SHK_OK) return rc;
     path = count_path(c, sub_kmers_ub);  // a flush may have grown the table
     if (path == PATH_DEFER && !c->acc_cur.p) return fail(c, SHK_ERR_INVARIANT, "accumulation regions missing");
@@ -852,7 +1110,7 @@ static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, boo
     if (rc != SHK_OK) return rc;
     if (path == PATH_DEFER) {
       c->acc_active = true;
-      c->acc_records_ub += sub_kmers_ub;
+      c->acc_records_ub += acc_records_est(c, sub_kmers_ub);
     }
   } else {
     {  // validate + count bases first (encoding.rs:353-356, 374-376); k_direct tests stats->bad
@@ -885,7 +1143,7 @@ static int settle_checked(shk_ctx *c) {
   if (rc != SHK_OK) return rc;
   // keep the load factor ≤ 1/2 for the next launch
   if (c->h_stats->n_distinct * 2 > c->tb.cap) {
-    rc = grow_to(c, log_pages_for(c->h_stats->n_distinct * 4));
+    rc = grow_to(c, log_pages_for(c->h_stats->n_distinct * 4, c->owner_bits));
     if (rc != SHK_OK) return rc;
   }
   return SHK_OK;
@@ -1002,9 +1260,26 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
     return fail(nullptr, SHK_ERR_NO_DEVICE, "device %d is %s; libshk is built for gfx950 only",
                 cfg->device, prop.gcnArchName);
 
+  if (cfg->n_owners > 1) {
+    if (cfg->n_owners > 64 || (cfg->n_owners & (cfg->n_owners - 1)))
+      return fail(nullptr, SHK_ERR_BAD_ARG, "n_owners must be a power of two ≤ 64, got %u", cfg->n_owners);
+    if (cfg->owner_id >= cfg->n_owners)
+      return fail(nullptr, SHK_ERR_BAD_ARG, "owner_id %u out of range (n_owners %u)", cfg->owner_id, cfg->n_owners);
+  }
   shk_ctx *c = new shk_ctx();
   c->cfg = *cfg;
+  c->cfg.device_ids = nullptr;
+  c->cfg.n_devices = 0;
   c->n_lanes = cfg->chunks == 0 ? 1 : cfg->chunks;  // io.rs:378
+  if (cfg->n_owners > 1) {
+    c->n_owners = cfg->n_owners;
+    c->owner_id = cfg->owner_id;
+    while ((1u << c->owner_bits) < c->n_owners) c->owner_bits++;
+    if (2 * cfg->k < c->owner_bits + 1) {
+      delete c;
+      return fail(nullptr, SHK_ERR_BAD_ARG, "k = %u leaves no key bits below %u owner bits", cfg->k, c->owner_bits);
+    }
+  }
   if (prop.multiProcessorCount > 0) c->n_cus = (uint32_t)prop.multiProcessorCount;
   c->lane_reads.assign(c->n_lanes, 0);
   auto bail = [&](int code) {
@@ -1041,7 +1316,7 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   c->h_hist = (const uint64_t *)(c->h_ctl + c->ctl_hist_off);
   c->h_stats->bad = ~0ull;
   uint64_t want = cfg->table_capacity_hint ? cfg->table_capacity_hint * 2 : (1ull << 20);
-  int rc = alloc_table(c, log_pages_for(want), &c->tb);
+  int rc = alloc_table(c, log_pages_for(want, c->owner_bits), &c->tb);
   if (rc == SHK_OK) rc = fill_state(c, c->tb, true);
   if (rc != SHK_OK) return bail(rc);
   HIPB(hipStreamSynchronize(c->stream));
@@ -1081,6 +1356,8 @@ void shk_destroy(shk_ctx *c) {
   c->part_meta.release();
   c->acc_buf.release();
   c->acc_cur.release();
+  c->xbuf.release();
+  c->xspill.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1101,7 +1378,7 @@ int shk_reset(shk_ctx *c) {
   c->n_inserted = 0;
   c->own_set = false;
   c->zero_count_keys = false;
-  c->finalized = c->poisoned = false;
+  c->finalized = c->poisoned = c->hist_ready = false;
   c->unsettled = false;  // the memsets above are ordered behind any launch still in flight
   c->acc_active = false;  // (the regions' cursors are cleared when they are planned again)
   c->acc_records_ub = 0;
@@ -1226,7 +1503,7 @@ int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, cons
   if (chunk_id >= c->n_lanes) return fail(c, SHK_ERR_BAD_ARG, "chunk_id out of range");
   if (n == 0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
-  c->finalized = false;
+  c->finalized = c->hist_ready = false;
   const uint64_t kmax = c->cfg.k >= 32 ? ~0ull : ((1ull << (2 * c->cfg.k)) - 1);
   for (uint64_t i = 0; i < n; ++i) {
     if (kmers[i] > kmax) return fail(c, SHK_ERR_BAD_ARG, "kmer %llu does not fit k=%u",
@@ -1254,6 +1531,119 @@ int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, cons
   return drain_spill(c, n);
 }
 
+int shk_xchg_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases,
+                            uint64_t layout_bases, void **d_records, void **d_cursors, shk_xchg_layout *layout,
+                            uint64_t *n_foreign_spilled) {
+  if (!c || !d_records || !d_cursors || !layout) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  if (n_bases > SHK_XCHG_MAX_BASES || (layout_bases && layout_bases > SHK_XCHG_MAX_BASES))
+    return fail(c, SHK_ERR_BAD_ARG, "an exchange batch takes at most %llu bases", (unsigned long long)SHK_XCHG_MAX_BASES);
+  XchgOut xo{};
+  xo.layout_bases = layout_bases;
+  int rc = ingest_core(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_seqs, n_bases, -1, &xo);
+  if (rc != SHK_OK) return rc;
+  *d_records = xo.d_records;
+  *d_cursors = xo.d_cursors;
+  *layout = xo.lay;
+  if (n_foreign_spilled) *n_foreign_spilled = xo.n_foreign;
+  return SHK_OK;
+}
+
+int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, const shk_xchg_layout *lay) {
+  if (!c || !lay) return SHK_ERR_BAD_ARG;
+  if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  HIPC(c, hipSetDevice(c->cfg.device));
+  PartGeom g = part_geom(c);
+  int rc = xchg_check(c, g);
+  if (rc != SHK_OK) return rc;
+  if (lay->n_owners != c->n_owners || lay->n_lanes != c->n_lanes || lay->log_p1 != g.log_p1 ||
+      lay->regions != c->n_lanes << (g.log_p1 - g.lw) || lay->region_cap == 0 || (lay->region_cap & ((1u << RB_LOG) - 1u)) ||
+      lay->segment_records != (uint64_t)lay->regions * lay->region_cap)
+    return fail(c, SHK_ERR_BAD_ARG, "exchange segment layout does not match this context (owners %u/%u, lanes %u/%u, level-1 bits %u/%u)",
+                lay->n_owners, c->n_owners, lay->n_lanes, c->n_lanes, lay->log_p1, g.log_p1);
+  if (!d_records || !d_cursors) return fail(c, SHK_ERR_BAD_ARG, "null segment");
+  c->finalized = c->hist_ready = false;
+  // a segment's regions are sized 1.25 × (1.5 ×) their expected fill: 4/5 of it bounds what it holds in practice
+  uint64_t est = lay->segment_records / 5 * 4 + 1024;
+  if (c->acc_active && c->acc_spill_cap) est = std::min<uint64_t>(est, c->acc_spill_cap);
+  rc = acc_prepare(c, est);  // (may count what is waiting first: launch + settle)
+  if (rc != SHK_OK) return rc;
+  g = part_geom(c);  // a settle may have grown the table
+  rc = xchg_check(c, g);
+  if (rc != SHK_OK) return rc;
+  const uint64_t spill_cap = std::max<uint64_t>(c->acc_spill_cap, est);
+  c->acc_spill_cap = spill_cap;
+  if (c->spillA.cap < spill_cap * 16) {
+    if (c->unsettled) {  // (its list is about to move)
+      rc = settle(c);
+      if (rc != SHK_OK) return rc;
+      rc = acc_prepare(c, est);
+      if (rc != SHK_OK) return rc;
+      g = part_geom(c);
+    }
+    HIPC(c, c->spillA.ensure(spill_cap * 16));
+  }
+  SpillRef sp = spill_ref(c->spillA, spill_cap);
+  rc = xl_absorb(c, g, (const uint32_t *)d_records, (const unsigned int *)d_cursors, lay->region_cap, lay->regions, sp);
+  if (rc != SHK_OK) return rc;
+  c->acc_active = true;
+  c->acc_records_ub += est;
+  c->unsettled = true;
+  c->unsettled_spill_cap = spill_cap;
+  return SHK_OK;
+}
+
+int shk_xchg_spill(shk_ctx *c, void **d_kmers, void **d_lanes, void **d_counts, uint64_t *n) {
+  if (!c || !n) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  int rc = read_stats(c);
+  if (rc != SHK_OK) return rc;
+  const SpillRef sp = spill_ref(c->xspill, c->xspill_cap);
+  if (d_kmers) *d_kmers = sp.keys;
+  if (d_lanes) *d_lanes = sp.lanes;
+  if (d_counts) *d_counts = sp.counts;
+  *n = c->h_stats->scratch[0];
+  return SHK_OK;
+}
+
+int shk_xchg_spill_clear(shk_ctx *c) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  HIPC(c, hipMemsetAsync(&c->d_stats->scratch[0], 0, sizeof(unsigned long long), c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  c->h_stats->scratch[0] = 0;
+  return SHK_OK;
+}
+
+int shk_insert_device(shk_ctx *c, const void *d_kmers, const void *d_lanes, const void *d_counts, uint64_t n) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
+  if (n == 0) return SHK_OK;
+  if (!d_kmers) return fail(c, SHK_ERR_BAD_ARG, "null k-mers");
+  c->finalized = c->hist_ready = false;
+  int rc = ensure_capacity(c, n >> c->owner_bits);
+  if (rc != SHK_OK) return rc;
+  c->n_inserted += n;
+  HIPC(c, c->spillA.ensure(n * 16));
+  SpillRef sp = spill_ref(c->spillA, n);
+  HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  {
+    ScopedTimer t(c, SHK_K_INSERT);
+    hipLaunchKernelGGL(k_insert, dim3(grid_for(n, WG, 4096)), dim3(WG), 0, c->stream, (const uint64_t *)d_kmers,
+                       (const uint32_t *)d_lanes, (const uint32_t *)d_counts, n, 0u, c->tb, c->d_stats, sp);
+  }
+  rc = read_stats(c);
+  if (rc != SHK_OK) return rc;
+  return drain_spill(c, n);
+}
+
+void *shk_stream(shk_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
 int shk_sync(shk_ctx *c) {
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -1269,7 +1659,7 @@ int shk_finalize(shk_ctx *c) {
   HIPC(c, hipSetDevice(c->cfg.device));
   uint64_t n_reads = 0;
   for (auto v : c->lane_reads) n_reads += v;
-  if (n_reads == 0 && c->n_inserted == 0 && !c->own_set)  // io.rs:578-580
+  if (n_reads == 0 && c->n_inserted == 0 && !c->own_set && !c->owner_bits)  // io.rs:578-580 (owner shares: the caller looks at the sum over the shares)
     return fail(c, SHK_ERR_NO_READS,
                 "No reads were ingested. Check that input files contain valid FASTQ records.");
   if (c->acc_active) {  // records still waiting for their page pass
@@ -1329,6 +1719,7 @@ int shk_finalize(shk_ctx *c) {
     if (rcs != SHK_OK) return rcs;
     if (redo) return shk_finalize(c);
   }
+  c->hist_ready = true;
   if (!c->own_set) {
     // io.rs:1042-1047 (and :1150-1155 for chunks==0)
     if (c->h_tot.n_hashed != c->h_tot.n_lane_sum)
@@ -1352,7 +1743,7 @@ int shk_finalize(shk_ctx *c) {
 
 int shk_histograms(shk_ctx *c, uint64_t *out) {
   if (!c) return SHK_ERR_BAD_ARG;
-  if (!c->finalized) return fail(c, SHK_ERR_STATE, "shk_histograms before shk_finalize");
+  if (!c->finalized && !c->hist_ready) return fail(c, SHK_ERR_STATE, "shk_histograms before shk_finalize");
   if (c->cfg.chunks == 0) return SHK_OK;
   if (!out) return fail(c, SHK_ERR_BAD_ARG, "null output");
   memcpy(out, c->h_hist, (size_t)c->cfg.chunks * (c->cfg.histo_max + 2) * sizeof(uint64_t));
@@ -1369,13 +1760,13 @@ int shk_get_counters(shk_ctx *c, shk_counters *o) {
   memset(o, 0, sizeof *o);
   for (auto v : c->lane_reads) o->n_reads_ingested += v;
   o->n_bases_read = c->n_bases_read;
-  if (!c->finalized) {  // (finalize has just brought the whole control block back)
+  if (!c->finalized && !c->hist_ready) {  // (finalize has just brought the whole control block back)
     HIPC(c, hipMemcpyAsync(c->h_lane_bases, c->d_lane_bases, sizeof(unsigned long long) * c->n_lanes,
                            hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
   }
   for (uint32_t l = 0; l < c->n_lanes; ++l) o->n_bases_ingested += c->h_lane_bases[l];
-  if (c->finalized) {
+  if (c->finalized || c->hist_ready) {
     o->n_kmers_ingested = c->h_tot.n_lane_sum;
     o->n_unique_kmers = c->h_tot.n_unique;
     o->n_hashed_kmers = c->h_tot.n_hashed;
@@ -1639,7 +2030,7 @@ int shk_table_reserve_pages(shk_ctx *c, uint64_t n_pages) {
   }
   uint32_t lp = 0;
   while ((1ull << lp) < n_pages) lp++;
-  c->finalized = false;
+  c->finalized = c->hist_ready = false;
   return grow_to(c, lp);
 }
 
@@ -1665,7 +2056,7 @@ int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, co
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
   }
-  c->finalized = false;
+  c->finalized = c->hist_ready = false;
   c->zero_count_keys = true;  // (a peer's table may hold keys inserted with count 0: keep reading the keys)
   const uint64_t n_slots = (p1 - p0) << PAGE_LOG;
   // worst case every peer key is new here
@@ -1731,7 +2122,7 @@ int shk_merge_entries(shk_ctx *c, const void *d_keys, const void *d_vals, uint64
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
   }
-  c->finalized = false;
+  c->finalized = c->hist_ready = false;
   c->zero_count_keys = true;  // (a peer's table may hold keys inserted with count 0: keep reading the keys)
   HIPC(c, c->spillA.ensure(n * c->n_lanes * 16));  // worst case every entry spills on every lane
   SpillRef sp = spill_ref(c->spillA, n * c->n_lanes);
@@ -1752,7 +2143,7 @@ int shk_set_owned_pages(shk_ctx *c, uint64_t p0, uint64_t p1) {
   c->own_p0 = p0;
   c->own_p1 = p1;
   c->own_set = true;
-  c->finalized = false;
+  c->finalized = c->hist_ready = false;
   return SHK_OK;
 }
 

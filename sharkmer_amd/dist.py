@@ -43,6 +43,162 @@ def shard_batches(n_reads: int, rank: int, world: int, batch: int = 1000):
     return out
 
 
+class OwnerCounter:
+    """KEY-SPACE-PARTITIONED ingest ("alternative when local tables do not fit"; what
+    BASELINE configs[4] — 10 cumulative lanes × a 3 Gb-genome load — needs: 48 B × 2^33 slots do not fit
+    one GPU, 1/8 of them does).  Rank r's engine is an OWNER SHARE (n_owners = world, owner_id = r): it
+    holds the k-mers whose owner bits (the top log2 W bits of the engine's key mix) equal r and nothing
+    else, so no table is ever exchanged; what crosses the links instead, during ingest, is every batch's
+    4-byte k-mer records grouped by owner.
+
+    One ROUND (collective: every rank calls `round` the same number of times, with an empty batch when it
+    has run out of reads):
+      1. engine.xchg_scatter: validate + extract + level-1 partition of the rank's batch; owner o's
+         records and their fill levels are one contiguous segment each;
+      2. ONE all_to_all_single per array with equal splits (fully connected xGMI: the W-1 transfers of a
+         rank run concurrently);
+      3. engine.xchg_absorb on each of the W received segments (level-2 partition into the waiting
+         (lane, page) regions; the page pass runs when enough has accumulated);
+      4. a 2-word all_reduce(MAX) carries (somebody hit an invalid byte, somebody has foreign spills);
+         foreign spills — records that overflowed a region on skewed input — are all-gathered and every
+         rank inserts what it owns: exact for any input.
+    Bytes on a link per round: one segment = regions × region_cap × 4 B ≈ 1.25 (× 1.5 with several
+    lanes) × 4 B × 0.87 × batch bases / W.  With a CUDA engine the collectives are queued on the engine's
+    own HIP stream (torch.cuda.ExternalStream), so a round needs no host-side synchronisation besides the
+    one the scatter does to report its outcome.
+
+    finalize_histograms: every rank's histogram covers its share; bins are additive across disjoint key
+    sets (KmerCounts::extend, counting.rs:157-166), so one all_reduce(SUM) of histogram + totals
+    finishes the job (io.rs:1023-1028 semantics on the union of all reads).
+
+    The engine is duck-typed (`xchg_scatter_tensors, xchg_absorb_tensors, xchg_spill_tensors,
+    insert_tensors, xchg_spill_clear, set_read_index, finalize, histograms, counters, stream`)."""
+
+    def __init__(self, engine, dist, device=None, round_bases: int = 1 << 28):
+        self.eng, self.dist = engine, dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.device = device
+        self.round_bases = int(round_bases)
+        self._recv = None
+        self.n_rounds = 0
+        self.n_foreign_rounds = 0   # rounds in which somebody had foreign spills to hand on
+        self.wire_bytes = 0
+
+    def _dev(self, t):
+        return t if self.device is None else t.to(f"cuda:{self.device}")
+
+    def _on_engine_stream(self):
+        import contextlib
+        if self.device is None:
+            return contextlib.nullcontext()
+        ext = torch.cuda.ExternalStream(self.eng.stream(), device=f"cuda:{self.device}")
+        return torch.cuda.stream(ext)
+
+    def round(self, batch=None):
+        """batch = (bases, offsets, n_seqs, n_bases, first_read_index) — device pointers for the HIP
+        engine — or None.  n_bases ≤ round_bases."""
+        dist, W = self.dist, self.world
+        err = None
+        try:
+            if batch is not None:
+                self.eng.set_read_index(batch[4])
+                rec, cur, lay, n_foreign = self.eng.xchg_scatter_tensors(batch[0], batch[1], batch[2], batch[3], self.round_bases)
+            else:
+                rec, cur, lay, n_foreign = self.eng.xchg_scatter_tensors(0, 0, 0, 0, self.round_bases)
+        except Exception as e:  # noqa: BLE001 — reported to every rank below
+            err, n_foreign = e, 0
+        with self._on_engine_stream():
+            st = self._dev(torch.tensor([1 if err is not None else 0, n_foreign], dtype=torch.int64))
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            any_err, any_foreign = (int(x) for x in st.cpu())
+            if any_err:
+                raise err if err is not None else RuntimeError("a peer rank failed in this exchange round")
+            if self._recv is None or self._recv[0].numel() != rec.numel() or self._recv[1].numel() != cur.numel():
+                self._recv = (torch.empty_like(rec), torch.empty_like(cur))
+            rrec, rcur = self._recv
+            dist.all_to_all_single(rrec, rec)
+            dist.all_to_all_single(rcur, cur)
+            S, G = lay.segment_records, lay.regions
+            for s in range(W):
+                self.eng.xchg_absorb_tensors(rrec[s * S:(s + 1) * S], rcur[s * G:(s + 1) * G], lay)
+            if any_foreign:
+                self.n_foreign_rounds += 1
+                self._exchange_spills()
+        self.n_rounds += 1
+        self.wire_bytes += (W - 1) * (lay.segment_records + lay.regions) * 4
+        return lay
+
+    def _exchange_spills(self):
+        """All-gather the foreign spill lists; every rank inserts what it owns (insert drops the rest)."""
+        dist, W = self.dist, self.world
+        k, l, c = self.eng.xchg_spill_tensors()
+        n = self._dev(torch.tensor([k.numel()], dtype=torch.int64))
+        ns = [torch.zeros_like(n) for _ in range(W)]
+        dist.all_gather(ns, n)
+        ns = [int(x.item()) for x in ns]
+        m = max(ns)
+        if m == 0:
+            return
+
+        def padded(t, dtype):
+            out = torch.zeros(m, dtype=dtype, device=t.device)
+            out[:t.numel()] = t
+            return out
+        for src_t, dtype, which in ((k, torch.int64, 0), (l, torch.int32, 1), (c, torch.int32, 2)):
+            parts = [torch.empty(m, dtype=dtype, device=src_t.device) for _ in range(W)]
+            dist.all_gather(parts, padded(src_t, dtype))
+            if which == 0:
+                gk = parts
+            elif which == 1:
+                gl = parts
+            else:
+                gc = parts
+        if k.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        for s in range(W):
+            if ns[s]:
+                self.eng.insert_tensors(gk[s][:ns[s]].contiguous(), gl[s][:ns[s]].contiguous(), gc[s][:ns[s]].contiguous())
+        self.eng.xchg_spill_clear()
+
+    def finalize_histograms(self):
+        dist = self.dist
+        err = None
+        try:
+            self.eng.finalize()
+            h = self.eng.histograms()
+            c = self.eng.counters()
+        except Exception as e:  # noqa: BLE001
+            err = e
+        names = ["n_reads_ingested", "n_bases_read", "n_bases_ingested", "n_kmers_ingested",
+                 "n_unique_kmers", "n_hashed_kmers", "any_saturated"]
+        if err is not None:
+            packed = np.zeros(1, dtype=np.int64)
+        else:
+            packed = np.concatenate([np.array([0] + [c[k] for k in names], dtype=np.int64), h.astype(np.int64).reshape(-1)])
+        flag = self._dev(torch.tensor([1 if err is not None else 0], dtype=torch.int64))
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise err if err is not None else RuntimeError("a peer rank failed in finalize")
+        pt = self._dev(torch.from_numpy(packed))
+        dist.all_reduce(pt, op=dist.ReduceOp.SUM)
+        red = pt.cpu().numpy()[1:]
+        self.totals = {k: int(v) for k, v in zip(names, red[:len(names)])}
+        self.totals["any_saturated"] = int(self.totals["any_saturated"] > 0)
+        hist = red[len(names):].astype(np.uint64).reshape(h.shape)
+        if self.totals["n_reads_ingested"] == 0:  # io.rs:578-580 on the whole job
+            raise RuntimeError("No reads were ingested. Check that input files contain valid FASTQ records.")
+        if hist.shape[0] > 0:
+            self.totals["n_singleton_kmers"] = int(hist[-1, 1])
+            if self.totals["n_hashed_kmers"] != self.totals["n_kmers_ingested"]:  # io.rs:1042-1047
+                raise RuntimeError(
+                    f"The total count of hashed kmers ({self.totals['n_hashed_kmers']}) does not equal "
+                    f"the number of ingested kmers ({self.totals['n_kmers_ingested']})")
+            if int(hist[-1, 1:].sum()) != self.totals["n_unique_kmers"]:  # io.rs:1127-1132
+                raise RuntimeError("The total count of unique kmers in the histogram does not equal "
+                                   "the total count of hashed kmers")
+        return hist
+
+
 class DistCounter:
     def __init__(self, engine, dist, device=None):
         self.eng = engine

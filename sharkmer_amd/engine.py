@@ -44,7 +44,16 @@ class ShkError(RuntimeError):
 class _Config(C.Structure):
     _fields_ = [("k", C.c_uint32), ("chunks", C.c_uint32), ("histo_max", C.c_uint64),
                 ("device", C.c_int32), ("flags", C.c_uint32),
-                ("table_capacity_hint", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+                ("table_capacity_hint", C.c_uint64), ("n_owners", C.c_uint32), ("owner_id", C.c_uint32),
+                ("n_devices", C.c_uint32), ("reserved32", C.c_uint32), ("device_ids", C.POINTER(C.c_int32)),
+                ("reserved", C.c_uint64 * 1)]
+
+
+class XchgLayout(C.Structure):
+    """shk_xchg_layout: how one exchange round's owner segments are laid out (include/shk.h)."""
+    _fields_ = [("n_owners", C.c_uint32), ("n_lanes", C.c_uint32), ("log_p1", C.c_uint32),
+                ("regions", C.c_uint32), ("region_cap", C.c_uint32), ("reserved", C.c_uint32),
+                ("segment_records", C.c_uint64)]
 
 
 class _Counters(C.Structure):
@@ -96,6 +105,8 @@ ABI_SYMBOLS = [
     "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_stats",
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
     "shk_run_error", "shk_run_files",
+    "shk_xchg_scatter_device", "shk_xchg_absorb", "shk_xchg_spill", "shk_xchg_spill_clear", "shk_insert_device",
+    "shk_stream",
 ]
 
 _lib = None
@@ -168,6 +179,14 @@ def load_library():
     L.shk_table_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.shk_merge_pages.argtypes = [vp, u64, u64, vp, vp, u64]
     L.shk_set_read_index.argtypes = [vp, u64]
+    L.shk_xchg_scatter_device.argtypes = [vp, vp, vp, u64, u64, u64, C.POINTER(vp), C.POINTER(vp),
+                                          C.POINTER(XchgLayout), C.POINTER(u64)]
+    L.shk_xchg_absorb.argtypes = [vp, vp, vp, C.POINTER(XchgLayout)]
+    L.shk_xchg_spill.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.shk_xchg_spill_clear.argtypes = [vp]
+    L.shk_insert_device.argtypes = [vp, vp, vp, vp, u64]
+    L.shk_stream.argtypes = [vp]
+    L.shk_stream.restype = vp
     L.shk_set_owned_pages.argtypes = [vp, u64, u64]
     L.shk_alloc_pinned.argtypes = [C.c_size_t]
     L.shk_alloc_pinned.restype = vp
@@ -206,11 +225,19 @@ class KmerEngine:
     CLI's rule).  capacity_hint: expected number of distinct k-mers."""
 
     def __init__(self, k: int, chunks: int = 0, histo_max: int = 10000, device: int = 0,
-                 capacity_hint: int = 0, flags: int = 0):
+                 capacity_hint: int = 0, flags: int = 0, n_owners: int = 0, owner_id: int = 0,
+                 device_ids=None):
+        """n_owners/owner_id: an OWNER SHARE — the context holds 1/n_owners of the key space
+        (shk_config.n_owners).  device_ids: a multi-device context (shk_config.n_devices)."""
         self._L = load_library()
         self.k, self.chunks, self.histo_max = k, chunks, histo_max
+        self.n_owners, self.owner_id = max(n_owners, 1), owner_id
         cfg = _Config(k=k, chunks=chunks, histo_max=histo_max, device=device, flags=flags,
-                      table_capacity_hint=capacity_hint)
+                      table_capacity_hint=capacity_hint, n_owners=n_owners, owner_id=owner_id)
+        if device_ids is not None:
+            ids = (C.c_int32 * len(device_ids))(*device_ids)
+            cfg.n_devices = len(device_ids)
+            cfg.device_ids = C.cast(ids, C.POINTER(C.c_int32))
         h = C.c_void_p()
         rc = self._L.shk_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -406,6 +433,32 @@ class KmerEngine:
     def merge_pages(self, p0: int, p1: int, d_keys: int, d_vals: int, lane_stride: int):
         self._check(self._L.shk_merge_pages(self._h, p0, p1, d_keys, d_vals, lane_stride))
 
+    # -- exchange rounds between owner shares (include/shk.h, shk_xchg_*) ---------------------
+    def stream(self) -> int:
+        return int(self._L.shk_stream(self._h) or 0)
+
+    def xchg_scatter_device(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int, layout_bases: int = 0):
+        """→ (d_records, d_cursors, XchgLayout, n_foreign_spilled)."""
+        rec, cur, lay, nf = C.c_void_p(), C.c_void_p(), XchgLayout(), C.c_uint64(0)
+        self._check(self._L.shk_xchg_scatter_device(self._h, d_bases, d_offsets, n_seqs, n_bases, layout_bases,
+                                                    C.byref(rec), C.byref(cur), C.byref(lay), C.byref(nf)))
+        return int(rec.value or 0), int(cur.value or 0), lay, int(nf.value)
+
+    def xchg_absorb(self, d_records: int, d_cursors: int, lay):
+        self._check(self._L.shk_xchg_absorb(self._h, d_records, d_cursors, C.byref(lay)))
+
+    def xchg_spill(self):
+        """→ (d_kmers, d_lanes, d_counts, n): the foreign spill list."""
+        k, l, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        self._check(self._L.shk_xchg_spill(self._h, C.byref(k), C.byref(l), C.byref(c), C.byref(n)))
+        return int(k.value or 0), int(l.value or 0), int(c.value or 0), int(n.value)
+
+    def xchg_spill_clear(self):
+        self._check(self._L.shk_xchg_spill_clear(self._h))
+
+    def insert_device(self, d_kmers: int, d_lanes: int, d_counts: int, n: int):
+        self._check(self._L.shk_insert_device(self._h, d_kmers, d_lanes, d_counts, n))
+
     def set_read_index(self, next_read_index: int):
         """Global index of the next read (chunk striping of a sharded stream)."""
         self._check(self._L.shk_set_read_index(self._h, next_read_index))
@@ -467,6 +520,43 @@ class KmerEngine:
             return
         assert keys_t.is_contiguous() and vals_t.stride(-1) == 1
         self._check(self._L.shk_merge_entries(self._h, keys_t.data_ptr(), vals_t.data_ptr(), n, vals_t.stride(0)))
+
+    # -- exchange rounds as torch tensors (sharkmer_amd/dist.py: OwnerCounter) -----------------------
+    @staticmethod
+    def _raw_tensor(ptr: int, n: int, typestr: str):
+        import torch
+
+        class _Raw:  # minimal __cuda_array_interface__ carrier
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr,
+                                                 "data": (ptr, False), "version": 2}
+        if n == 0 or not ptr:
+            return torch.empty(0, dtype={"<i4": torch.int32, "<i8": torch.int64}[typestr], device="cuda")
+        return torch.as_tensor(_Raw(ptr, (n,), typestr), device="cuda")
+
+    def xchg_scatter_tensors(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int, layout_bases: int = 0):
+        """One round's level-1 scatter → (records int32[W·segment_records], cursors int32[W·regions],
+        layout, n_foreign_spilled) as zero-copy views of the context's exchange buffer."""
+        rec, cur, lay, nf = self.xchg_scatter_device(d_bases, d_offsets, n_seqs, n_bases, layout_bases)
+        W = lay.n_owners
+        return (self._raw_tensor(rec, W * lay.segment_records, "<i4"), self._raw_tensor(cur, W * lay.regions, "<i4"),
+                lay, nf)
+
+    def xchg_absorb_tensors(self, rec_t, cur_t, lay):
+        assert rec_t.is_contiguous() and cur_t.is_contiguous()
+        assert rec_t.numel() == lay.segment_records and cur_t.numel() == lay.regions
+        self.xchg_absorb(rec_t.data_ptr(), cur_t.data_ptr(), lay)
+
+    def xchg_spill_tensors(self):
+        """(kmers int64[n], lanes int32[n], counts int32[n]) views of the foreign spill list."""
+        k, l, c, n = self.xchg_spill()
+        return self._raw_tensor(k, n, "<i8"), self._raw_tensor(l, n, "<i4"), self._raw_tensor(c, n, "<i4")
+
+    def insert_tensors(self, kmers_t, lanes_t, counts_t):
+        n = kmers_t.numel()
+        if n:
+            assert kmers_t.is_contiguous() and lanes_t.is_contiguous() and counts_t.is_contiguous()
+            self.insert_device(kmers_t.data_ptr(), lanes_t.data_ptr(), counts_t.data_ptr(), n)
 
     # -- device memory + synthetic input ---------------------------------------------
     def alloc_device(self, nbytes: int) -> int:

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in _header_functions():
         assert hasattr(L, name), f"{name} declared in include/shk.h but not exported"
     L.shk_abi_version.restype = ctypes.c_int
-    assert L.shk_abi_version() == 1
+    assert L.shk_abi_version() == 2
 
 
 def test_code_object_is_gfx950(built):

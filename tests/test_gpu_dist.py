@@ -49,6 +49,15 @@ class ThreadGroup:
         t.copy_(res)
         torch.cuda.synchronize()
 
+    def all_gather(self, outs, t):
+        torch.cuda.synchronize()
+        self.s.slots[self.rank] = t.clone()
+        self.s.barrier.wait()
+        for src in range(self.s.world):
+            outs[src].copy_(self.s.slots[src])
+        torch.cuda.synchronize()
+        self.s.barrier.wait()
+
     def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
         torch.cuda.synchronize()
         W = self.s.world

@@ -1,0 +1,192 @@
+"""GPU tests of KEY-SPACE-PARTITIONED ingest (owner shares; SURVEY.md §8e's alternative, BASELINE
+configs[4]): a context with shk_config.n_owners = W holds the k-mers of ONE owner in W.  Through the C ABI,
+bit-exact against the oracle:
+
+  * drop mode  — every share is handed all reads and keeps what it owns: the shares' histograms add up
+                 to the oracle's, their tables are disjoint and their union is the oracle's table;
+  * exchange   — W contexts on one card play W ranks, every rank ingests its own reads and the records are
+                 exchanged by owner (sharkmer_amd.dist.OwnerCounter over an in-process transport);
+  * one owner's share of configs[4] at full table size (2^30 slots × 48 B), foreign records dropped.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import sharkmer_amd as sa
+from sharkmer_amd.dist import OwnerCounter, shard_batches
+
+from test_gpu_dist import ThreadGroup
+
+pytestmark = pytest.mark.gpu
+
+
+def _owner_of(keys, k, W):
+    """Owner of canonical k-mers = top log2(W) bits of the engine's bijective key mix (shk_device.hip.h)."""
+    bits = 2 * k
+    mask = (1 << bits) - 1
+    M1, M2 = 0x9E3779B1, 0x85EBCA6B
+    out = np.empty(len(keys), dtype=np.int64)
+    lw = W.bit_length() - 1
+    for i, x in enumerate(int(v) for v in keys):
+        y = (x * M1) & mask
+        y ^= y >> ((bits + 1) >> 1)
+        y = (y * M2) & mask
+        out[i] = (y >> (bits - lw)) if lw and bits >= lw else 0
+    return out
+
+
+def _shares_against_oracle(orc, bases, offsets, k, chunks, histo_max, W, flags=0, hint=0, splits=None):
+    ref = orc.run_batch(bases, offsets, k, chunks, histo_max)
+    rk, rc = ref.merged().export()
+    hist_sum = None
+    all_k, all_c = [], []
+    tot = dict(n_kmers_ingested=0, n_unique_kmers=0, n_hashed_kmers=0)
+    for o in range(W):
+        with sa.KmerEngine(k, chunks, histo_max, capacity_hint=hint, flags=flags, n_owners=W, owner_id=o) as eng:
+            n = len(offsets) - 1
+            cuts = [0] + sorted(splits or []) + [n]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                eng.ingest_reads(bases, offsets[a:b + 1])
+            eng.finalize()
+            h = eng.histograms()
+            c = eng.counters()
+            gk, gc = eng.export_table()
+            # point lookups: owned keys give their count, foreign keys 0
+            probe = rk[:: max(len(rk) // 300, 1)]
+            got = eng.lookup(probe)
+            own = _owner_of(probe, k, W) == o
+            want = np.where(own, rc[:: max(len(rk) // 300, 1)], 0)
+            assert np.array_equal(got, want.astype(np.uint32))
+        assert c["n_reads_ingested"] == ref.stats["n_reads_ingested"]
+        assert c["n_bases_ingested"] == ref.stats["n_bases_ingested"]
+        assert np.all(_owner_of(gk, k, W) == o), "a share holds a k-mer it does not own"
+        hist_sum = h.astype(np.uint64) if hist_sum is None else hist_sum + h
+        all_k.append(gk)
+        all_c.append(gc)
+        for f in tot:
+            tot[f] += c[f]
+    assert np.array_equal(hist_sum, ref.histograms())
+    uk = np.concatenate(all_k)
+    uc = np.concatenate(all_c)
+    order = np.argsort(uk, kind="stable")
+    assert np.array_equal(uk[order], rk) and np.array_equal(uc[order], rc)
+    for f in tot:
+        assert tot[f] == ref.stats[f], f
+
+
+@pytest.mark.parametrize("W", [2, 8])
+@pytest.mark.parametrize("k,chunks,flags,hint", [(21, 10, 0, 0), (21, 3, sa.FLAG_FORCE_DIRECT, 0), (31, 2, 0, 0),
+                                                 (15, 0, 0, 0), (21, 1, 0, 4_200_000), (9, 4, 0, 0)])
+def test_owner_shares_drop_mode(orc, k, chunks, flags, hint, W):
+    """Every share sees every read and keeps its own k-mers (global atomics on small tables / long
+    k-mers, the owner layout where 4-byte records fit)."""
+    spec = sa.SynthSpec(genome_len=60_000, sub_per_64k=300, n_per_64k=60)
+    bases, offsets = sa.synth_reads(spec, 0, 12_500)
+    _shares_against_oracle(orc, bases, offsets, k, chunks, 200, W, flags=flags, hint=hint, splits=[3_100, 9_000])
+
+
+@pytest.mark.parametrize("W,k,chunks,lvl1,hint,budget", [(2, 21, 10, 10, 4_200_000, 0), (4, 21, 3, 10, 2_000_000, 600_000),
+                                                         (8, 19, 2, 6, 1_000_000, 0), (2, 17, 16, 9, 600_000, 300_000),
+                                                         (4, 21, 1, 10, 16_000_000, 0)])
+def test_owner_layout_route(orc, monkeypatch, W, k, chunks, lvl1, hint, budget):
+    """The owner layout forced on small inputs: level 1 over [owner][lane][super-page] regions, level 2
+    into the waiting (lane, page) regions, deferred page passes; several ingest calls per share."""
+    monkeypatch.setenv("SHK_LEVEL1_LOG", str(lvl1))
+    if budget:
+        monkeypatch.setenv("SHK_DEFER_BUDGET", str(budget))
+    spec = sa.SynthSpec(genome_len=150_000, sub_per_64k=200, n_per_64k=40)
+    bases, offsets = sa.synth_reads(spec, 0, 21_000)
+    with sa.KmerEngine(k, chunks, 100, capacity_hint=hint, flags=sa.FLAG_TIMING, n_owners=W, owner_id=W - 1) as eng:
+        eng.ingest_reads(bases, offsets)
+        t = eng.timings()
+        assert "scatter" in t and "pscan" in t, t  # the route under test ran (level 1 + level 2)
+    _shares_against_oracle(orc, bases, offsets, k, chunks, 100, W, hint=hint, splits=[2_000, 9_500, 15_250])
+
+
+def test_owner_share_skewed_input_spills_exactly(orc, monkeypatch):
+    """Low-complexity reads overflow their (lane, super-page) region: the excess takes the spill path."""
+    monkeypatch.setenv("SHK_LEVEL1_LOG", "8")
+    rng = np.random.default_rng(3)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [b"A" * 150 if i % 3 else lut[rng.integers(0, 4, size=150)].tobytes() for i in range(9_000)]
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    offsets = np.arange(len(seqs) + 1, dtype=np.uint64) * 150
+    _shares_against_oracle(orc, bases, offsets, 19, 4, 1000, 2, hint=2_000_000)
+
+
+# ---- exchange mode: W contexts on one card as W ranks ------------------------------------------------
+
+def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint):
+    """Every rank ingests its own 1000-read batches (round-robin, shard_batches), one batch per round."""
+    n_reads = len(offsets) - 1
+    ref = orc.run_batch(bases, offsets, k, chunks, histo_max) if orc is not None else None
+    shared = ThreadGroup.Shared(W)
+    results, errors = [None] * W, []
+    d_bases = torch.from_numpy(bases.copy()).cuda()
+    n_rounds = len(shard_batches(n_reads, 0, W))  # rank 0 has the most batches
+
+    def run(rank):
+        try:
+            eng = sa.KmerEngine(k, chunks, histo_max, capacity_hint=hint, n_owners=W, owner_id=rank)
+            oc = OwnerCounter(eng, ThreadGroup(shared, rank), device=0, round_bases=1000 * 160)
+            mine = shard_batches(n_reads, rank, W)
+            keep = []
+            for r in range(n_rounds):
+                if r >= len(mine):
+                    oc.round(None)  # out of reads: still takes part in the round
+                    continue
+                first, n = mine[r]
+                o0, o1 = int(offsets[first]), int(offsets[first + n])
+                offs = torch.from_numpy((offsets[first:first + n + 1] - offsets[first]).astype(np.int64)).cuda()
+                keep.append(offs)
+                oc.round((d_bases[o0:o1].data_ptr(), offs.data_ptr(), n, o1 - o0, first))
+            results[rank] = (oc.finalize_histograms(), oc.totals, eng.counters()["n_spilled"], oc.n_foreign_rounds)
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    st = ref.stats
+    for hist, tot, _, _ in results:
+        assert np.array_equal(hist, ref.histograms())
+        for f in ("n_kmers_ingested", "n_unique_kmers", "n_reads_ingested", "n_bases_ingested", "n_hashed_kmers"):
+            assert tot[f] == st[f], f
+    return results
+
+
+@pytest.mark.parametrize("W,k,chunks,lvl1", [(2, 21, 10, 10), (4, 21, 3, 10), (2, 17, 1, 5), (8, 19, 0, 6)])
+def test_exchange_between_contexts_like_ranks(orc, monkeypatch, W, k, chunks, lvl1):
+    monkeypatch.setenv("SHK_LEVEL1_LOG", str(lvl1))
+    spec = sa.SynthSpec(genome_len=80_000, sub_per_64k=250, n_per_64k=50)
+    bases, offsets = sa.synth_reads(spec, 0, 20_500)
+    _exchange_run(orc, bases, offsets, k, chunks, 300, W, hint=4_200_000 if lvl1 == 10 else 1_000_000)  # (2k - lvl1 ≤ 32: 4-byte records)
+
+
+def test_exchange_with_skewed_input_goes_through_the_foreign_spill_list(orc, monkeypatch):
+    monkeypatch.setenv("SHK_LEVEL1_LOG", "8")
+    rng = np.random.default_rng(9)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [b"ACAC" * 37 + b"AC" if i % 2 else lut[rng.integers(0, 4, size=150)].tobytes() for i in range(8_000)]
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    offsets = np.arange(len(seqs) + 1, dtype=np.uint64) * 150
+    res = _exchange_run(orc, bases, offsets, 19, 2, 5000, 2, hint=1_000_000)
+    assert any(r[3] > 0 for r in res), "the skew was meant to overflow a level-1 region"
+
+
+def test_exchange_invalid_byte_fails_every_rank(monkeypatch):
+    monkeypatch.setenv("SHK_LEVEL1_LOG", "8")
+    spec = sa.SynthSpec(genome_len=50_000)
+    bases, offsets = sa.synth_reads(spec, 0, 4_000)
+    bad = bases.copy()
+    bad[int(offsets[2_500]) + 3] = ord("x")
+    with pytest.raises(AssertionError, match="Invalid character 'x'"):
+        _exchange_run(None, bad, offsets, 19, 1, 100, 2, hint=1_000_000)

@@ -142,6 +142,40 @@ def test_insert_accumulates_and_saturates():
         assert list(eng.lookup([42, 1, 99])) == [10, 0xFFFFFFFF, 0]
 
 
+def test_extend_with_histogram_saturation_across_lanes(orc):
+    """counting.rs:183-200 + io.rs:1023-1047 through the device histogram scan: lanes {0xFFFFFFFE, 5} of one
+    k-mer merge to the CAPPED count u32::MAX, every column bins the stored (capped) count, the saturation
+    warning is raised, and — Σ merged counts ≠ Σ ingested counts — the reference's invariant fails the run.
+    Expected values come from the oracle's own extend_with_histogram on the same chunk tables."""
+    k, histo_max = 5, 10
+    lanes = [{7: 0xFFFFFFFE, 3: 2, 11: 10}, {7: 5, 3: 3, 20: 1}, {7: 1, 20: 0xFFFFFFFF}]
+    merged, h = orc.KmerCounts(k), orc.Histogram(histo_max)
+    want_cols, want_sat = [], False
+    for tbl in lanes:
+        kc = orc.KmerCounts(k)
+        for key, cnt in tbl.items():
+            kc.insert(key, cnt)
+        want_sat |= merged.extend_with_histogram(kc, h)
+        want_cols.append(np.array(h.get_vector(), dtype=np.uint64))
+    n_ingested = sum(sum(t.values()) for t in lanes)
+    with sa.KmerEngine(k, len(lanes), histo_max) as eng:
+        for lane, tbl in enumerate(lanes):
+            eng.insert(list(tbl), list(tbl.values()), chunk_id=lane)
+        with pytest.raises(sa.ShkError) as ei:
+            eng.finalize()
+        assert ei.value.code == -6  # SHK_ERR_INVARIANT, io.rs:1042-1047
+        assert ei.value.msg == (f"The total count of hashed kmers ({merged.get_n_kmers()}) does not equal "
+                                f"the number of ingested kmers ({n_ingested})")
+        # the reference has computed histo_vecs by then (io.rs:1023-1028 precede the check): they stay readable
+        got = eng.histograms()
+        c = eng.counters()
+        assert [int(x) for x in eng.lookup([7, 3, 11, 20])] == [merged.get_count(x) for x in (7, 3, 11, 20)]
+    assert want_sat and c["any_saturated"] == 1
+    assert np.array_equal(got, np.stack(want_cols))
+    assert list(got[0]) == [0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1, 1]          # 3:2, 11:10, 7 → overflow bin
+    assert c["n_hashed_kmers"] == merged.get_n_kmers() and c["n_unique_kmers"] == 4
+
+
 @pytest.mark.parametrize("flags", FLAGSETS)
 def test_saturating_add_under_ingest(orc, flags):
     """counting.rs:82-85: ingest increments saturate exactly at u32::MAX."""
@@ -771,7 +805,14 @@ def _deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget):
     rk, rc = ref.merged().export()
     assert np.array_equal(gk, rk) and np.array_equal(gc, rc)
     if "scatter" in t:  # the deferred path ran: fewer page passes than partition launches
-        assert t["pages"][1] <= t["scatter"][1]
+        # (a budget below two batches' worth of records cannot defer anything: every 1500-read batch — the
+        # engine books a launch at its upper bound, one record per base of its 16 Ki-base tiles — uses it
+        # up and ends its own window, one page pass per partition launch)
+        batch_records = -(-step * 150 // 16384) * 16384
+        if budget and budget < 2 * batch_records:
+            assert t["pages"][1] <= t["scatter"][1] + 1
+        else:
+            assert t["pages"][1] < t["scatter"][1]
         if not budget and hint:  # … just the mid-stream lookup’s and finalize’s when the table is large and the budget untouched
             assert t["pages"][1] <= 3 * max(chunks, 1)  # (8-byte records: one page launch per lane and pass)
 
