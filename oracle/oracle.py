@@ -130,6 +130,9 @@ def lib():
     L.orc_find_oligos.restype = C.c_size_t
     L.orc_filter_matches.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.orc_filter_matches.restype = C.c_int
+    L.orc_probe_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32,
+                                  C.c_void_p, C.c_uint64, C.c_void_p]
+    L.orc_probe_count.restype = C.c_int
 
     L.orc_histo_new.argtypes = [C.c_uint64]
     L.orc_histo_new.restype = C.c_void_p
@@ -465,6 +468,39 @@ def run_batch(bases: np.ndarray, offsets: np.ndarray, k: int, chunks: int, histo
     r.push_batch(bases, offsets)
     r.finish()
     return r
+
+
+def probe_counts(bases: np.ndarray, offsets: np.ndarray, k: int, probes: np.ndarray, n_lanes: int = 1,
+                 first_read_index: int = 0, threads: int = 0, out: np.ndarray | None = None) -> np.ndarray:
+    """Occurrences of every probe k-mer (sorted, distinct u64) over the reads, per chunk lane:
+    (n_lanes, len(probes)) u64, extraction by the oracle's kmers_from_ascii, lane of read i =
+    (first_read_index + i) // 1000 % n_lanes.  The reads are sharded over `threads` host threads
+    (ctypes releases the GIL); `out` accumulates across calls."""
+    import concurrent.futures as cf
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    probes = np.ascontiguousarray(probes, dtype=np.uint64)
+    n = len(offsets) - 1
+    T = threads or min(os.cpu_count() or 1, 32)
+    T = max(1, min(T, (n + 999) // 1000))
+    cuts = [n * t // T for t in range(T + 1)]
+    parts = [np.zeros((n_lanes, len(probes)), dtype=np.uint64) for _ in range(T)]
+    L = lib()
+
+    def work(t):
+        a, b = cuts[t], cuts[t + 1]
+        if b <= a:
+            return ORC_OK
+        return L.orc_probe_count(bases.ctypes.data, offsets[a:b + 1].ctypes.data, b - a, k, first_read_index + a,
+                                 n_lanes, probes.ctypes.data, len(probes), parts[t].ctypes.data)
+    with cf.ThreadPoolExecutor(T) as ex:
+        for rc in ex.map(work, range(T)):
+            if rc != ORC_OK:
+                raise OracleError(rc, "orc_probe_count")
+    tot = out if out is not None else np.zeros((n_lanes, len(probes)), dtype=np.uint64)
+    for p_ in parts:
+        tot += p_
+    return tot
 
 
 # ---- second, code-independent oracle (numpy; small inputs) -------------------

@@ -1072,3 +1072,84 @@ int orc_filter_matches(const orc_counts *primers, const uint8_t *seq, size_t len
   free(km);
   return hit;
 }
+
+/* ---- probe-set counting (test infrastructure for the full-size parity checks) ------------------------
+ * For reads [0, n_seqs) of a batch whose first read has global index first_read_index: the k-mers of every
+ * read come from orc_kmers_from_ascii (encoding.rs:332-371), a read's chunk lane is
+ * (global read index / 1000) % n_lanes (io.rs:340-361), and every occurrence of a k-mer that is in
+ * `probes` (sorted ascending, distinct) adds one to counts[lane * n_probes + its index] (u64: the caller
+ * clamps like saturating_add, counting.rs:82-85).  Thread-safe on disjoint `counts`; callers shard reads
+ * over threads with one counts array each.  Returns ORC_OK or the extractor's error. */
+int orc_probe_count(const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs, int k,
+                    uint64_t first_read_index, uint32_t n_lanes, const uint64_t *probes, uint64_t n_probes,
+                    uint64_t *counts) {
+  if (n_probes == 0 || n_seqs == 0) return ORC_OK;
+  /* open-addressing index of the probes (power-of-two table, load ≤ 1/4, stays in cache) */
+  uint64_t cap = 16;
+  while (cap < n_probes * 4) cap <<= 1;
+  uint64_t *tk = (uint64_t *)malloc(cap * sizeof(uint64_t));
+  uint32_t *ti = (uint32_t *)malloc(cap * sizeof(uint32_t));
+  if (!tk || !ti) {
+    free(tk);
+    free(ti);
+    return ORC_ERR_NOMEM;
+  }
+  memset(tk, 0xFF, cap * sizeof(uint64_t));
+  for (uint64_t i = 0; i < n_probes; i++) {
+    uint64_t h = mix64(probes[i]) & (cap - 1);
+    while (tk[h] != ~0ull) h = (h + 1) & (cap - 1);
+    tk[h] = probes[i];
+    ti[h] = (uint32_t)i;
+  }
+  /* a one-word-per-lookup Bloom filter in front of it (512 KiB: stays in L2; almost every k-mer of the
+   * reads is no probe and never touches the index) */
+  const uint64_t bloom_words = 1ull << 16;
+  uint64_t *bloom = (uint64_t *)calloc(bloom_words, sizeof(uint64_t));
+  if (!bloom) {
+    free(tk);
+    free(ti);
+    return ORC_ERR_NOMEM;
+  }
+  for (uint64_t i = 0; i < n_probes; i++) {
+    const uint64_t h = mix64(probes[i]);
+    bloom[(h >> 40) & (bloom_words - 1)] |= (1ull << (h & 63)) | (1ull << ((h >> 6) & 63));
+  }
+  size_t km_cap = 1024;
+  uint64_t *km = (uint64_t *)malloc(km_cap * sizeof(uint64_t));
+  int rc = km ? ORC_OK : ORC_ERR_NOMEM;
+  for (uint64_t r = 0; r < n_seqs && rc == ORC_OK; r++) {
+    const size_t len = (size_t)(offsets[r + 1] - offsets[r]);
+    if (len > km_cap) {
+      km_cap = len * 2;
+      uint64_t *nk = (uint64_t *)realloc(km, km_cap * sizeof(uint64_t));
+      if (!nk) {
+        rc = ORC_ERR_NOMEM;
+        break;
+      }
+      km = nk;
+    }
+    size_t n = 0;
+    uint8_t bad = 0;
+    rc = orc_kmers_from_ascii(bases + offsets[r], len, k, km, &n, &bad);
+    if (rc != ORC_OK) break;
+    const uint32_t lane = (uint32_t)(((first_read_index + r) / 1000) % n_lanes);
+    for (size_t j = 0; j < n; j++) {
+      const uint64_t hh = mix64(km[j]);
+      const uint64_t need = (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63));
+      if ((bloom[(hh >> 40) & (bloom_words - 1)] & need) != need) continue;
+      uint64_t h = hh & (cap - 1);
+      while (tk[h] != ~0ull) {
+        if (tk[h] == km[j]) {
+          counts[(uint64_t)lane * n_probes + ti[h]]++;
+          break;
+        }
+        h = (h + 1) & (cap - 1);
+      }
+    }
+  }
+  free(km);
+  free(tk);
+  free(ti);
+  free(bloom);
+  return rc;
+}

@@ -157,6 +157,12 @@ int orc_run_write_final_histo(const orc_run *r, const char *path, const char *ve
 int orc_run_write_stats_yaml(const orc_run *r, const char *path, const char *version,
                              const char *command, const char *sample, uint64_t peak_memory_bytes);
 
+/* Test infrastructure: occurrences of a sorted probe set over a batch of reads, per chunk lane
+ * (extractor: orc_kmers_from_ascii; lane of read i: (first_read_index + i) / 1000 % n_lanes). */
+int orc_probe_count(const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs, int k,
+                    uint64_t first_read_index, uint32_t n_lanes, const uint64_t *probes, uint64_t n_probes,
+                    uint64_t *counts);
+
 #ifdef __cplusplus
 }
 #endif

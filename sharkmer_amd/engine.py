@@ -531,7 +531,7 @@ class KmerEngine:
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr,
                                                  "data": (ptr, False), "version": 2}
         if n == 0 or not ptr:
-            return torch.empty(0, dtype={"<i4": torch.int32, "<i8": torch.int64}[typestr], device="cuda")
+            return torch.empty(0, dtype={"<i4": torch.int32, "<i8": torch.int64, "|u1": torch.uint8}[typestr], device="cuda")
         return torch.as_tensor(_Raw(ptr, (n,), typestr), device="cuda")
 
     def xchg_scatter_tensors(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int, layout_bases: int = 0):

@@ -190,3 +190,67 @@ def test_exchange_invalid_byte_fails_every_rank(monkeypatch):
     bad[int(offsets[2_500]) + 3] = ord("x")
     with pytest.raises(AssertionError, match="Invalid character 'x'"):
         _exchange_run(None, bad, offsets, 19, 1, 100, 2, hint=1_000_000)
+
+
+# ---- one owner's share of BASELINE configs[4] at its full table size ----------------------------------
+
+def test_config5_owner_share_on_one_card(orc):
+    """BASELINE.json configs[4] — 10 cumulative subsets (chunk lanes) of reads over a 3 Gb genome on 8 GPUs —
+    as ONE owner's share on one card: owner 5 of 8, 10 lanes, a 2^30-slot table × (8 + 10·4) B = 51 GB (the
+    whole key space would need 412 GB per rank).  Every read is offered, the seven other owners' records are
+    dropped in the level-1 pass (the same kernels the 8-GPU exchange runs).  SHK_SHARE_READS reads (default
+    125 M = one rank's share of the 1 B; set 1000000000 for all of them: every record this owner would receive).
+    Checks: an EXACT probe set per chunk lane — 10^5 k-mers of sampled reads counted over all reads by the
+    oracle's extractor; owned probes must come back with exactly that merged count, foreign ones with 0 —
+    plus the size-independent properties of the incremental histograms."""
+    from probe_util import ProbeChecker
+    n = int(os.environ.get("SHK_SHARE_READS", "125000000"))
+    L, k, batch, W, owner, chunks = 150, 21, 1_700_000, 8, 5, 10
+    n = n // batch * batch
+    spec = sa.SynthSpec(genome_len=3_000_000_000, read_len=L)
+    pc = ProbeChecker(orc, k, chunks, L, n_probes=120_000)
+    with sa.KmerEngine(k, chunks, 1000, capacity_hint=3_000_000_000 // W, n_owners=W, owner_id=owner) as eng:
+        n_pages, page_slots, n_lanes = eng.table_geometry()
+        assert n_pages * page_slots == 1 << 30 and n_lanes == chunks
+        d_bases = eng.alloc_device(batch * L)
+        d_off = eng.alloc_device((batch + 1) * 8)
+        try:
+            for s_batch in (0, n // batch // 2, n // batch - 1):
+                eng.synth_reads_device(spec, s_batch * batch + 4321, 320, d_bases, d_off)
+                eng.sync()
+                pc.add_sample(pc._fetch(eng, d_bases, 320), 320)
+            probes = pc.freeze()
+            for b in range(n // batch):
+                eng.synth_reads_device(spec, b * batch, batch, d_bases, d_off)
+                eng.ingest_reads_device(d_bases, d_off, batch, batch * L)
+                pc.count_async(pc._fetch(eng, d_bases, batch), batch, b * batch)
+            eng.finalize()
+            h = eng.histograms()
+            c = eng.counters()
+            got = eng.lookup(probes)
+        finally:
+            eng.sync()
+            eng.free_device(d_bases)
+            eng.free_device(d_off)
+    per_lane = pc.result()
+    pc.close()
+    own = _owner_of(probes, k, W) == owner
+    assert 0.10 < own.mean() < 0.15                                   # owners are hash bits: 1/8 of the probes
+    want = np.where(own, np.minimum(per_lane.sum(axis=0), 0xFFFFFFFF), 0).astype(np.uint32)
+    assert np.array_equal(got, want)                                  # exact, k-mer by k-mer; foreign k-mers absent
+    total = (L - k + 1) * n
+    assert c["n_reads_ingested"] == n and c["n_bases_ingested"] == n * L
+    assert abs(c["n_kmers_ingested"] - total / W) < 0.002 * total / W  # this owner's eighth of the occurrences
+    assert c["n_hashed_kmers"] == c["n_kmers_ingested"] and c["n_grows"] == 0
+    assert int(h[-1].sum()) == c["n_unique_kmers"]
+    last = h[-1].astype(object)
+    assert sum(int(f) * i for i, f in enumerate(last)) == c["n_kmers_ingested"]
+    for j in range(1, chunks):                                        # cumulative columns only ever gain k-mers
+        assert int(h[j].sum()) >= int(h[j - 1].sum())
+    # column j = the histogram after lanes 0..j: the probes' per-lane counts say which bin each owned probe is in
+    cum = np.minimum(np.cumsum(per_lane[:, own], axis=0), 0xFFFFFFFF)
+    for j in (0, chunks // 2, chunks - 1):
+        bins = np.bincount(np.minimum(cum[j][cum[j] > 0], 1001).astype(np.int64), minlength=1002)
+        assert (h[j][:1002] >= bins[:1002].astype(np.uint64)).all()
+    expect = 3e9 * (1 - np.exp(-total / 3e9)) / W
+    assert abs(c["n_unique_kmers"] - expect) < 0.01 * expect
