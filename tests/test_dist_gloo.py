@@ -212,3 +212,185 @@ def test_shard_batches_cover_every_read_once():
                 assert first % 1000 == 0 and 0 < cnt <= 1000
                 seen[first:first + cnt] += 1
         assert (seen == 1).all()
+
+
+# ---- key-space-partitioned ingest (sharkmer_amd.dist.OwnerCounter) under gloo ----------------------------------
+
+MIX_M1, MIX_M2 = 0x9E3779B1, 0x85EBCA6B
+MIX_M1_INV, MIX_M2_INV = 0xCFA4A56B0E8B2F51, 0x000A7324A5CB9243  # shk_device.hip.h
+
+
+def _mix(x, bits):
+    mask = (1 << bits) - 1
+    x = (x * MIX_M1) & mask
+    x ^= x >> ((bits + 1) >> 1)
+    return (x * MIX_M2) & mask
+
+
+def _unmix(y, bits):
+    mask = (1 << bits) - 1
+    y = (y * MIX_M2_INV) & mask
+    y ^= y >> ((bits + 1) >> 1)
+    return (y * MIX_M1_INV) & mask
+
+
+class _Layout:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class NumpyOwnerEngine:
+    """Stand-in for an owner-share KmerEngine (shk_config.n_owners): speaks the exchange wire format of
+    include/shk.h — per owner one segment of `regions` = [lane][super-page] regions of `region_cap` 4-byte
+    records (the low bits of the mixed key below the level-1 bits), block-interleaved in 1024-record blocks,
+    fill levels as one u32 per region; overflow goes to the foreign spill list."""
+
+    def __init__(self, k, chunks, histo_max, n_owners, owner_id, log_p1, region_cap=1024):
+        self.k, self.chunks, self.histo_max = k, chunks, histo_max
+        self.n_lanes = max(chunks, 1)
+        self.W, self.me = n_owners, owner_id
+        self.lw = n_owners.bit_length() - 1
+        self.log_p1 = log_p1
+        self.log_p1w = log_p1 - self.lw
+        self.cap = region_cap
+        self.counts = {}
+        self.spill = []
+        self.next_read = 0
+        self.n_reads = self.n_bases = self.n_valid = 0
+        assert 2 * k - log_p1 <= 32
+
+    def set_read_index(self, i):
+        self.next_read = i
+
+    def stream(self):
+        return 0
+
+    def _slot(self, g, n_grp, j):
+        return (((j >> 10) * n_grp + g) << 10) | (j & 1023)
+
+    def xchg_scatter_tensors(self, bases, offsets, n_seqs, n_bases, layout_bases=0):
+        from oracle import oracle as orc
+        n_grp = self.n_lanes << self.log_p1w
+        seg = n_grp * self.cap
+        rec = np.zeros(self.W * seg, dtype=np.int32)
+        cur = np.zeros(self.W * n_grp, dtype=np.int32)
+        bits, r1 = 2 * self.k, 2 * self.k - self.log_p1
+        if n_seqs:
+            offsets = np.asarray(offsets, dtype=np.int64)
+            segb = bases[offsets[0]:offsets[-1]]
+            if np.any(~np.isin(segb, np.frombuffer(b"ACGTN", dtype=np.uint8))):
+                bad = segb[~np.isin(segb, np.frombuffer(b"ACGTN", dtype=np.uint8))][0]
+                raise RuntimeError(f"Invalid character '{chr(bad)}' in sequence. Only ACGTN allowed.")
+            kmers, rid = orc.canonical_kmers_numpy(segb, offsets - offsets[0], self.k, return_read_id=True)
+            lanes = ((self.next_read + rid) // 1000) % self.n_lanes
+            for key, lane in zip(kmers.tolist(), lanes.tolist()):
+                y = _mix(key, bits)
+                gp = y >> r1
+                o, sp = gp >> self.log_p1w, gp & ((1 << self.log_p1w) - 1)
+                g = (lane << self.log_p1w) | sp
+                j = int(cur[o * n_grp + g])
+                if j < self.cap:
+                    rec[o * seg + self._slot(g, n_grp, j)] = np.uint32(y & ((1 << r1) - 1)).view(np.int32)
+                    cur[o * n_grp + g] = j + 1
+                else:
+                    self.spill.append((key, lane, 1))
+            self.n_reads += n_seqs
+            self.n_bases += len(segb)
+            self.n_valid += int((segb != ord("N")).sum())
+        lay = _Layout(n_owners=self.W, n_lanes=self.n_lanes, log_p1=self.log_p1, regions=n_grp,
+                      region_cap=self.cap, segment_records=seg)
+        return torch.from_numpy(rec), torch.from_numpy(cur), lay, len(self.spill)
+
+    def _add(self, key, lane, cnt):
+        v = self.counts.setdefault(key, np.zeros(self.n_lanes, dtype=np.int64))
+        v[lane] = min(v[lane] + cnt, 0xFFFFFFFF)
+
+    def xchg_absorb_tensors(self, rec_t, cur_t, lay):
+        assert lay.n_owners == self.W and lay.regions == self.n_lanes << self.log_p1w
+        rec, cur = rec_t.numpy().view(np.uint32), cur_t.numpy()
+        bits, r1 = 2 * self.k, 2 * self.k - self.log_p1
+        for g in range(lay.regions):
+            lane, sp = g >> self.log_p1w, g & ((1 << self.log_p1w) - 1)
+            for j in range(min(int(cur[g]), lay.region_cap)):
+                y = ((((self.me << self.log_p1w) | sp) << r1) | int(rec[self._slot(g, lay.regions, j)]))
+                self._add(_unmix(y, bits), lane, 1)
+
+    def xchg_spill_tensors(self):
+        a = np.array(self.spill, dtype=np.int64).reshape(-1, 3)
+        return (torch.from_numpy(a[:, 0].copy()), torch.from_numpy(a[:, 1].astype(np.int32)),
+                torch.from_numpy(a[:, 2].astype(np.int32)))
+
+    def insert_tensors(self, k_t, l_t, c_t):
+        bits = 2 * self.k
+        for key, lane, cnt in zip(k_t.tolist(), l_t.tolist(), c_t.tolist()):
+            if (_mix(key, bits) >> (bits - self.lw) if self.lw else 0) == self.me:
+                self._add(key, lane, cnt)
+
+    def xchg_spill_clear(self):
+        self.spill = []
+
+    finalize = NumpyPagedEngine.finalize
+    histograms = NumpyPagedEngine.histograms
+    counters = NumpyPagedEngine.counters
+    owned = None
+
+
+def _owner_worker(rank, world, port, k, chunks, histo_max, n_reads, log_p1, cap, poly, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import sharkmer_amd as sa
+    from sharkmer_amd.dist import OwnerCounter, shard_batches
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bases, offsets = _owner_input(sa, n_reads, poly)
+    eng = NumpyOwnerEngine(k, chunks, histo_max, world, rank, log_p1, cap)
+    oc = OwnerCounter(eng, dist, round_bases=1000 * 160)
+    mine = shard_batches(n_reads, rank, world)
+    for r in range(len(shard_batches(n_reads, 0, world))):
+        if r < len(mine):
+            first, n = mine[r]
+            oc.round((bases, offsets[first:first + n + 1], n, int(offsets[first + n] - offsets[first]), first))
+        else:
+            oc.round(None)
+    hist = oc.finalize_histograms()
+    np.save(os.path.join(out_dir, f"hist_{rank}.npy"), hist)
+    np.save(os.path.join(out_dir, f"tot_{rank}.npy"),
+            np.array([oc.totals[x] for x in ("n_reads_ingested", "n_bases_read", "n_bases_ingested",
+                                             "n_kmers_ingested", "n_unique_kmers")] + [oc.n_foreign_rounds], dtype=np.int64))
+    dist.destroy_process_group()
+
+
+def _owner_input(sa, n_reads, poly):
+    spec = sa.SynthSpec(genome_len=3000, sub_per_64k=400, n_per_64k=100)
+    bases, offsets = sa.synth_reads(spec, 0, n_reads)
+    if poly:  # low-complexity reads: their one k-mer overflows its region → the foreign spill list
+        bases = bases.copy()
+        for i in range(0, n_reads, 3):
+            bases[int(offsets[i]):int(offsets[i + 1])] = ord("A")
+    return bases, offsets
+
+
+@pytest.mark.parametrize("k,chunks,n_reads,log_p1,cap,poly", [(21, 10, 3300, 10, 1024, False), (15, 3, 2500, 4, 1024, True),
+                                                             (9, 0, 1800, 1, 2048, False)])
+def test_two_rank_owner_partitioned_ingest_matches_single_oracle(orc, tmp_path, k, chunks, n_reads, log_p1, cap, poly):
+    """World 2, 10 chunk lanes (BASELINE configs[4]'s shape): every rank ingests its own 1000-read batches,
+    records travel by owner every round, nothing is merged at finalize; a skewed case goes through the
+    foreign spill list."""
+    import sharkmer_amd as sa
+    histo_max = 40
+    port = _free_port()
+    mp.spawn(_owner_worker, args=(2, port, k, chunks, histo_max, n_reads, log_p1, cap, poly, str(tmp_path)), nprocs=2, join=True)
+    bases, offsets = _owner_input(sa, n_reads, poly)
+    ref = orc.run_batch(bases, offsets, k, chunks, histo_max)
+    h0 = np.load(tmp_path / "hist_0.npy")
+    h1 = np.load(tmp_path / "hist_1.npy")
+    assert np.array_equal(h0, h1)
+    assert np.array_equal(h0, ref.histograms())
+    t0 = np.load(tmp_path / "tot_0.npy")
+    st = ref.stats
+    assert list(t0[:5]) == [st["n_reads_ingested"], st["n_bases_read"], st["n_bases_ingested"],
+                            st["n_kmers_ingested"], st["n_unique_kmers"]]
+    if poly:
+        assert t0[5] > 0, "the low-complexity reads were meant to overflow a region"
