@@ -22,7 +22,7 @@ using namespace shk;
 struct shk_ctx;
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed);
 static int prepare_cursors(shk_ctx *c, bool multi, bool defer, uint32_t *n_words);
-static int acc_prepare(shk_ctx *c, uint64_t kmers_ub);
+static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t lane_add_exact = 0);
 static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub);
 static int settle(shk_ctx *c);
 static int settle_light(shk_ctx *c);
@@ -147,6 +147,8 @@ struct shk_ctx {
   bool acc_active = false;        // the regions hold records that k_pages32 has not counted yet
   uint32_t acc_lp = 0, acc_cap = 0, acc_region_lanes = 1;  // geometry the regions were planned for
   uint64_t acc_records_ub = 0, acc_budget = 0;              // records in the regions (upper bound) / allowed
+  std::vector<uint64_t> acc_lane_ub;                        // … per chunk lane (a lane's regions hold a lane's share)
+  uint64_t acc_lane_budget = 0;                             // records one lane's regions were sized for
   uint64_t acc_spill_cap = 0;     // ONE spill list per accumulation window: every launch of it uses this capacity
   uint64_t acc_nd0 = 0;           // distinct keys when the window was planned
   double acc_new_frac = 1.0;      // new keys per record in the last window (1 = nothing known yet)
@@ -432,7 +434,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   } else {
     const uint64_t first_kmers_ub = std::min(tiles_per_sub, n_tiles_ub) * TILE_T;
     const bool defer = first_launch_defers(c, first_kmers_ub);
-    int rc = defer ? acc_prepare(c, acc_records_est(c, first_kmers_ub)) : (c->acc_active ? settle(c) : SHK_OK);  // (may flush: launch + settle)
+    int rc = defer ? acc_prepare(c, acc_records_est(c, first_kmers_ub), striped && n_blocks > 1 ? -1 : (int64_t)(lane_fixed >= 0 ? (uint64_t)lane_fixed : (striped ? (g0 / 1000) % NL : 0))) : (c->acc_active ? settle(c) : SHK_OK);  // (may flush: launch + settle)
     if (rc == SHK_OK) rc = prepare_cursors(c, striped && n_blocks > 1, defer && first_launch_defers(c, first_kmers_ub), &n_cursor_words);
     if (rc != SHK_OK) return rc;
   }
@@ -595,10 +597,33 @@ static CountPath count_path(const shk_ctx *c, uint64_t sub_kmers_ub) {
 
 // Make room for `kmers_ub` more records in the accumulation regions: plan them if there are none,
 // count what is waiting first (flush) if these would not fit any more.
-static int acc_prepare(shk_ctx *c, uint64_t kmers_ub) {
-  if (c->acc_active && (c->acc_lp != c->tb.log_pages || c->acc_records_ub + kmers_ub > c->acc_budget)) {
-    int rc = settle(c);  // flush + settle (may grow the table)
-    if (rc != SHK_OK) return rc;
+// What a launch of ≤ est records adds to each chunk lane's regions at most: everything to one lane
+// (lane_one ≥ 0: an explicit-chunk batch, or a batch inside one 1000-read block), or — striped over the
+// blocks of the batch (lane_one < 0) — a lane's share of the blocks.
+static uint64_t acc_lane_add(const shk_ctx *c, uint64_t est, int64_t lane_one, uint64_t lane_add_exact = 0) {
+  const uint32_t NL = c->n_lanes;
+  if (lane_add_exact) return std::min(est, lane_add_exact);  // (the caller knows a bound: an exchange segment's regions per lane)
+  if (NL == 1 || lane_one >= 0) return est;
+  const uint64_t nb = std::max<uint64_t>(c->cur_blocks, 1);
+  return std::min<uint64_t>(est, est / nb * ((nb + NL - 1) / NL) + 2 * TILE_T);
+}
+static void acc_book(shk_ctx *c, uint64_t est, int64_t lane_one, uint64_t lane_add_exact = 0) {
+  c->acc_records_ub += est;
+  const uint64_t add = acc_lane_add(c, est, lane_one, lane_add_exact);
+  if (c->acc_lane_ub.size() != c->n_lanes) c->acc_lane_ub.assign(c->n_lanes, 0);
+  for (uint32_t l = 0; l < c->n_lanes; ++l)
+    if (lane_one < 0 || (uint32_t)lane_one == l || c->n_lanes == 1) c->acc_lane_ub[l] += add;
+}
+static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t lane_add_exact) {
+  if (c->acc_active) {
+    bool full = c->acc_lp != c->tb.log_pages || c->acc_records_ub + kmers_ub > c->acc_budget;
+    const uint64_t add = acc_lane_add(c, kmers_ub, lane_one, lane_add_exact);
+    for (uint32_t l = 0; l < c->n_lanes && !full && l < c->acc_lane_ub.size(); ++l)
+      if ((lane_one < 0 || (uint32_t)lane_one == l) && c->acc_lane_ub[l] + add > c->acc_lane_budget) full = true;
+    if (full) {
+      int rc = settle(c);  // flush + settle (may grow the table)
+      if (rc != SHK_OK) return rc;
+    }
   }
   if (c->acc_active) return SHK_OK;
   const uint64_t n_pages = 1ull << c->tb.log_pages;
@@ -624,15 +649,19 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub) {
   // every window's budget stays below that: freeing and re-allocating tens of GB between windows
   // stalls the host for seconds (the driver wipes VRAM that changes hands).
   if (!(c->acc_buf.p && c->acc_lp == c->tb.log_pages && c->acc_rec32 == rec32 && c->acc_region_lanes == NL &&
-        kmers_ub <= c->acc_budget_max)) {
+        kmers_ub <= c->acc_budget_max && acc_lane_add(c, kmers_ub, lane_one, lane_add_exact) <= c->acc_lane_budget)) {
     // lanes each get a full-size region set; 8-byte records also need k_pages' miss queues
-    const uint64_t rec_bytes = rec32 ? 4ull * NL + 1 : 8ull * NL + 8 + 1;
+    const uint64_t rec_bytes = rec32 ? 4ull * 2 + 1 : 8ull * 2 + 8 + 1;  // (lanes: 1.5 × 1.25 shares of the window together)
     const uint64_t mem_records = (uint64_t)(free_b / 2 + c->acc_buf.cap) / rec_bytes;
     // up to eight tables' worth of records while that is a few GiB, two tables' worth beyond
     const uint64_t few_gib = (8ull << 30) / (rec32 ? 4 : 8) / NL;
     uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), c->tb.cap * 2);
     bmax = std::max<uint64_t>(std::min(bmax, mem_records), kmers_ub);
-    uint64_t cap = bmax / n_pages + bmax / n_pages / 4 + 1024;
+    // a lane's regions take a lane's share of the window (+ 50 %: blocks of uneven read lengths), but at
+    // least what one launch can put into a single lane
+    const uint64_t lane_max = NL > 1 ? std::max<uint64_t>(std::min(bmax, bmax / NL * 3 / 2), acc_lane_add(c, kmers_ub, lane_one, lane_add_exact)) : bmax;
+    c->acc_lane_budget = lane_max;
+    uint64_t cap = lane_max / n_pages + lane_max / n_pages / 4 + 1024;
     cap = (cap + (1u << RB_LOG) - 1) & ~(uint64_t)((1u << RB_LOG) - 1);
     if (cap > 0x7FFFF000ull) cap = 0x7FFFF000ull;
     if (!rec32 && !g.two_level) {  // the one-level 8-byte scatter addresses a lane's regions with 32-bit byte offsets
@@ -654,6 +683,7 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub) {
   c->acc_region_lanes = NL;
   c->acc_budget = budget;
   c->acc_records_ub = 0;
+  c->acc_lane_ub.assign(NL, 0);
   c->acc_nd0 = nd;
   c->acc_spill_cap = std::min<uint64_t>(std::max<uint64_t>(budget, kmers_ub), 1ull << 28);
   return SHK_OK;
@@ -1089,7 +1119,7 @@ static uint64_t acc_records_est(const shk_ctx *c, uint64_t kmers_ub) {
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed) {
   CountPath path = count_path(c, sub_kmers_ub);
   if (path == PATH_DEFER) {  // (the first launch of an ingest was planned before k_mark_starts)
-    int rc = acc_prepare(c, acc_records_est(c, sub_kmers_ub));
+    int rc = acc_prepare(c, acc_records_est(c, sub_kmers_ub), b.tiles ? -1 : (int64_t)b.lane0);
     if (rc != SHK_OK) return rc;
     path = count_path(c, sub_kmers_ub);  // a flush may have grown the table
     if (path == PATH_DEFER && !c->acc_cur.p) return fail(c, SHK_ERR_INVARIANT, "accumulation regions missing");
@@ -1110,7 +1140,7 @@ static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, boo
     if (rc != SHK_OK) return rc;
     if (path == PATH_DEFER) {
       c->acc_active = true;
-      c->acc_records_ub += acc_records_est(c, sub_kmers_ub);
+      acc_book(c, acc_records_est(c, sub_kmers_ub), b.tiles ? -1 : (int64_t)b.lane0);
     }
   } else {
     {  // validate + count bases first (encoding.rs:353-356, 374-376); k_direct tests stats->bad
@@ -1180,6 +1210,7 @@ static int flush_acc(shk_ctx *c) {
   HIPC(c, hipMemsetAsync(c->acc_cur.p, 0, (size_t)NL * n_pages * 4, c->stream));
   c->acc_active = false;
   c->acc_records_ub = 0;
+  c->acc_lane_ub.assign(NL, 0);
   c->unsettled = true;
   c->unsettled_spill_cap = spill_cap;
   return SHK_OK;
@@ -1566,7 +1597,8 @@ int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, co
   // a segment's regions are sized 1.25 × (1.5 ×) their expected fill: 4/5 of it bounds what it holds in practice
   uint64_t est = lay->segment_records / 5 * 4 + 1024;
   if (c->acc_active && c->acc_spill_cap) est = std::min<uint64_t>(est, c->acc_spill_cap);
-  rc = acc_prepare(c, est);  // (may count what is waiting first: launch + settle)
+  const uint64_t lane_bound = lay->segment_records / lay->n_lanes;  // a lane's regions of the segment cannot hold more
+  rc = acc_prepare(c, est, -1, lane_bound);  // (may count what is waiting first: launch + settle)
   if (rc != SHK_OK) return rc;
   g = part_geom(c);  // a settle may have grown the table
   rc = xchg_check(c, g);
@@ -1577,7 +1609,7 @@ int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, co
     if (c->unsettled) {  // (its list is about to move)
       rc = settle(c);
       if (rc != SHK_OK) return rc;
-      rc = acc_prepare(c, est);
+      rc = acc_prepare(c, est, -1, lane_bound);
       if (rc != SHK_OK) return rc;
       g = part_geom(c);
     }
@@ -1587,7 +1619,7 @@ int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, co
   rc = xl_absorb(c, g, (const uint32_t *)d_records, (const unsigned int *)d_cursors, lay->region_cap, lay->regions, sp);
   if (rc != SHK_OK) return rc;
   c->acc_active = true;
-  c->acc_records_ub += est;
+  acc_book(c, est, -1, lane_bound);
   c->unsettled = true;
   c->unsettled_spill_cap = spill_cap;
   return SHK_OK;

@@ -830,7 +830,7 @@ def _deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget):
         # (a budget below two batches' worth of records cannot defer anything: every 1500-read batch — the
         # engine books a launch at its upper bound, one record per base of its 16 Ki-base tiles — uses it
         # up and ends its own window, one page pass per partition launch)
-        batch_records = -(-step * 150 // 16384) * 16384
+        batch_records = (-(-step * 150 // 16384) + (3 if chunks > 1 else 0)) * 16384  # (+ a partial tile per 1000-read block)
         if budget and budget < 2 * batch_records:
             assert t["pages"][1] <= t["scatter"][1] + 1
         else:
