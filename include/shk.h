@@ -401,6 +401,9 @@ typedef struct shk_run_config {
   uint64_t table_capacity_hint;
   uint64_t batch_reads;     /* reads per device super-batch; 0 = 1,000,000 */
   uint64_t batch_bases;     /* pinned buffer bytes; 0 = 256 MiB */
+  uint32_t n_devices;       /* > 1: one multi-device context over device_ids (shk_config.n_devices); else `device` */
+  uint32_t reserved32;
+  const int32_t *device_ids;
 } shk_run_config;
 int shk_run_files(const shk_run_config *cfg, shk_run_stats *out_stats);
 

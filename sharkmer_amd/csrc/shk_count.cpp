@@ -23,6 +23,7 @@ int main(int argc, char **argv) {
   unsigned long long k = 19, chunks = 0, histo_max = 10000, max_reads = 0, validate_every = 0, threads = 1,
                      device = 0, hint = 0;
   const char *sample = nullptr, *outdir = "./";
+  std::vector<int32_t> devices;  // --devices 0,1,2,3: one multi-device context (not a reference flag)
   std::vector<const char *> inputs;
   std::string command;
   for (int i = 0; i < argc; ++i) {
@@ -61,6 +62,18 @@ int main(int argc, char **argv) {
     else if (key == "-t" || key == "--threads") num(&threads);
     else if (key == "--device") num(&device);
     else if (key == "--capacity-hint") num(&hint);
+    else if (key == "--devices") {
+      const char *v = val ? val : need(i, key.c_str());
+      for (const char *p = v; *p;) {
+        char *end = nullptr;
+        devices.push_back((int32_t)strtol(p, &end, 10));
+        if (end == p) {
+          fprintf(stderr, "error: invalid value '%s' for '--devices'\n", v);
+          return 2;
+        }
+        p = *end == ',' ? end + 1 : end;
+      }
+    }
     else if (key == "-s" || key == "--sample") sample = val ? argv[i] + eq + 1 : need(i, key.c_str());
     else if (key == "-o" || key == "--outdir") outdir = val ? argv[i] + eq + 1 : need(i, key.c_str());
     else if (key == "-h" || key == "--help") {
@@ -87,6 +100,8 @@ int main(int argc, char **argv) {
   rc.outdir = outdir;
   rc.command = command.c_str();
   rc.table_capacity_hint = hint;
+  rc.n_devices = (uint32_t)devices.size();
+  rc.device_ids = devices.empty() ? nullptr : devices.data();
   shk_run_stats st{};
   int rcode = shk_run_files(&rc, &st);
   if (rcode != SHK_OK) {

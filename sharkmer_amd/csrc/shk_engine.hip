@@ -95,6 +95,7 @@ struct shk_ctx {
   uint32_t n_lanes = 1;
   // owner share (cfg.n_owners > 1): this context holds the k-mers of owner `owner_id` only
   uint32_t n_owners = 1, owner_bits = 0, owner_id = 0;
+  int64_t xchg_lane_fixed = -1;  // the next shk_xchg_scatter_device sends every read to this chunk lane (multi-device shk_ingest_batch)
   uint32_t n_cus = 256;  // compute units of the device (multiProcessorCount)
   hipStream_t stream = nullptr;
   // table
@@ -902,7 +903,7 @@ static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub,
   int rc = xchg_check(c, g);
   if (rc != SHK_OK) return rc;
   const uint64_t lb = xo->layout_bases ? xo->layout_bases : std::max<uint64_t>(kmers_ub, TILE_T);
-  if (kmers_ub > (lb + TILE_T - 1) / TILE_T * TILE_T) return fail(c, SHK_ERR_BAD_ARG, "batch larger than the exchange layout it is to use");
+  if (b.n_bases > lb) return fail(c, SHK_ERR_BAD_ARG, "batch larger than the exchange layout it is to use");
   const XlPlan x = xchg_plan(c, g, lb);
   // the foreign spill list: whatever it holds already stays (the caller drains it between rounds)
   const uint64_t pending = c->h_stats->scratch[0];
@@ -1256,6 +1257,8 @@ static int settle_light(shk_ctx *c) {
   return SHK_OK;
 }
 
+#include "shk_group.hip.h"
+
 // =============================================================================================
 // C ABI
 // =============================================================================================
@@ -1280,6 +1283,14 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return fail(nullptr, SHK_ERR_NO_DEVICE, "no HIP device available (libshk has no CPU fallback)");
+  if (cfg->n_devices > 1) return group_create(cfg, out);  // one owner share per device (shk_group.hip.h)
+  if (cfg->n_devices == 1 && cfg->device_ids) {
+    shk_config c1 = *cfg;
+    c1.device = cfg->device_ids[0];
+    c1.n_devices = 0;
+    c1.device_ids = nullptr;
+    return shk_create(&c1, out);
+  }
   if (cfg->device < 0 || cfg->device >= n_dev)
     return fail(nullptr, SHK_ERR_NO_DEVICE, "device %d out of range (have %d)", cfg->device, n_dev);
   if (hipSetDevice(cfg->device) != hipSuccess)
@@ -1347,6 +1358,10 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   c->h_hist = (const uint64_t *)(c->h_ctl + c->ctl_hist_off);
   c->h_stats->bad = ~0ull;
   uint64_t want = cfg->table_capacity_hint ? cfg->table_capacity_hint * 2 : (1ull << 20);
+  if (c->owner_bits && 2 * cfg->k > 32 + c->owner_bits && 2 * cfg->k - 32 <= (uint32_t)env_int("SHK_LEVEL1_LOG", 10))
+    // an owner share starts with enough pages for 4-byte exchange records (2k − level-1 bits ≤ 32, the
+    // level-1 fan-out being at most the page bits of the virtual table): k = 21 → 2^10 pages over all owners
+    want = std::max<uint64_t>(want, (uint64_t)PAGE_SLOTS << (2 * cfg->k - 32 - c->owner_bits));
   int rc = alloc_table(c, log_pages_for(want, c->owner_bits), &c->tb);
   if (rc == SHK_OK) rc = fill_state(c, c->tb, true);
   if (rc != SHK_OK) return bail(rc);
@@ -1358,6 +1373,7 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
 
 void shk_destroy(shk_ctx *c) {
   if (!c) return;
+  if (c->group) return group_destroy(c);
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   resolve_timings(c);
@@ -1395,6 +1411,17 @@ void shk_destroy(shk_ctx *c) {
 
 int shk_reset(shk_ctx *c) {
   if (!c) return SHK_ERR_BAD_ARG;
+  if (c->group) {
+    shk_group *g = c->group;
+    for (uint32_t d = 0; d < g->D; ++d) {
+      const int rc = shk_reset(g->ctx[d]);
+      if (rc != SHK_OK) return group_fail(c, g, rc, d);
+    }
+    g->next_read = 0;
+    g->finalized = g->hist_ready = false;
+    c->err.clear();
+    return SHK_OK;
+  }
   HIPC(c, hipSetDevice(c->cfg.device));
   {
     int rc = fill_state(c, c->tb, true);  // table + control block (stats, totals, histogram) in one launch
@@ -1503,15 +1530,18 @@ int shk_ingest_batch(shk_ctx *c, uint32_t chunk_id, const uint8_t *bases, const 
   if (!c) return SHK_ERR_BAD_ARG;
   if (chunk_id >= c->n_lanes)
     return fail(c, SHK_ERR_BAD_ARG, "chunk_id %u out of range (n_chunks %u)", chunk_id, c->n_lanes);
+  if (c->group) return group_ingest(c, bases, offsets, n_seqs, (int64_t)chunk_id);
   return ingest_host(c, bases, offsets, n_seqs, (int64_t)chunk_id);
 }
 
 int shk_ingest_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs) {
+  if (c && c->group) return group_ingest(c, bases, offsets, n_seqs, -1);
   return ingest_host(c, bases, offsets, n_seqs, -1);
 }
 
 int shk_set_read_index(shk_ctx *c, uint64_t next_read_index) {
   if (!c) return SHK_ERR_BAD_ARG;
+  if (c->group) c->group->next_read = next_read_index;
   c->n_reads_read = next_read_index;
   return SHK_OK;
 }
@@ -1519,6 +1549,7 @@ int shk_set_read_index(shk_ctx *c, uint64_t next_read_index) {
 int shk_ingest_reads_device(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs,
                             uint64_t n_bases) {
   if (!c) return SHK_ERR_BAD_ARG;
+  if (c->group) return fail(c, SHK_ERR_STATE, "a multi-device context takes host buffers (shk_ingest_reads / shk_ingest_batch)");
   HIPC(c, hipSetDevice(c->cfg.device));
   return ingest_core(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_seqs, n_bases, -1);
 }
@@ -1526,6 +1557,15 @@ int shk_ingest_reads_device(shk_ctx *c, const void *d_bases, const void *d_offse
 int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, const uint32_t *counts,
                       uint64_t n) {
   if (!c) return SHK_ERR_BAD_ARG;
+  if (c->group) {  // every share is offered every k-mer and keeps what it owns
+    shk_group *g = c->group;
+    g->finalized = g->hist_ready = false;
+    for (uint32_t d = 0; d < g->D; ++d) {
+      const int rc = shk_insert_counts(g->ctx[d], chunk_id, kmers, counts, n);
+      if (rc != SHK_OK) return group_fail(c, g, rc, d);
+    }
+    return SHK_OK;
+  }
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
   {
     int rcs = settle(c);
@@ -1565,13 +1605,14 @@ int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, cons
 int shk_xchg_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases,
                             uint64_t layout_bases, void **d_records, void **d_cursors, shk_xchg_layout *layout,
                             uint64_t *n_foreign_spilled) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c || !d_records || !d_cursors || !layout) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
   if (n_bases > SHK_XCHG_MAX_BASES || (layout_bases && layout_bases > SHK_XCHG_MAX_BASES))
     return fail(c, SHK_ERR_BAD_ARG, "an exchange batch takes at most %llu bases", (unsigned long long)SHK_XCHG_MAX_BASES);
   XchgOut xo{};
   xo.layout_bases = layout_bases;
-  int rc = ingest_core(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_seqs, n_bases, -1, &xo);
+  int rc = ingest_core(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_seqs, n_bases, c->xchg_lane_fixed, &xo);
   if (rc != SHK_OK) return rc;
   *d_records = xo.d_records;
   *d_cursors = xo.d_cursors;
@@ -1581,6 +1622,7 @@ int shk_xchg_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offse
 }
 
 int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, const shk_xchg_layout *lay) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c || !lay) return SHK_ERR_BAD_ARG;
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -1626,6 +1668,7 @@ int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, co
 }
 
 int shk_xchg_spill(shk_ctx *c, void **d_kmers, void **d_lanes, void **d_counts, uint64_t *n) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c || !n) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
   int rc = read_stats(c);
@@ -1639,6 +1682,7 @@ int shk_xchg_spill(shk_ctx *c, void **d_kmers, void **d_lanes, void **d_counts, 
 }
 
 int shk_xchg_spill_clear(shk_ctx *c) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
   HIPC(c, hipMemsetAsync(&c->d_stats->scratch[0], 0, sizeof(unsigned long long), c->stream));
@@ -1648,6 +1692,7 @@ int shk_xchg_spill_clear(shk_ctx *c) {
 }
 
 int shk_insert_device(shk_ctx *c, const void *d_kmers, const void *d_lanes, const void *d_counts, uint64_t n) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -1674,10 +1719,17 @@ int shk_insert_device(shk_ctx *c, const void *d_kmers, const void *d_lanes, cons
   return drain_spill(c, n);
 }
 
-void *shk_stream(shk_ctx *c) { return c ? (void *)c->stream : nullptr; }
+void *shk_stream(shk_ctx *c) { return c && !c->group ? (void *)c->stream : nullptr; }
 
 int shk_sync(shk_ctx *c) {
   if (!c) return SHK_ERR_BAD_ARG;
+  if (c->group) {
+    for (uint32_t d = 0; d < c->group->D; ++d) {
+      const int rc = shk_sync(c->group->ctx[d]);
+      if (rc != SHK_OK) return group_fail(c, c->group, rc, d);
+    }
+    return SHK_OK;
+  }
   HIPC(c, hipSetDevice(c->cfg.device));
   HIPC(c, hipStreamSynchronize(c->stream));
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
@@ -1686,6 +1738,7 @@ int shk_sync(shk_ctx *c) {
 
 int shk_finalize(shk_ctx *c) {
   if (!c) return SHK_ERR_BAD_ARG;
+  if (c->group) return group_finalize(c);
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
   if (c->finalized) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -1775,6 +1828,13 @@ int shk_finalize(shk_ctx *c) {
 
 int shk_histograms(shk_ctx *c, uint64_t *out) {
   if (!c) return SHK_ERR_BAD_ARG;
+  if (c->group) {
+    if (!c->group->finalized && !c->group->hist_ready) return fail(c, SHK_ERR_STATE, "shk_histograms before shk_finalize");
+    if (c->cfg.chunks == 0) return SHK_OK;
+    if (!out) return fail(c, SHK_ERR_BAD_ARG, "null output");
+    memcpy(out, c->group->hist.data(), c->group->hist.size() * sizeof(uint64_t));
+    return SHK_OK;
+  }
   if (!c->finalized && !c->hist_ready) return fail(c, SHK_ERR_STATE, "shk_histograms before shk_finalize");
   if (c->cfg.chunks == 0) return SHK_OK;
   if (!out) return fail(c, SHK_ERR_BAD_ARG, "null output");
@@ -1784,6 +1844,7 @@ int shk_histograms(shk_ctx *c, uint64_t *out) {
 
 int shk_get_counters(shk_ctx *c, shk_counters *o) {
   if (!c || !o) return SHK_ERR_BAD_ARG;
+  if (c->group) return group_counters(c, o);
   HIPC(c, hipSetDevice(c->cfg.device));
   {
     int rcs = settle(c);
@@ -1815,6 +1876,15 @@ int shk_get_counters(shk_ctx *c, shk_counters *o) {
 
 int shk_get_timings(shk_ctx *c, shk_timings *o) {
   if (!c || !o) return SHK_ERR_BAD_ARG;
+  if (c->group) {  // summed over the devices
+    memset(o, 0, sizeof *o);
+    for (uint32_t d = 0; d < c->group->D; ++d) {
+      shk_timings t{};
+      (void)shk_get_timings(c->group->ctx[d], &t);
+      for (int i = 0; i < SHK_N_KERNELS; ++i) o->ms[i] += t.ms[i], o->launches[i] += t.launches[i];
+    }
+    return SHK_OK;
+  }
   (void)hipSetDevice(c->cfg.device);
   resolve_timings(c);
   *o = c->timings;
@@ -1823,6 +1893,10 @@ int shk_get_timings(shk_ctx *c, shk_timings *o) {
 
 int shk_reset_timings(shk_ctx *c) {
   if (!c) return SHK_ERR_BAD_ARG;
+  if (c->group) {
+    for (uint32_t d = 0; d < c->group->D; ++d) (void)shk_reset_timings(c->group->ctx[d]);
+    return SHK_OK;
+  }
   (void)hipSetDevice(c->cfg.device);
   resolve_timings(c);
   memset(&c->timings, 0, sizeof c->timings);
@@ -1831,6 +1905,19 @@ int shk_reset_timings(shk_ctx *c) {
 
 int shk_export_table(shk_ctx *c, uint64_t *kmers, uint32_t *counts, uint64_t cap, uint64_t *n_out) {
   if (!c || !n_out) return SHK_ERR_BAD_ARG;
+  if (c->group) {  // the shares are disjoint: one after the other
+    uint64_t at = 0;
+    for (uint32_t d = 0; d < c->group->D; ++d) {
+      uint64_t n = 0;
+      const uint64_t room = at < cap ? cap - at : 0;
+      const int rc = shk_export_table(c->group->ctx[d], kmers ? kmers + std::min(at, cap) : nullptr,
+                                      counts ? counts + std::min(at, cap) : nullptr, room, &n);
+      if (rc != SHK_OK) return group_fail(c, c->group, rc, d);
+      at += n;
+    }
+    *n_out = at;
+    return SHK_OK;
+  }
   HIPC(c, hipSetDevice(c->cfg.device));
   {
     int rcs = settle(c);
@@ -1863,6 +1950,16 @@ int shk_export_table(shk_ctx *c, uint64_t *kmers, uint32_t *counts, uint64_t cap
 }
 
 int shk_lookup(shk_ctx *c, const uint64_t *kmers, uint32_t *counts, uint64_t n, int canonical) {
+  if (c && c->group) {  // exactly one share owns a k-mer; the others answer 0
+    std::vector<uint32_t> part(n);
+    std::fill(counts, counts + n, 0u);
+    for (uint32_t d = 0; d < c->group->D; ++d) {
+      const int rc = shk_lookup(c->group->ctx[d], kmers, part.data(), n, canonical);
+      if (rc != SHK_OK) return group_fail(c, c->group, rc, d);
+      for (uint64_t i = 0; i < n; ++i) counts[i] += part[i];
+    }
+    return SHK_OK;
+  }
   if (!c) return SHK_ERR_BAD_ARG;
   if (n == 0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -1886,6 +1983,19 @@ int shk_lookup(shk_ctx *c, const uint64_t *kmers, uint32_t *counts, uint64_t n, 
 
 int shk_find_oligos(shk_ctx *c, const uint64_t *oligos, uint32_t n_oligos, uint32_t oligo_len,
                     uint32_t min_count, uint64_t *kmers, uint32_t *counts, uint64_t cap, uint64_t *n_out) {
+  if (c && c->group) {  // the shares are disjoint: one after the other
+    uint64_t at = 0;
+    for (uint32_t d = 0; d < c->group->D; ++d) {
+      uint64_t n = 0;
+      const uint64_t room = at < cap ? cap - at : 0;
+      const int rc = shk_find_oligos(c->group->ctx[d], oligos, n_oligos, oligo_len, min_count, kmers ? kmers + std::min(at, cap) : nullptr,
+                                     counts ? counts + std::min(at, cap) : nullptr, room, &n);
+      if (rc != SHK_OK) return group_fail(c, c->group, rc, d);
+      at += n;
+    }
+    if (n_out) *n_out = at;
+    return SHK_OK;
+  }
   if (!c || !n_out) return SHK_ERR_BAD_ARG;
   const uint32_t k = c->cfg.k;
   // the reference asserts these (primers.rs:169-186)
@@ -1946,6 +2056,10 @@ int shk_find_oligos(shk_ctx *c, const uint64_t *oligos, uint32_t n_oligos, uint3
 
 int shk_filter_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
                      const uint64_t *primer_kmers, uint64_t n_kmers, uint8_t *out_matches) {
+  if (c && c->group) {  // stateless: any device will do
+    const int rc = shk_filter_reads(c->group->ctx[0], bases, offsets, n_seqs, primer_kmers, n_kmers, out_matches);
+    return rc == SHK_OK ? rc : group_fail(c, c->group, rc, 0);
+  }
   if (!c || (n_seqs && (!offsets || !out_matches))) return SHK_ERR_BAD_ARG;
   if (n_seqs == 0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -1994,6 +2108,10 @@ int shk_filter_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, 
 
 int shk_kmers_from_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
                          uint64_t *kmers, uint64_t kmers_cap, uint32_t *n_kmers, uint8_t *bad_byte) {
+  if (c && c->group) {  // stateless: any device will do
+    const int rc = shk_kmers_from_reads(c->group->ctx[0], bases, offsets, n_seqs, kmers, kmers_cap, n_kmers, bad_byte);
+    return rc == SHK_OK ? rc : group_fail(c, c->group, rc, 0);
+  }
   if (!c || (n_seqs && (!offsets || !n_kmers || !bad_byte))) return SHK_ERR_BAD_ARG;
   if (n_seqs == 0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -2041,6 +2159,7 @@ int shk_kmers_from_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offse
 }
 
 int shk_table_geometry(shk_ctx *c, uint64_t *n_pages, uint32_t *page_slots, uint32_t *n_lanes) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
   {
@@ -2054,6 +2173,7 @@ int shk_table_geometry(shk_ctx *c, uint64_t *n_pages, uint32_t *page_slots, uint
 }
 
 int shk_table_reserve_pages(shk_ctx *c, uint64_t n_pages) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
   {
@@ -2067,6 +2187,7 @@ int shk_table_reserve_pages(shk_ctx *c, uint64_t n_pages) {
 }
 
 int shk_table_device_ptrs(shk_ctx *c, void **d_keys, void **d_vals) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
   {
@@ -2081,6 +2202,7 @@ int shk_table_device_ptrs(shk_ctx *c, void **d_keys, void **d_vals) {
 
 int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, const void *d_vals,
                     uint64_t vals_lane_stride) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   if (p1 <= p0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -2107,6 +2229,7 @@ int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, co
 }
 
 int shk_owner_counts(shk_ctx *c, uint32_t n_owners, uint64_t *counts) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c || !counts || n_owners == 0) return SHK_ERR_BAD_ARG;
   const uint64_t n_pages = 1ull << c->tb.log_pages;
   if (n_pages % n_owners) return fail(c, SHK_ERR_BAD_ARG, "%llu pages do not split over %u owners",
@@ -2129,6 +2252,7 @@ int shk_owner_counts(shk_ctx *c, uint32_t n_owners, uint64_t *counts) {
 
 int shk_compact_owners(shk_ctx *c, uint32_t n_owners, const uint64_t *seg_offsets, void *d_keys, void *d_vals,
                        uint64_t vals_lane_stride, int32_t skip_owner) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c || !seg_offsets || n_owners == 0) return SHK_ERR_BAD_ARG;
   const uint64_t n_pages = 1ull << c->tb.log_pages;
   if (n_pages % n_owners) return fail(c, SHK_ERR_BAD_ARG, "%llu pages do not split over %u owners",
@@ -2147,6 +2271,7 @@ int shk_compact_owners(shk_ctx *c, uint32_t n_owners, const uint64_t *seg_offset
 }
 
 int shk_merge_entries(shk_ctx *c, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   if (n == 0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
@@ -2170,6 +2295,7 @@ int shk_merge_entries(shk_ctx *c, const void *d_keys, const void *d_vals, uint64
 }
 
 int shk_set_owned_pages(shk_ctx *c, uint64_t p0, uint64_t p1) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   if (p1 < p0 || p1 > (1ull << c->tb.log_pages)) return fail(c, SHK_ERR_BAD_ARG, "bad page range");
   c->own_p0 = p0;
@@ -2188,6 +2314,7 @@ void shk_free_pinned(void *p) {
   if (p) (void)hipHostFree(p);
 }
 void *shk_alloc_device(shk_ctx *c, size_t bytes) {
+  if (c && c->group) return nullptr;
   if (!c) return nullptr;
   (void)hipSetDevice(c->cfg.device);
   void *p = nullptr;
@@ -2195,6 +2322,7 @@ void *shk_alloc_device(shk_ctx *c, size_t bytes) {
   return p;
 }
 void shk_free_device(shk_ctx *c, void *p) {
+  if (c && c->group) return;
   if (!c || !p) return;
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
@@ -2203,6 +2331,7 @@ void shk_free_device(shk_ctx *c, void *p) {
 
 int shk_synth_reads_device(shk_ctx *c, const shk_synth *spec, uint64_t first_read, uint64_t n_reads,
                            void *d_bases, void *d_offsets) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c || !spec) return SHK_ERR_BAD_ARG;
   if (spec->read_len == 0 || spec->genome_len < spec->read_len)
     return fail(c, SHK_ERR_BAD_ARG, "bad synth spec");

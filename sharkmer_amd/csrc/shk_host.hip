@@ -507,6 +507,12 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
   cfg.histo_max = rc->histo_max;
   cfg.device = rc->device;
   cfg.table_capacity_hint = rc->table_capacity_hint;
+  if (rc->n_devices > 1) {  // one context over several devices; a single device id is just that device
+    cfg.n_devices = rc->n_devices;
+    cfg.device_ids = rc->device_ids;
+  } else if (rc->n_devices == 1 && rc->device_ids) {
+    cfg.device = rc->device_ids[0];
+  }
   shk_ctx *ctx = nullptr;
   v = shk_create(&cfg, &ctx);
   if (v != SHK_OK) {

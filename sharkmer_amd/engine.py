@@ -84,7 +84,8 @@ class _RunConfig(C.Structure):
                 ("max_reads", C.c_uint64), ("validate_every", C.c_uint64), ("sample", C.c_char_p),
                 ("outdir", C.c_char_p), ("command", C.c_char_p), ("version", C.c_char_p),
                 ("table_capacity_hint", C.c_uint64), ("batch_reads", C.c_uint64),
-                ("batch_bases", C.c_uint64)]
+                ("batch_bases", C.c_uint64), ("n_devices", C.c_uint32), ("reserved32", C.c_uint32),
+                ("device_ids", C.POINTER(C.c_int32))]
 
 
 class _Synth(C.Structure):
@@ -656,8 +657,9 @@ def validate_args(k: int, histo_max: int, sample):
 
 def run_files(inputs, k: int, chunks: int, sample: str, outdir: str = "./", histo_max: int = 10000,
               max_reads: int = 0, validate_every: int = 0, device: int = 0, capacity_hint: int = 0,
-              command: str = "", batch_reads: int = 0, batch_bases: int = 0) -> dict:
-    """main.rs:112-197 without sPCR: FASTQ files → counts → .histo/.final.histo/.stats.yaml."""
+              command: str = "", batch_reads: int = 0, batch_bases: int = 0, device_ids=None) -> dict:
+    """main.rs:112-197 without sPCR: FASTQ files → counts → .histo/.final.histo/.stats.yaml.
+    device_ids: run on one multi-device context (shk_run_config.n_devices)."""
     L = load_library()
     arr = (C.c_char_p * max(len(inputs), 1))(*[os.fsencode(p) for p in inputs])
     cfg = _RunConfig(inputs=arr, n_inputs=len(inputs), k=k, chunks=chunks, device=device,
@@ -665,6 +667,10 @@ def run_files(inputs, k: int, chunks: int, sample: str, outdir: str = "./", hist
                      sample=None if sample is None else sample.encode(), outdir=os.fsencode(outdir),
                      command=command.encode(), version=None, table_capacity_hint=capacity_hint,
                      batch_reads=batch_reads, batch_bases=batch_bases)
+    if device_ids is not None:
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        cfg.n_devices = len(device_ids)
+        cfg.device_ids = C.cast(ids, C.POINTER(C.c_int32))
     st = _RunStats()
     rc = L.shk_run_files(C.byref(cfg), C.byref(st))
     if rc != 0:
