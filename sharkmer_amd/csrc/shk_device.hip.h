@@ -91,35 +91,46 @@ struct SpillRef {
 // tools/hash_eval.py: page occupancy and slot collisions match a Poisson process on random,
 // AT-rich, tandem-repeat and sequential keys (without the finaliser sequential keys collide).
 constexpr uint32_t MAX_LOG_PAGES = 20;  // page bits + the 11 home-bucket bits ≤ 32 hash bits; 2^33 slots ≈ 103 GB
-// mix_key: a BIJECTION of the 2k-bit key space (multiply by an odd constant mod 2^2k, fold the
-// upper half down, multiply again: every step is invertible), so the position of a key in the
-// table — page = top log_pages bits, home bucket = next 11 bits — together with the remaining
-// low bits identifies the key.  The 4-byte-record path of the paged counter ships only those
-// low bits and rebuilds a key with unmix_key when it has to.
-// The multipliers are 32-bit odd numbers on purpose: a 64-bit product by one of them is one
-// v_mad_u64_u32 + one v_mul_lo_u32 instead of the four instructions a 64-bit constant costs, in a
-// kernel (k_scatter32) that is bound by VALU issue; tools/hash_eval.py shows the same Poisson-like
-// page and bucket occupancy as with 64-bit constants.
-constexpr uint64_t MIX_M1 = 0x9E3779B1ull, MIX_M2 = 0x85EBCA6Bull;
-constexpr uint64_t MIX_M1_INV = 0xCFA4A56B0E8B2F51ull, MIX_M2_INV = 0x000A7324A5CB9243ull;  // mod 2^64
-static_assert((MIX_M1 * MIX_M1_INV) == 1ull && (MIX_M2 * MIX_M2_INV) == 1ull, "inverses mod 2^64");
+// mix_key: a BIJECTION of the 2k-bit key space — ONE multiplication by an odd constant mod 2^2k — so the
+// position of a key in the table (page = top log_pages bits of the product, home bucket = the next 11
+// bits) together with the remaining low bits identifies the key.  The 4-byte-record path of the paged
+// counter ships only those low bits and rebuilds a key with unmix_key (the inverse multiplication) when
+// it has to.  Everything the engine reads off the mixed key it reads off its TOP bits (owner, partition,
+// page, bucket), and the top bits of a product depend on every bit of the key; the low bits, which depend
+// on the key's low bits only, are just carried along as the fingerprint.  Up to 42 key bits (k ≤ 21: the
+// 4-byte-record path, k_scatter32, which is bound by VALU issue) the multiplier is a 32-bit constant — a
+// 64-bit product by it is one v_mad_u64_u32 + one v_mul_lo_u32 — beyond that a 64-bit one (longer keys need
+// the wider constant for keys that differ in their low bits only to reach the top).  tools/hash_eval.py:
+// page occupancy and bucket overflow match a Poisson process on random, AT-rich, tandem-repeat and
+// sequential keys for k = 9…31 (round 1 used multiply–fold–multiply; one multiply measures the same
+// spread and takes five instructions fewer per k-mer in the scatter's walk).
+#ifndef SHK_MIX_M32
+#define SHK_MIX_M32 0xC2B2AE35ull
+#define SHK_MIX_M32_INV 0xD16E308E7ED1B41Dull
+#endif
+constexpr uint64_t MIX_M32 = SHK_MIX_M32, MIX_M64 = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t MIX_M32_INV = SHK_MIX_M32_INV, MIX_M64_INV = 0xF1DE83E19937733Dull;  // mod 2^64
+static_assert((MIX_M32 * MIX_M32_INV) == 1ull && (MIX_M64 * MIX_M64_INV) == 1ull, "inverses mod 2^64");
+#ifndef SHK_MIX_NARROW_BITS
+#define SHK_MIX_NARROW_BITS 42
+#endif
+constexpr uint32_t MIX_NARROW_BITS = SHK_MIX_NARROW_BITS;
 __host__ __device__ __forceinline__ uint64_t mix_key(uint64_t x, uint32_t bits) {
   const uint64_t mask = ~0ull >> (64 - bits);
-  x = (x * MIX_M1) & mask;
-  x ^= x >> ((bits + 1) >> 1);
-  return (x * MIX_M2) & mask;
+  return (x * (bits <= MIX_NARROW_BITS ? MIX_M32 : MIX_M64)) & mask;
 }
 __host__ __device__ __forceinline__ uint64_t unmix_key(uint64_t y, uint32_t bits) {
   const uint64_t mask = ~0ull >> (64 - bits);
-  y = (y * MIX_M2_INV) & mask;
-  y ^= y >> ((bits + 1) >> 1);  // the fold is its own inverse: the shift is at least half the width
-  return (y * MIX_M1_INV) & mask;
+  return (y * (bits <= MIX_NARROW_BITS ? MIX_M32_INV : MIX_M64_INV)) & mask;
 }
 // the 32 hash bits the table geometry is read from: the top of the mixed key
 __device__ __forceinline__ uint32_t hash64(uint64_t key, uint32_t bits) {
-  uint64_t x = (key * MIX_M1) & (~0ull >> (64 - bits));
-  x ^= x >> ((bits + 1) >> 1);
-  return (uint32_t)(((x * MIX_M2) << (64 - bits)) >> 32);
+  return (uint32_t)((mix_key(key, bits) << (64 - bits)) >> 32);
+}
+// a full-avalanche hash for small open-addressing sets that index by LOW bits (k_filter_reads' primer set)
+__host__ __device__ __forceinline__ uint32_t set_hash(uint64_t key) {
+  key ^= key >> 31;
+  return (uint32_t)((key * MIX_M64) >> 32);
 }
 __device__ __forceinline__ uint64_t page_of(uint32_t h, uint32_t log_pages) {
   return log_pages ? (uint64_t)(h >> (32 - log_pages)) : 0ull;
@@ -447,6 +458,127 @@ __device__ __forceinline__ uint32_t stage_tile(const BatchRef &b, uint64_t t0, u
     }
   }
   return n_non_n;
+}
+
+// ---- k_scatter32's staging: one 16-base group per thread, kept in REGISTERS -------------------------------
+// Thread t owns group t + 2 of the staged tile — exactly the sixteen end positions it walks — so the
+// group's packed bases and its "a k-mer ends here" bits never leave its registers; only what its
+// NEIGHBOURS need (the packed word for the walk's warm-up window, the N / read-start masks for the
+// validity smear) goes through LDS, as one (packed, masks) pair per group, behind ONE barrier.
+// Threads 0 and 1 stage the two halo groups as well.  (stage_tile's generic form — code bytes or packed
+// streams in LDS, a second pass for the validity bits behind a second barrier — serves the other kernels.)
+template <int NT, int TT>
+struct StageRegs32 {
+  uint32_t raw[2][4];
+  uint32_t sb0[2], sb1[2];
+};
+// group index of (thread, slot): slot 0 = the thread's own group, slot 1 = a halo group (threads 0, 1)
+template <int NT>
+__device__ __forceinline__ int stage32_group(int slot) { return slot == 0 ? (int)threadIdx.x + 2 : (int)threadIdx.x; }
+template <int NT, int TT>
+__device__ __forceinline__ void stage32_prefetch(const BatchRef &b, uint64_t t0, StageRegs32<NT, TT> &pre) {
+  const int64_t p0 = (int64_t)t0 - HALO;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r == 1 && threadIdx.x >= 2) break;
+    const int m = stage32_group<NT>(r);
+    const int64_t p = p0 + (int64_t)m * 16;
+    if (p >= 0 && (uint64_t)p + 16 <= b.n_bases) {
+      __builtin_memcpy(pre.raw[r], b.bases + p, 16);  // unaligned 16-B global load (one dwordx4)
+      pre.sb0[r] = b.startbits[(uint64_t)p >> 5];
+      pre.sb1[r] = b.startbits[((uint64_t)p >> 5) + 1];
+    }
+  }
+}
+// One group: validate + count non-N bases (positions in [t0, t1) only), 2-bit pack, N / read-start masks.
+// Returns the packed word (first base on top); *gm = nmask16 | startmask16 << 16; *nn += non-N bases.
+__device__ __forceinline__ uint32_t stage32_group_regs(const BatchRef &b, uint64_t t0, uint64_t t1, int m, const uint32_t (&raw)[4],
+                                                       uint32_t sb0, uint32_t sb1, DevStats *stats, uint32_t *gm, uint32_t *nn) {
+  const int64_t p = (int64_t)t0 - HALO + (int64_t)m * 16;
+  uint32_t w[4];
+  uint32_t nmask = 0;
+  const bool fast = p >= 0 && (uint64_t)p + 16 <= b.n_bases;  // same test as stage32_prefetch
+  if (fast) {
+    w[0] = raw[0], w[1] = raw[1], w[2] = raw[2], w[3] = raw[3];
+    if ((uint64_t)p >= t0 && (uint64_t)p < t1) {
+      if ((uint64_t)p + 16 <= t1) {
+        uint32_t bad = 0, n_n = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t z;
+          const uint32_t c = codes4(w[q], &z);  // (the conversion below recomputes it: CSE)
+          bad |= invalid_bytes4(w[q], c);
+          n_n += __builtin_popcount(z);
+        }
+        *nn += 16 - n_n;
+        if (bad) {
+          for (int r = 0; r < 16; ++r) {
+            const uint32_t c = (w[r >> 2] >> (8 * (r & 3))) & 0xFF;
+            if (!byte_is_acgtn(c)) {
+              atomicMin(&stats->bad, ((unsigned long long)(p + r) << 8) | c);
+              break;
+            }
+          }
+        }
+      } else {
+        for (int r = 0; r < 16 && (uint64_t)p + r < t1; ++r) {
+          const uint32_t c = (w[r >> 2] >> (8 * (r & 3))) & 0xFF;
+          if (!byte_is_acgtn(c)) atomicMin(&stats->bad, ((unsigned long long)(p + r) << 8) | c);
+          *nn += (c != 'N');
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t z;
+      w[q] = codes4(w[q], &z);
+      nmask |= msb_gather4(z) << (4 * q);
+    }
+  } else {
+    const uint4 e = stage_edge_group(b.bases, b.n_bases, p, t0, t1, true, stats);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t c8 = (e.x >> (8 * q)) & 0xFFu;  // four 2-bit codes
+      w[q] = (c8 & 3u) | (((c8 >> 2) & 3u) << 8) | (((c8 >> 4) & 3u) << 16) | (((c8 >> 6) & 3u) << 24);
+    }
+    nmask = e.y;
+    *nn += e.z;
+  }
+  uint32_t f = 0;  // read-start flags for these 16 positions: bits [p, p+16) of startbits
+  if (fast) {
+    const uint64_t two = (uint64_t)sb0 | ((uint64_t)sb1 << 32);
+    f = (uint32_t)(two >> ((uint32_t)p & 31)) & 0xFFFFu;
+  } else if (p >= 0 && (uint64_t)p < b.n_bases) {
+    const uint64_t wi = (uint64_t)p >> 5;
+    const uint64_t two = (uint64_t)b.startbits[wi] | ((uint64_t)b.startbits[wi + 1] << 32);
+    f = (uint32_t)(two >> ((uint32_t)p & 31)) & 0xFFFFu;
+  } else if (p < 0 && p + 16 > 0) {  // straddles position 0
+    f = (b.startbits[0] << (uint32_t)(-p)) & 0xFFFFu;
+  }
+  *gm = nmask | (f << 16);
+  return pack16(make_uint4(w[0], w[1], w[2], w[3]));
+}
+// "a k-mer ends here" bits of a group from its own masks g2 and those of the two groups before it
+// (position j is bad if an N lies in [j-k+1, j] or a read starts in [j-k+2, j]); positions at or beyond
+// the tile's end never get the bit.
+__device__ __forceinline__ uint32_t stage32_okbits(uint32_t g0, uint32_t g1, uint32_t g2, int k, int lim) {
+  uint64_t N = (uint64_t)(g0 & 0xFFFFu) | ((uint64_t)(g1 & 0xFFFFu) << 16) | ((uint64_t)(g2 & 0xFFFFu) << 32);
+  uint64_t S = (uint64_t)(g0 >> 16) | ((uint64_t)(g1 >> 16) << 16) | ((uint64_t)(g2 >> 16) << 32);
+  // an N at p spoils the end positions [p, p+k-1], a read start at p the end positions [p, p+k-2]: ONE
+  // smear of N | S over k-1 positions, plus the N's themselves k-1 further on
+  uint64_t T = k >= 2 ? N | S : N;
+  if (k >= 2) {
+    int s = 1;
+    while (2 * s <= k - 1) {
+      T |= T << s;
+      s *= 2;
+    }
+    if (k - 1 > s) T |= T << (k - 1 - s);
+    T |= N << (k - 1);
+  }
+  uint32_t ok = ~(uint32_t)(T >> 32) & 0xFFFFu;  // ≥ 32 ≥ k-1 bases of history
+  if (lim < 16) ok = lim > 0 ? ok & ((1u << lim) - 1u) : 0u;
+  return ok;
 }
 
 // workgroup sum of a per-thread u32, result valid in thread 0 (red: WG/64 words of LDS)
@@ -1115,7 +1247,7 @@ __global__ void __launch_bounds__(WG) k_filter_reads(const uint8_t *__restrict__
     rev = (rev >> 2) | ((3 - b2) << (2 * (k - 1)));
     if (++n_valid >= k && !hit) {
       const uint64_t key = fwd < rev ? fwd : rev;
-      for (uint32_t s = (uint32_t)mix_key(key, 2 * k) & set_mask;; s = (s + 1) & set_mask) {
+      for (uint32_t s = set_hash(key) & set_mask;; s = (s + 1) & set_mask) {
         const uint64_t cur = set_keys[s];
         if (cur == key) hit = true;
         if (cur == key || cur == EMPTY) break;
@@ -1685,11 +1817,11 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
 // tstart read has to wait behind the previous entry's write (one LDS round trip per entry).
 template <int NT, int SPAN>
 __device__ __forceinline__ void place_entries(uint32_t *__restrict__ sorted, const uint32_t *__restrict__ tstart,
-                                              const uint32_t (&pr)[SPAN]) {
+                                              const uint32_t (&pr)[SPAN], uint32_t P) {
 #pragma unroll
   for (int i = 0; i < SPAN; ++i) {
-    const uint32_t v = pr[i];
-    if (v != 0xFFFFFFFFu) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = ((v >> 16) << 14) | (i * NT + threadIdx.x);  // → recs index
+    const uint32_t v = pr[i];  // partition << 16 | rank; partitions ≥ P are the walk's spare counters (no record)
+    if (v < (P << 16)) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = ((v >> 16) << 14) | (i * NT + threadIdx.x);  // → recs index
   }
 }
 
@@ -1731,12 +1863,11 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   constexpr int GROUPS = (TT + HALO) / 16;
   const uint32_t log_parts = LOGP ? (uint32_t)LOGP : log_parts_;
   const uint32_t P = 1u << log_parts;
-  uint8_t *codes = reinterpret_cast<uint8_t *>(sh);  // the stage's group masks (GROUPS words), then the
-  uint16_t *okbits = reinterpret_cast<uint16_t *>(sh + GROUPS + 2);  // "k-mer ends here" bits, 16 per group; dead once the walk is over
-  static_assert(SPAN == 16, "the walk reads one packed word and one okbits half-word per thread");
-  uint32_t *sorted = sh;                             // TT entries; aliases codes
+  uint2 *pg = reinterpret_cast<uint2 *>(sh);         // the stage's (packed word, N | read-start masks) per group, for the neighbours; dead once the walk starts
+  static_assert(SPAN == 16 && GROUPS == NT + 2, "a thread walks exactly the group it staged");
+  uint32_t *sorted = sh;                             // TT entries; aliases pg
   uint32_t *recs = sh + TT;                          // TT records: thread t's i-th end position at i·NT + t
-  uint32_t *packed = recs + TT;                      // GROUPS + 2 words
+  uint32_t *packed = recs + TT;                      // (GROUPS + 2 words, unused since the staged groups stay in registers)
   uint32_t *cnt = packed + GROUPS + 2;               // P
   uint32_t *tstart = cnt + P;                        // P
   uint32_t *gbase = tstart + P;                      // P: (this tile's reservation) - tstart
@@ -1767,8 +1898,8 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   uint32_t lane;
   bool have = next_tile(b, t, !all_lanes, lane_filter, t0, t1, lane);
   uint32_t sub = 0;
-  StageRegs<NT, TT> pre;
-  if (have) stage_prefetch<NT, TT>(b, t0, pre);
+  StageRegs32<NT, TT> pre;
+  if (have) stage32_prefetch<NT, TT>(b, t0, pre);
   while (have) {
     const uint64_t s0 = t0 + (uint64_t)sub * TT;
     const uint64_t s1 = s0 + TT < t1 ? s0 + TT : t1;
@@ -1777,8 +1908,17 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
     tprev = __builtin_readcyclecounter();
 #endif
     for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
+    // ---- stage: this thread's group (and, threads 0 and 1, a halo group) → registers + one LDS pair ----
+    uint32_t my_pw, my_gm;
     {
-      const uint32_t nn = stage_tile<true, NT, true, TT, true>(b, s0, s1, codes, stats, pre, packed, nullptr, okbits);
+      uint32_t nn = 0;
+      my_pw = stage32_group_regs(b, s0, s1, (int)threadIdx.x + 2, pre.raw[0], pre.sb0[0], pre.sb1[0], stats, &my_gm, &nn);
+      pg[threadIdx.x + 2] = make_uint2(my_pw, my_gm);
+      if (threadIdx.x < 2) {
+        uint32_t gm1;
+        const uint32_t pw1 = stage32_group_regs(b, s0, s1, (int)threadIdx.x, pre.raw[1], pre.sb0[1], pre.sb1[1], stats, &gm1, &nn);
+        pg[threadIdx.x] = make_uint2(pw1, gm1);
+      }
       if (all_lanes) {  // this tile's lane: wave sum, one LDS add per wave
         uint32_t v = nn;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -1796,7 +1936,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
       hn = next_tile(b, nt, !all_lanes, lane_filter, n0, n1, nl);
       nsub = 0;
     }
-    if (hn) stage_prefetch<NT, TT>(b, n0 + (uint64_t)nsub * TT, pre);  // in flight during the rest of this one
+    if (hn) stage32_prefetch<NT, TT>(b, n0 + (uint64_t)nsub * TT, pre);  // in flight during the rest of this one
     __syncthreads();
     STAMP(0);
     // ---- walk ---------------------------------------------------------------------------------
@@ -1807,9 +1947,14 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
       const int jemit = HALO + e0;
       const int jend = HALO + (e0 + SPAN < n_end ? e0 + SPAN : n_end);
       Roll x{0, 0, 0, 0};
-      if (e0 < n_end) {
-        // frames just before the first end position: the k bases up to jemit-1 as one window
-        const uint64_t f0 = window_at(packed, jemit - k, k);
+      // the two groups before mine: their packed words are the walk's warm-up window, their masks the
+      // history of my validity bits
+      const uint2 gA = pg[threadIdx.x], gB = pg[threadIdx.x + 1];
+      const uint32_t my_ok = stage32_okbits(gA.y, gB.y, my_gm, k, n_end + HALO - ((int)threadIdx.x + 2) * 16);
+      {
+        // frames just before the first end position: the k bases up to jemit-1 are the low 2k bits of the
+        // 32 bases of the two groups before mine
+        const uint64_t f0 = (((uint64_t)gA.x << 32) | gB.x) & mask;
         const uint64_t r0 = revcomp(f0, k) << (64 - 2 * k);
         x.f_lo = (uint32_t)f0;
         x.f_hi = (uint32_t)(f0 >> 32);
@@ -1829,9 +1974,24 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
       // this thread's sixteen end positions are exactly group 2 + threadIdx.x of the staged tile: their
       // bases are one word of the packed stream (first base on top), their "a k-mer ends here" bits one
       // half-word (never set at or beyond the tile's end)
-      const uint32_t pw = packed[2 + threadIdx.x];
-      const uint32_t okw = okbits[2 + threadIdx.x];
+      const uint32_t pw = my_pw;
+      const uint32_t okw = my_ok;
+      const uint32_t spare_pc = P + (threadIdx.x & 7u);
       (void)jend;
+      (void)jemit;
+      const uint32_t npw = ~pw;
+      const uint32_t rbits_c = RB32 ? 32u : rbits;
+#ifdef SHK_EXP_GENERIC_WALK
+      if (false) {
+#else
+      if (KC >= 17) {  // this copy keeps BOTH frames left-aligned
+#endif
+        const uint64_t ff = (((uint64_t)x.f_hi << 32) | x.f_lo) << (64 - 2 * (KC ? KC : 1));
+        x.f_lo = (uint32_t)ff;
+        x.f_hi = (uint32_t)(ff >> 32);
+      }
+      (void)npw;
+      (void)rbits_c;
 #pragma unroll
       for (int q = 0; q < SPAN / 8; ++q) {
         // Straight-line on purpose: every lane mixes and issues its LDS add (end positions without
@@ -1843,19 +2003,57 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const uint32_t c = ((pw >> (30 - 2 * (q * 8 + r))) & 3u) | (((okw >> (q * 8 + r)) & 1u) << 2);
-          roll_step(x, c & 3u, mlo, mhi);
-          const uint64_t fwd = ((uint64_t)x.f_hi << 32) | x.f_lo;
-          const uint64_t rev = (((uint64_t)x.r_hi << 32) | x.r_lo) >> (64 - 2 * kk);
-          const uint64_t y = mix_key(rev < fwd ? rev : fwd, 2 * kk);
-          const uint32_t page = RB32 ? (uint32_t)(y >> 32) : (uint32_t)(y >> rbits);
-          bool emit = (c & 4u) != 0u;
-          if (OWN) emit = emit && ((((page >> log_p1w) ^ own.keep) & keep_mask) == 0u);  // a foreign owner's record: dropped
-          pcs[r] = emit ? page : P + (threadIdx.x & 7u);
+          uint64_t y;
+          uint32_t page;
+#ifdef SHK_EXP_GENERIC_WALK
+          if (false) {
+#else
+          if (KC >= 17) {
+#endif
+            // Hand-shaped for instruction COUNT (every integer VALU op of this loop, 64-bit shifts, compares
+            // and v_mad_u64_u32 included, issues at the same 4 cycles per wave on gfx950 — tools/ibench2.hip —
+            // and the kernel is 70 % VALU-busy): BOTH frames are LEFT-aligned in 64 bits here, so shifting
+            // needs no mask on the way out (the forward frame sheds its oldest base off the top, its low
+            // 64-2k bits stay zero; the reverse frame sheds off the bottom into bits that are cleared once,
+            // after the select), min(fwd, rev) is one 64-bit compare on the frames as they are, and the
+            // product by the 32-bit multiplier one v_mul_lo_u32 + one v_mad_u64_u32 (mod 2^64 on a
+            // left-aligned key IS mod 2^2k on the key).
+            constexpr uint32_t LS = 64u - 2u * (KC ? KC : 1);      // left shift of a frame (22 at k = 21)
+            constexpr int BSH = 30 - 2 * 8 * 0;                    // (see bsh below)
+            (void)BSH;
+            const int bpos = 30 - 2 * (q * 8 + r);                 // where this step's base sits in pw
+            // the base at bits [LS, LS+2) of a word, and the complement base at bits [0, 2): one shift each
+            const uint32_t bL = (bpos >= (int)LS ? pw >> ((bpos - (int)LS) & 31) : pw << (((int)LS - bpos) & 31)) & (3u << (LS & 31));
+            const uint32_t nb = npw >> bpos;
+            x.f_hi = __builtin_amdgcn_alignbit(x.f_hi, x.f_lo, 30);
+            x.f_lo = (x.f_lo << 2) | bL;
+            x.r_lo = __builtin_amdgcn_alignbit(x.r_hi, x.r_lo, 2);
+            x.r_hi = __builtin_amdgcn_alignbit(nb, x.r_hi, 2);   // (only nb's low two bits enter)
+            const uint64_t fL = ((uint64_t)x.f_hi << 32) | x.f_lo, rL = ((uint64_t)x.r_hi << 32) | x.r_lo;
+            // (k odd: a k-mer is never its own reverse complement, so the bits below LS of the reverse frame
+            // — bases that have left the window — cannot decide the compare; k even: a tie is a palindrome and
+            // both arms are the same k-mer)
+            const uint64_t cL = (rL < fL ? rL : fL) & ~((1ull << LS) - 1ull);
+            const uint64_t yL = (uint64_t)(uint32_t)cL * (uint32_t)MIX_M32 + ((uint64_t)((uint32_t)(cL >> 32) * (uint32_t)MIX_M32) << 32);
+            y = yL >> LS;                                          // (the record below takes its low 32 bits)
+            page = (uint32_t)(yL >> ((LS + rbits_c) & 63));
+          } else {
+            roll_step(x, c & 3u, mlo, mhi);
+            const uint64_t fwd = ((uint64_t)x.f_hi << 32) | x.f_lo;
+            const uint64_t rev = (((uint64_t)x.r_hi << 32) | x.r_lo) >> (64 - 2 * kk);
+            y = mix_key(rev < fwd ? rev : fwd, 2 * kk);
+            page = RB32 ? (uint32_t)(y >> 32) : (uint32_t)(y >> rbits);
+          }
+          // emit mask as arithmetic (all ones / zero) and a bit-select instead of ?: — the compiler turns a
+          // select whose one arm is expensive into an exec-mask branch around that arm, per k-mer
+          uint32_t em = 0u - ((okw >> (q * 8 + r)) & 1u);
+          if (OWN) em &= 0u - (uint32_t)((((page >> log_p1w) ^ own.keep) & keep_mask) == 0u);  // a foreign owner's record: dropped
+          pcs[r] = (page & em) | (spare_pc & ~em);
           recs[(q * 8 + r) * NT + threadIdx.x] = RB32 ? (uint32_t)y : (uint32_t)y & rmask;  // transposed: no bank conflicts
           rks[r] = atomicAdd(&cnt[pcs[r]], 1u);  // rank < 2^14
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pr[q * 8 + r] = pcs[r] >= P ? 0xFFFFFFFFu : (pcs[r] << 16) | rks[r];
+        for (int r = 0; r < 8; ++r) pr[q * 8 + r] = (pcs[r] << 16) | rks[r];  // (a spare counter, ≥ P: no record — place_entries looks)
       }
       };
       auto walk_k = [&](auto rb32_t) {
@@ -1907,7 +2105,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
     __syncthreads();  // codes are dead from here: `sorted` may overwrite them; tstart is complete
     STAMP(3);
     // ---- place ------------------------------------------------------------------------------------
-    place_entries<NT, SPAN>(sorted, tstart, pr);
+    place_entries<NT, SPAN>(sorted, tstart, pr, P);
 #pragma unroll
     for (int r = 0; r < (int)(sizeof(gres) / 4); ++r)
       if (threadIdx.x + r * NT < P) gbase[threadIdx.x + r * NT] = gres[r] - tstart[threadIdx.x + r * NT];

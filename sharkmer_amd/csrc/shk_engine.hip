@@ -2073,7 +2073,7 @@ int shk_filter_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, 
     const uint64_t key = primer_kmers[j];
     if (2 * k < 64 && (key >> (2 * k)) != 0)
       return fail(c, SHK_ERR_BAD_ARG, "primer k-mer %llu does not fit %u bases", (unsigned long long)key, k);
-    for (uint64_t sl = mix_key(key, 2 * k) & (cap - 1);; sl = (sl + 1) & (cap - 1)) {
+    for (uint64_t sl = set_hash(key) & (cap - 1);; sl = (sl + 1) & (cap - 1)) {
       if (set[sl] == key) break;
       if (set[sl] == ~0ull) {
         set[sl] = key;

@@ -216,22 +216,15 @@ def test_shard_batches_cover_every_read_once():
 
 # ---- key-space-partitioned ingest (sharkmer_amd.dist.OwnerCounter) under gloo ----------------------------------
 
-MIX_M1, MIX_M2 = 0x9E3779B1, 0x85EBCA6B
-MIX_M1_INV, MIX_M2_INV = 0xCFA4A56B0E8B2F51, 0x000A7324A5CB9243  # shk_device.hip.h
+MIX_M32, MIX_M64 = 0xC2B2AE35, 0x9E3779B97F4A7C15  # shk_device.hip.h: mix_key
 
 
 def _mix(x, bits):
-    mask = (1 << bits) - 1
-    x = (x * MIX_M1) & mask
-    x ^= x >> ((bits + 1) >> 1)
-    return (x * MIX_M2) & mask
+    return (x * (MIX_M32 if bits <= 42 else MIX_M64)) & ((1 << bits) - 1)
 
 
 def _unmix(y, bits):
-    mask = (1 << bits) - 1
-    y = (y * MIX_M2_INV) & mask
-    y ^= y >> ((bits + 1) >> 1)
-    return (y * MIX_M1_INV) & mask
+    return (y * pow(MIX_M32 if bits <= 42 else MIX_M64, -1, 1 << 64)) & ((1 << bits) - 1)
 
 
 class _Layout:

@@ -24,18 +24,16 @@ pytestmark = pytest.mark.gpu
 
 
 def _owner_of(keys, k, W):
-    """Owner of canonical k-mers = top log2(W) bits of the engine's bijective key mix (shk_device.hip.h)."""
+    """Owner of canonical k-mers = top log2(W) bits of the engine's bijective key mix (shk_device.hip.h,
+    mix_key: one multiplication by an odd constant mod 2^2k)."""
     bits = 2 * k
-    mask = (1 << bits) - 1
-    M1, M2 = 0x9E3779B1, 0x85EBCA6B
-    out = np.empty(len(keys), dtype=np.int64)
     lw = W.bit_length() - 1
-    for i, x in enumerate(int(v) for v in keys):
-        y = (x * M1) & mask
-        y ^= y >> ((bits + 1) >> 1)
-        y = (y * M2) & mask
-        out[i] = (y >> (bits - lw)) if lw and bits >= lw else 0
-    return out
+    if not lw or bits < lw:
+        return np.zeros(len(keys), dtype=np.int64)
+    M = 0xC2B2AE35 if bits <= 42 else 0x9E3779B97F4A7C15
+    with np.errstate(over="ignore"):
+        y = (np.asarray(keys, dtype=np.uint64) * np.uint64(M)) & np.uint64((1 << bits) - 1)
+    return (y >> np.uint64(bits - lw)).astype(np.int64)
 
 
 def _shares_against_oracle(orc, bases, offsets, k, chunks, histo_max, W, flags=0, hint=0, splits=None):

@@ -2,16 +2,12 @@
 """Quality check of the table hash (shk::mix_key in sharkmer_amd/csrc/shk_device.hip.h): page
 occupancy spread and home-bucket overflow against a Poisson process, plus the bijection property,
 on random, AT-rich, tandem-repeat and sequential keys.  CPU only (numpy restatement of the device
-formula: multiply by an odd constant mod 2^2k, fold the upper half down, multiply again)."""
+formula: ONE multiplication by an odd constant mod 2^2k — a 32-bit constant up to 42 key bits, a 64-bit one beyond)."""
 import numpy as np
-M1=np.uint64(0x9E3779B1); M2=np.uint64(0x85EBCA6B)
+M32=np.uint64(0xC2B2AE35); M64=np.uint64(0x9E3779B97F4A7C15)
 def mix(x,bits):
     mask=np.uint64((1<<bits)-1)
-    s=np.uint64((bits+1)//2)
-    x=(x*M1)&mask
-    x^=x>>s
-    x=(x*M2)&mask
-    return x
+    return (x*(M32 if bits<=42 else M64))&mask
 def canon(codes,k):
     n=len(codes)-k+1
     f=np.zeros(n,dtype=np.uint64); r=np.zeros(n,dtype=np.uint64)
