@@ -1821,7 +1821,7 @@ __device__ __forceinline__ void place_entries(uint32_t *__restrict__ sorted, con
 #pragma unroll
   for (int i = 0; i < SPAN; ++i) {
     const uint32_t v = pr[i];  // partition << 16 | rank; partitions ≥ P are the walk's spare counters (no record)
-    if (v < (P << 16)) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = ((v >> 16) << 14) | (i * NT + threadIdx.x);  // → recs index
+    if (v < (P << 16)) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = ((v >> 16) << 18) | ((i * NT + threadIdx.x) << 2);  // partition · 2^18 | byte offset into recs
   }
 }
 
@@ -1864,13 +1864,13 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   const uint32_t log_parts = LOGP ? (uint32_t)LOGP : log_parts_;
   const uint32_t P = 1u << log_parts;
   uint2 *pg = reinterpret_cast<uint2 *>(sh);         // the stage's (packed word, N | read-start masks) per group, for the neighbours; dead once the walk starts
-  static_assert(SPAN == 16 && GROUPS == NT + 2, "a thread walks exactly the group it staged");
-  uint32_t *sorted = sh;                             // TT entries; aliases pg
-  uint32_t *recs = sh + TT;                          // TT records: thread t's i-th end position at i·NT + t
-  uint32_t *packed = recs + TT;                      // (GROUPS + 2 words, unused since the staged groups stay in registers)
-  uint32_t *cnt = packed + GROUPS + 2;               // P
+  static_assert(SPAN == 16 && GROUPS == NT + 2 && 2 * GROUPS <= TT, "a thread walks exactly the group it staged; the staged pairs fit the entries they alias");
+  uint32_t *sorted = sh;                             // TT + P entries (every partition's run starts at an EVEN entry: up to P holes); aliases pg
+  uint32_t *recs = sh + TT + P;                      // TT records: thread t's i-th end position at i·NT + t
+  uint32_t *cnt = recs + TT;                         // P
   uint32_t *tstart = cnt + P;                        // P
-  uint32_t *gbase = tstart + P;                      // P: (this tile's reservation) - tstart
+  uint32_t *gbase = cnt;                             // P: ((this tile's reservation) - tstart) · 4 — takes cnt's place once the runs are placed
+  __shared__ uint32_t n_ent_sh;                      // entries of this tile, holes included
   // (cnt[P..P+7] = tstart[0..7] double as the spare counters of the walk: tstart is written after it)
 #ifdef SHK_PHASE_TIMING
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2071,9 +2071,11 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
     STAMP(2);
     // ---- exclusive scan of the counts → tstart ---------------------------------------------------
     {
+      // (a run takes an even number of entries: the write phase works on aligned pairs, and a pair never
+      // straddles two partitions; an odd run's last pair ends in a hole)
       uint32_t lo = threadIdx.x * per, sacc = 0;
       if (lo < P)
-        for (uint32_t i = 0; i < per; ++i) sacc += cnt[lo + i];
+        for (uint32_t i = 0; i < per; ++i) sacc += (cnt[lo + i] + 1u) & ~1u;
       const uint32_t inc = wave_scan_incl(sacc);
       if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
       __syncthreads();
@@ -2086,7 +2088,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
       if (lo < P)
         for (uint32_t i = 0; i < per; ++i) {
           tstart[lo + i] = run;
-          run += cnt[lo + i];
+          run += (cnt[lo + i] + 1u) & ~1u;
         }
     }
     const uint32_t rbase = all_lanes ? lane * P : 0u;  // first region of this tile's lane
@@ -2107,15 +2109,24 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
     // ---- place ------------------------------------------------------------------------------------
     place_entries<NT, SPAN>(sorted, tstart, pr, P);
 #pragma unroll
-    for (int r = 0; r < (int)(sizeof(gres) / 4); ++r)
-      if (threadIdx.x + r * NT < P) gbase[threadIdx.x + r * NT] = gres[r] - tstart[threadIdx.x + r * NT];
+    for (int r = 0; r < (int)(sizeof(gres) / 4); ++r) {
+      const uint32_t i = threadIdx.x + r * NT;
+      if (i < P) {
+        const uint32_t ts = tstart[i], c1 = cnt[i];
+        gbase[i] = (gres[r] - ts) << 2;              // (overwrites cnt[i]: nobody else looks at it any more)
+        if (c1 & 1u) sorted[ts + c1] = 0xFFFFFFFFu;  // the hole behind an odd run
+        if (i == P - 1) n_ent_sh = ts + ((c1 + 1u) & ~1u);
+      }
+    }
     __syncthreads();
     STAMP(4);
-    // ---- write: two entries per lane ------------------------------------------------------------
+    // ---- write: one aligned PAIR of entries per lane and step, both of one partition -------------------
     {
-      const uint32_t n_rec = tstart[P - 1] + cnt[P - 1];
+      const uint32_t n_ent = n_ent_sh;  // entries, holes included (even)
       const uint2 *sorted2 = reinterpret_cast<const uint2 *>(sorted);
       char *const base = reinterpret_cast<char *>(part_buf32);
+      const char *const recs_b = reinterpret_cast<const char *>(recs);
+      const char *const gbase_b = reinterpret_cast<const char *>(gbase);
       auto spill_rec = [&](uint32_t pc, uint32_t rec) {  // the page's region is full (skewed input)
         const uint64_t km = unmix_key(((uint64_t)pc << rbits) | rec, 2 * k);
         const unsigned long long j = atomicAdd(OWN && sp.count ? sp.count : &stats->spill_count, 1ull);
@@ -2125,31 +2136,40 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
           sp.counts[j] = 1u;
         }
       };
-#pragma unroll 4
-      for (uint32_t i = threadIdx.x; 2 * i < n_rec; i += NT) {
+      // record index `at` inside partition pc's region → where it lives (block-interleaved regions; WIDE:
+      // the buffer accumulates the records of many launches and needs 64-bit offsets)
+      auto slot_ptr = [&](uint32_t pc, uint32_t at) -> uint32_t * {
+        if (OWN)  // segment of pc's owner, then the block-interleave among that owner's regions
+          return reinterpret_cast<uint32_t *>(base + (own_seg(pc) * own.seg_recs + rec_slot(own_grp(pc, lane), n_grp, at)) * 4u);
+        if (WIDE) return part_buf32 + rec_slot64(rbase + pc, n_regions, at);
+        return reinterpret_cast<uint32_t *>(base + rec_slot(rbase + pc, n_regions, at) * 4u);
+      };
+      const uint32_t cap4 = cap_p << 2;
+#pragma unroll 2
+      for (uint32_t i = threadIdx.x; 2 * i < n_ent; i += NT) {
         const uint2 ee = sorted2[i];
-        const bool two = 2 * i + 1 < n_rec;
-        const uint32_t pc0 = ee.x >> 14, pc1 = two ? ee.y >> 14 : pc0;
-        const uint32_t r0 = recs[ee.x & 0x3FFFu], r1 = two ? recs[ee.y & 0x3FFFu] : 0u;
-        const uint32_t at0 = gbase[pc0] + 2 * i;  // record index inside the page's region
-        // (a launch covers ≤ 2^28 k-mers: byte offsets into a per-launch buffer fit 32 bits; WIDE:
-        // the buffer accumulates the records of many launches and needs 64-bit offsets)
-        auto slot_ptr = [&](uint32_t pc, uint32_t at) -> uint32_t * {
-          if (OWN)  // segment of pc's owner, then the block-interleave among that owner's regions
-            return reinterpret_cast<uint32_t *>(base + (own_seg(pc) * own.seg_recs + rec_slot(own_grp(pc, lane), n_grp, at)) * 4u);
-          if (WIDE) return part_buf32 + rec_slot64(rbase + pc, n_regions, at);
-          return reinterpret_cast<uint32_t *>(base + rec_slot(rbase + pc, n_regions, at) * 4u);
-        };
-        if (two && pc1 == pc0 && at0 + 2 <= cap_p && (at0 & ((1u << RB_LOG) - 1u)) != (1u << RB_LOG) - 1u) {
-          const uint2 rec2 = make_uint2(r0, r1);  // (both records in one block)
-          __builtin_memcpy(slot_ptr(pc0, at0), &rec2, 8);
+        const uint32_t pcb = ee.x >> 16;  // partition · 4 (a byte offset into gbase)
+        const uint32_t r0 = *reinterpret_cast<const uint32_t *>(recs_b + (ee.x & 0xFFFCu));
+        const uint32_t r1 = *reinterpret_cast<const uint32_t *>(recs_b + (ee.y & 0xFFFCu));  // (a hole reads some record: unused)
+        const uint32_t at4 = *reinterpret_cast<const uint32_t *>(gbase_b + pcb) + 8u * i;  // record index inside the region, · 4
+        const bool hole = ee.y == 0xFFFFFFFFu;
+        const bool edge = (at4 & (((1u << RB_LOG) - 1u) << 2)) == (((1u << RB_LOG) - 1u) << 2);  // last record of a block
+        if (!hole && !edge && at4 + 8u <= cap4) {
+          const uint2 rec2 = make_uint2(r0, r1);  // (both records in one block: one 8-byte store)
+          if (!OWN && !WIDE && !ALL && LOGP) {
+            // 2^LOGP regions of one lane: byte offset = at·4 + (at >> 10)·(regions - 1)·4096 + region·4096
+            const uint32_t off = __umul24(at4 >> (RB_LOG + 2), (uint32_t)(((1u << LOGP) - 1u) << (RB_LOG + 2))) + at4 + (pcb << RB_LOG);
+            __builtin_memcpy(base + off, &rec2, 8);
+          } else {
+            __builtin_memcpy(slot_ptr(pcb >> 2, at4 >> 2), &rec2, 8);
+          }
         } else {
-          if (at0 < cap_p) *slot_ptr(pc0, at0) = r0;
-          else spill_rec(pc0, r0);
-          if (two) {
-            const uint32_t at1 = gbase[pc1] + 2 * i + 1;
-            if (at1 < cap_p) *slot_ptr(pc1, at1) = r1;
-            else spill_rec(pc1, r1);
+          const uint32_t pc = pcb >> 2, at0 = at4 >> 2;
+          if (at0 < cap_p) *slot_ptr(pc, at0) = r0;
+          else spill_rec(pc, r0);
+          if (!hole) {
+            if (at0 + 1 < cap_p) *slot_ptr(pc, at0 + 1) = r1;
+            else spill_rec(pc, r1);
           }
         }
       }

@@ -542,7 +542,7 @@ static bool use_rec32(const shk_ctx *c, const PartGeom &g) {
 constexpr int SC32_NT = 1024, SC32_TT = 16384;  // k_scatter32: 64 KiB of records + 64 KiB of entries in LDS,
 constexpr size_t SC32_LDS_MAX = 160 * 1024 - 1024;  // one workgroup per CU (its static LDS is < 1 KiB)
 static size_t scatter32_lds(uint32_t P1) {
-  return (size_t)SC32_TT * 8 + ((size_t)(SC32_TT + HALO) / 16 + 2) * 4 + (size_t)P1 * 12 + 32;  // (+ the walk's 8 spare counters when P1 < 8)
+  return (size_t)SC32_TT * 8 + (size_t)P1 * 12 + 32;  // entries (+ P1/2 holes at most) + records + three words per partition (+ the walk's 8 spare counters when P1 < 8)
 }
 // records-in-LDS scatter (k_scatter32: one 1024-thread workgroup per CU) when its LDS footprint fits
 static bool use_scatter32(const shk_ctx *c, const PartGeom &g) {
