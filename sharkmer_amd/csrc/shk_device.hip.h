@@ -1818,10 +1818,13 @@ __global__ void __launch_bounds__(NT, SORTED_WAVES_PER_SIMD) k_part_scatter_sort
 template <int NT, int SPAN>
 __device__ __forceinline__ void place_entries(uint32_t *__restrict__ sorted, const uint32_t *__restrict__ tstart,
                                               const uint32_t (&pr)[SPAN], uint32_t P) {
+  const char *const ts_b = reinterpret_cast<const char *>(tstart);
 #pragma unroll
   for (int i = 0; i < SPAN; ++i) {
-    const uint32_t v = pr[i];  // partition << 16 | rank; partitions ≥ P are the walk's spare counters (no record)
-    if (v < (P << 16)) sorted[tstart[v >> 16] + (v & 0xFFFFu)] = ((v >> 16) << 18) | ((i * NT + threadIdx.x) << 2);  // partition · 2^18 | byte offset into recs
+    const uint32_t v = pr[i];  // partition · 2^18 | rank; partitions ≥ P are the walk's spare counters (no record)
+    // (v >> 16 = partition · 4: tstart's byte offset; the entry keeps the partition field and gets the record's byte offset)
+    if (v < (P << 18))
+      sorted[*reinterpret_cast<const uint32_t *>(ts_b + (v >> 16)) + (v & 0x3FFFFu)] = (v & 0xFFFC0000u) | ((i * NT + threadIdx.x) << 2);
   }
 }
 
@@ -1979,18 +1982,11 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
       const uint32_t spare_pc = P + (threadIdx.x & 7u);
       (void)jend;
       (void)jemit;
-      const uint32_t npw = ~pw;
       const uint32_t rbits_c = RB32 ? 32u : rbits;
-#ifdef SHK_EXP_GENERIC_WALK
-      if (false) {
-#else
-      if (KC >= 17) {  // this copy keeps BOTH frames left-aligned
-#endif
-        const uint64_t ff = (((uint64_t)x.f_hi << 32) | x.f_lo) << (64 - 2 * (KC ? KC : 1));
-        x.f_lo = (uint32_t)ff;
-        x.f_hi = (uint32_t)(ff >> 32);
-      }
-      (void)npw;
+      // the window copies (KC ≥ 17): the 48 bases in sight and their reverse complement, as packed words
+      const uint32_t w0 = gA.x, w1 = gB.x, w2 = pw;
+      const uint32_t rw0 = rev2(~w2), rw1 = rev2(~w1), rw2 = rev2(~w0);
+      (void)w0, (void)w1, (void)w2, (void)rw0, (void)rw1, (void)rw2;
       (void)rbits_c;
 #pragma unroll
       for (int q = 0; q < SPAN / 8; ++q) {
@@ -2010,30 +2006,45 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
 #else
           if (KC >= 17) {
 #endif
-            // Hand-shaped for instruction COUNT (every integer VALU op of this loop, 64-bit shifts, compares
-            // and v_mad_u64_u32 included, issues at the same 4 cycles per wave on gfx950 — tools/ibench2.hip —
-            // and the kernel is 70 % VALU-busy): BOTH frames are LEFT-aligned in 64 bits here, so shifting
-            // needs no mask on the way out (the forward frame sheds its oldest base off the top, its low
-            // 64-2k bits stay zero; the reverse frame sheds off the bottom into bits that are cleared once,
-            // after the select), min(fwd, rev) is one 64-bit compare on the frames as they are, and the
-            // product by the 32-bit multiplier one v_mul_lo_u32 + one v_mad_u64_u32 (mod 2^64 on a
-            // left-aligned key IS mod 2^2k on the key).
-            constexpr uint32_t LS = 64u - 2u * (KC ? KC : 1);      // left shift of a frame (22 at k = 21)
-            constexpr int BSH = 30 - 2 * 8 * 0;                    // (see bsh below)
-            (void)BSH;
-            const int bpos = 30 - 2 * (q * 8 + r);                 // where this step's base sits in pw
-            // the base at bits [LS, LS+2) of a word, and the complement base at bits [0, 2): one shift each
-            const uint32_t bL = (bpos >= (int)LS ? pw >> ((bpos - (int)LS) & 31) : pw << (((int)LS - bpos) & 31)) & (3u << (LS & 31));
-            const uint32_t nb = npw >> bpos;
-            x.f_hi = __builtin_amdgcn_alignbit(x.f_hi, x.f_lo, 30);
-            x.f_lo = (x.f_lo << 2) | bL;
-            x.r_lo = __builtin_amdgcn_alignbit(x.r_hi, x.r_lo, 2);
-            x.r_hi = __builtin_amdgcn_alignbit(nb, x.r_hi, 2);   // (only nb's low two bits enter)
-            const uint64_t fL = ((uint64_t)x.f_hi << 32) | x.f_lo, rL = ((uint64_t)x.r_hi << 32) | x.r_lo;
-            // (k odd: a k-mer is never its own reverse complement, so the bits below LS of the reverse frame
-            // — bases that have left the window — cannot decide the compare; k even: a tie is a palindrome and
-            // both arms are the same k-mer)
-            const uint64_t cL = (rL < fL ? rL : fL) & ~((1ull << LS) - 1ull);
+            // Hand-shaped for instruction COUNT (every integer VALU op of this loop — 64-bit shifts, compares
+            // and v_mad_u64_u32 included — issues at the same 4 cycles per wave on gfx950, tools/ibench2.hip,
+            // and the kernel is 70 % VALU-busy).  No rolling state at all: the 48 bases this thread can see
+            // — the two groups before its own and its own, three packed words, first base on top — hold
+            // every k-mer it emits as a WINDOW, and so do the three words of their reverse complement
+            // (rw0..rw2, built once per tile).  A frame LEFT-aligned in 64 bits is two funnel shifts by
+            // compile-time counts; the bits below the k-mer are neighbouring bases, cleared once, after the
+            // select: min(fwd, rev) is one 64-bit compare on the frames as they are (k odd: a k-mer is never
+            // its own reverse complement, so those bits cannot decide it; k even: a tie is a palindrome and
+            // both arms are the same k-mer).  The product by the 32-bit multiplier is one v_mul_lo_u32 + one
+            // v_mad_u64_u32: mod 2^64 on a left-aligned key IS mod 2^2k on the key.
+            constexpr int KK = KC ? KC : 1;
+            constexpr uint32_t LS = 64u - 2u * KK;                 // left shift of a frame (22 at k = 21)
+            constexpr int j = 0;
+            (void)j;
+            const int e = q * 8 + r;                               // this step's end position in my group (compile-time: unrolled)
+            const int of = 2 * (32 + e - KK + 1);                  // bit offset of the forward window in w0:w1:w2
+            const int orv = 2 * (15 - e);                          // … of the reverse-complement window in rw0:rw1:rw2
+            uint32_t f_hi, f_lo, r_hi, r_lo;
+            if (of < 32) {
+              f_hi = of ? __builtin_amdgcn_alignbit(w0, w1, (32 - of) & 31) : w0;
+              f_lo = of ? __builtin_amdgcn_alignbit(w1, w2, (32 - of) & 31) : w1;
+            } else {
+              f_hi = of > 32 ? __builtin_amdgcn_alignbit(w1, w2, (64 - of) & 31) : w1;
+              f_lo = of > 32 ? w2 << ((of - 32) & 31) : w2;
+            }
+            r_hi = orv ? __builtin_amdgcn_alignbit(rw0, rw1, (32 - orv) & 31) : rw0;
+            r_lo = orv ? __builtin_amdgcn_alignbit(rw1, rw2, (32 - orv) & 31) : rw1;
+            // min(fwd, rev) on the 32-bit halves: the borrow of rev - fwd (two carry-chained subtracts) selects —
+            // a 64-bit compare wants its operands in register PAIRS, which costs two or three v_mov per k-mer
+            uint32_t c_hi, c_lo, scratch;
+            asm("v_sub_co_u32 %2, vcc, %5, %3\n\t"
+                "v_subb_co_u32 %2, vcc, %6, %4, vcc\n\t"
+                "v_cndmask_b32 %0, %3, %5, vcc\n\t"
+                "v_cndmask_b32 %1, %4, %6, vcc"
+                : "=&v"(c_lo), "=&v"(c_hi), "=&v"(scratch)
+                : "v"(f_lo), "v"(f_hi), "v"(r_lo), "v"(r_hi)
+                : "vcc");
+            const uint64_t cL = (((uint64_t)c_hi << 32) | c_lo) & ~((1ull << LS) - 1ull);
             const uint64_t yL = (uint64_t)(uint32_t)cL * (uint32_t)MIX_M32 + ((uint64_t)((uint32_t)(cL >> 32) * (uint32_t)MIX_M32) << 32);
             y = yL >> LS;                                          // (the record below takes its low 32 bits)
             page = (uint32_t)(yL >> ((LS + rbits_c) & 63));
@@ -2046,14 +2057,15 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
           }
           // emit mask as arithmetic (all ones / zero) and a bit-select instead of ?: — the compiler turns a
           // select whose one arm is expensive into an exec-mask branch around that arm, per k-mer
-          uint32_t em = 0u - ((okw >> (q * 8 + r)) & 1u);
+          uint32_t em;
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(em) : "v"(okw), "n"(q * 8 + r));  // all ones where a k-mer ends here
           if (OWN) em &= 0u - (uint32_t)((((page >> log_p1w) ^ own.keep) & keep_mask) == 0u);  // a foreign owner's record: dropped
-          pcs[r] = (page & em) | (spare_pc & ~em);
+          asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(pcs[r]) : "v"(em), "v"(page), "v"(spare_pc));  // (em & page) | (~em & spare)
           recs[(q * 8 + r) * NT + threadIdx.x] = RB32 ? (uint32_t)y : (uint32_t)y & rmask;  // transposed: no bank conflicts
           rks[r] = atomicAdd(&cnt[pcs[r]], 1u);  // rank < 2^14
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pr[q * 8 + r] = (pcs[r] << 16) | rks[r];  // (a spare counter, ≥ P: no record — place_entries looks)
+        for (int r = 0; r < 8; ++r) pr[q * 8 + r] = (pcs[r] << 18) | rks[r];  // partition · 2^18 | rank (a spare counter, ≥ P: no record — place_entries looks)
       }
       };
       auto walk_k = [&](auto rb32_t) {
