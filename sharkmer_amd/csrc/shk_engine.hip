@@ -23,7 +23,7 @@ struct shk_ctx;
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed);
 static int prepare_cursors(shk_ctx *c, bool multi, bool defer, uint32_t *n_words);
 static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t lane_add_exact = 0);
-static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub);
+static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub, bool multi);
 static int settle(shk_ctx *c);
 static int settle_light(shk_ctx *c);
 static int flush_acc(shk_ctx *c);
@@ -346,6 +346,19 @@ int drain_spill(shk_ctx *c, uint64_t spill_cap) {
       return fail(c, SHK_ERR_INVARIANT, "spill list overflow (%llu > %llu)", (unsigned long long)n,
                   (unsigned long long)spill_cap);
     c->n_spilled += n;
+    if (env_int("SHK_DEBUG_SPILL", 0)) {  // experiment hook: show what spilled
+      const uint64_t m = std::min<uint64_t>(n, 48);
+      std::vector<uint64_t> hk(m);
+      std::vector<uint32_t> hl(m);
+      SpillRef in0 = spill_ref(*cur, spill_cap);
+      (void)hipMemcpy(hk.data(), in0.keys, m * 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hl.data(), in0.lanes, m * 4, hipMemcpyDeviceToHost);
+      for (uint64_t i = 0; i < m; ++i) {
+        const uint64_t y = mix_key(hk[i], 2 * c->cfg.k);
+        fprintf(stderr, "[spill %llu/%llu] key %011llx lane %u page %llu rec %08llx\n", (unsigned long long)i, (unsigned long long)n,
+                (unsigned long long)hk[i], hl[i], (unsigned long long)(y >> (2 * c->cfg.k - c->tb.log_pages)), (unsigned long long)(y & 0xFFFFFFFFull));
+      }
+    }
     uint32_t lp = log_pages_for((c->h_stats->n_distinct + n) * 2, c->owner_bits);
     if (round > 0) {
       if (c->tb.log_pages + c->owner_bits >= MAX_LOG_PAGES)
@@ -434,9 +447,9 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     if (rc != SHK_OK) return rc;
   } else {
     const uint64_t first_kmers_ub = std::min(tiles_per_sub, n_tiles_ub) * TILE_T;
-    const bool defer = first_launch_defers(c, first_kmers_ub);
+    const bool defer = first_launch_defers(c, first_kmers_ub, striped && n_blocks > 1);
     int rc = defer ? acc_prepare(c, acc_records_est(c, first_kmers_ub), striped && n_blocks > 1 ? -1 : (int64_t)(lane_fixed >= 0 ? (uint64_t)lane_fixed : (striped ? (g0 / 1000) % NL : 0))) : (c->acc_active ? settle(c) : SHK_OK);  // (may flush: launch + settle)
-    if (rc == SHK_OK) rc = prepare_cursors(c, striped && n_blocks > 1, defer && first_launch_defers(c, first_kmers_ub), &n_cursor_words);
+    if (rc == SHK_OK) rc = prepare_cursors(c, striped && n_blocks > 1, defer && first_launch_defers(c, first_kmers_ub, striped && n_blocks > 1), &n_cursor_words);
     if (rc != SHK_OK) return rc;
   }
   {
@@ -582,8 +595,16 @@ static bool xl_route(const shk_ctx *c, const PartGeom &g, bool multi, bool defer
 enum CountPath { PATH_DIRECT, PATH_PAGED, PATH_DEFER };
 static bool paged_feasible(const shk_ctx *c);
 static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub);
-static CountPath count_path(const shk_ctx *c, uint64_t sub_kmers_ub) {
+static CountPath count_path(const shk_ctx *c, uint64_t sub_kmers_ub, bool multi = false) {
   if (!paged_feasible(c) || (c->cfg.flags & SHK_FLAG_FORCE_DIRECT)) return PATH_DIRECT;
+  // a batch over several chunk lanes into a two-level table: the owner-layout route (ONE level-1 pass, ONE
+  // level-2 pass, ONE page launch that keeps a page's tags in LDS for all its lanes) instead of a scatter,
+  // a re-scatter and a page pass per lane, each re-reading the keys — also when the batch is large enough
+  // to be counted at once (the records just wait for the page pass that finalize, or the budget, asks for)
+  if (multi && c->n_lanes > 1 && !c->owner_bits && env_int("SHK_XL", 1) != 0 && env_int("SHK_DEFER", 1) != 0) {
+    const PartGeom g2 = part_geom(c);
+    if (g2.two_level && xl_feasible(c, g2)) return PATH_DEFER;
+  }
   if (c->owner_bits)  // an owner share: the owner layout + deferred page passes, or global atomics (both drop foreign k-mers)
     return xl_feasible(c, part_geom(c)) && env_int("SHK_DEFER", 1) != 0 ? PATH_DEFER : PATH_DIRECT;
   if ((c->cfg.flags & SHK_FLAG_FORCE_PAGED) || paged_pays(c, sub_kmers_ub)) return PATH_PAGED;
@@ -690,7 +711,7 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
   return SHK_OK;
 }
 
-static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub) { return count_path(c, kmers_ub) == PATH_DEFER; }
+static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub, bool multi) { return count_path(c, kmers_ub, multi) == PATH_DEFER; }
 
 // Bytes of the per-launch cursor buffer (part_meta).  One size for everybody who asks: the buffer
 // must not be reallocated between k_mark_starts (which clears cursors in it) and the partition launch.
@@ -1118,11 +1139,11 @@ static uint64_t acc_records_est(const shk_ctx *c, uint64_t kmers_ub) {
 }
 
 static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, bool prezeroed) {
-  CountPath path = count_path(c, sub_kmers_ub);
+  CountPath path = count_path(c, sub_kmers_ub, b.tiles != nullptr);
   if (path == PATH_DEFER) {  // (the first launch of an ingest was planned before k_mark_starts)
     int rc = acc_prepare(c, acc_records_est(c, sub_kmers_ub), b.tiles ? -1 : (int64_t)b.lane0);
     if (rc != SHK_OK) return rc;
-    path = count_path(c, sub_kmers_ub);  // a flush may have grown the table
+    path = count_path(c, sub_kmers_ub, b.tiles != nullptr);  // a flush may have grown the table
     if (path == PATH_DEFER && !c->acc_cur.p) return fail(c, SHK_ERR_INVARIANT, "accumulation regions missing");
   }
   if (path != PATH_DEFER && c->acc_active) {  // the other paths work on the table itself
