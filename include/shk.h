@@ -260,6 +260,12 @@ int shk_owner_counts(shk_ctx *ctx, uint32_t n_owners, uint64_t *counts);
 int shk_compact_owners(shk_ctx *ctx, uint32_t n_owners, const uint64_t *seg_offsets, void *d_keys, void *d_vals,
                        uint64_t vals_lane_stride, int32_t skip_owner);
 int shk_merge_entries(shk_ctx *ctx, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride);
+/* shk_compact_owners with every owner's entries as ONE self-contained piece of d_buf — at byte offset
+ * (Σ_{o'<o} counts[o'])·(8 + 4·n_lanes): [k-mers 8·c][lane 0 counts 4·c] … [lane L−1 counts], c = counts[o]
+ * (from shk_owner_counts; counts[skip_owner] must be 0) — so that k-mers and all lanes' counts cross the links
+ * in one all-to-all.  A received piece goes to shk_merge_entries(piece, piece + 8·c, c, c).  Asynchronous on
+ * the context's stream (shk_stream). */
+int shk_compact_owners_packed(shk_ctx *ctx, uint32_t n_owners, const uint64_t *counts, void *d_buf, int32_t skip_owner);
 /* Restrict finalize's histogram scan to pages [p0,p1) (owner shard). */
 int shk_set_owned_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1);
 

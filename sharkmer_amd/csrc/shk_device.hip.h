@@ -1320,7 +1320,8 @@ __global__ void __launch_bounds__(WG) k_compact_owners(TableRef tb, uint64_t spo
                                                        unsigned long long *__restrict__ seg_cursor,
                                                        uint64_t *__restrict__ out_keys,
                                                        uint32_t *__restrict__ out_vals, uint64_t lane_stride,
-                                                       uint32_t skip_owner, uint32_t OWNER_BLOCKS) {
+                                                       uint32_t skip_owner, uint32_t OWNER_BLOCKS,
+                                                       const unsigned long long *__restrict__ packed) {
   __shared__ uint32_t red[WG / 64];
   __shared__ uint32_t wbase[WG / 64];
   __shared__ unsigned long long blk_base;
@@ -1349,8 +1350,19 @@ __global__ void __launch_bounds__(WG) k_compact_owners(TableRef tb, uint64_t spo
     }
     if (key != EMPTY) {
       const unsigned long long i = at + off + __popcll(mm & ((1ull << lane_id) - 1ull));
-      out_keys[i] = key;
-      for (uint32_t l = 0; l < tb.n_lanes; ++l) out_vals[(uint64_t)l * lane_stride + i] = tb.vals[(uint64_t)l * tb.cap + s];
+      if (packed) {
+        // PACKED: owner o's entries are one self-contained piece — [keys 8·c][lane 0 counts 4·c]…[lane L-1] at
+        // byte offset seg_offset[o]·(8 + 4L), c = packed[o] — so keys and every lane's counts cross the
+        // links in ONE collective; i counts from seg_offset[o]
+        const unsigned long long so = seg_offset[o], c_o = packed[o], j = i - so;
+        char *const seg = reinterpret_cast<char *>(out_keys) + so * (8ull + 4ull * tb.n_lanes);
+        __builtin_memcpy(seg + j * 8ull, &key, 8);  // (4-byte aligned when L and the offset are odd)
+        for (uint32_t l = 0; l < tb.n_lanes; ++l)
+          *reinterpret_cast<uint32_t *>(seg + c_o * 8ull + ((unsigned long long)l * c_o + j) * 4ull) = tb.vals[(uint64_t)l * tb.cap + s];
+      } else {
+        out_keys[i] = key;
+        for (uint32_t l = 0; l < tb.n_lanes; ++l) out_vals[(uint64_t)l * lane_stride + i] = tb.vals[(uint64_t)l * tb.cap + s];
+      }
     }
     at += chunk;
     __syncthreads();

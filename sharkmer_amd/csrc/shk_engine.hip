@@ -2286,9 +2286,40 @@ int shk_compact_owners(shk_ctx *c, uint32_t n_owners, const uint64_t *seg_offset
   const uint32_t bpo = std::min<uint32_t>(1024, std::max<uint32_t>(16, 2048 / n_owners));  // blocks per owner
   hipLaunchKernelGGL(k_compact_owners, dim3(n_owners * bpo), dim3(WG), 0, c->stream, c->tb,
                      c->tb.cap / n_owners, (const unsigned long long *)doff, dcur, (uint64_t *)d_keys,
-                     (uint32_t *)d_vals, vals_lane_stride, skip_owner < 0 ? ~0u : (uint32_t)skip_owner, bpo);
+                     (uint32_t *)d_vals, vals_lane_stride, skip_owner < 0 ? ~0u : (uint32_t)skip_owner, bpo,
+                     (const unsigned long long *)nullptr);
   HIPC(c, hipStreamSynchronize(c->stream));  // the caller hands the buffers to a collective next
   return SHK_OK;
+}
+
+int shk_compact_owners_packed(shk_ctx *c, uint32_t n_owners, const uint64_t *counts, void *d_buf, int32_t skip_owner) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  if (!c || !counts || n_owners == 0) return SHK_ERR_BAD_ARG;
+  const uint64_t n_pages = 1ull << c->tb.log_pages;
+  if (n_pages % n_owners) return fail(c, SHK_ERR_BAD_ARG, "%llu pages do not split over %u owners",
+                                      (unsigned long long)n_pages, n_owners);
+  HIPC(c, hipSetDevice(c->cfg.device));
+  // device: [seg offsets (entries) × W][cursors × W][counts × W], staged through pinned memory
+  HIPC(c, c->misc.ensure((size_t)n_owners * 24));
+  HIPC(c, c->h_rebased[0].ensure((size_t)n_owners * 16));
+  unsigned long long *h = (unsigned long long *)c->h_rebased[0].p;
+  unsigned long long run = 0;
+  for (uint32_t o = 0; o < n_owners; ++o) {
+    h[o] = run;
+    h[n_owners + o] = counts[o];
+    run += counts[o];
+  }
+  unsigned long long *doff = (unsigned long long *)c->misc.p, *dcur = doff + n_owners, *dcnt = dcur + n_owners;
+  HIPC(c, hipMemcpyAsync(doff, h, (size_t)n_owners * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(dcnt, h + n_owners, (size_t)n_owners * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemsetAsync(dcur, 0, (size_t)n_owners * 8, c->stream));
+  const uint32_t bpo = std::min<uint32_t>(1024, std::max<uint32_t>(16, 2048 / n_owners));  // blocks per owner
+  hipLaunchKernelGGL(k_compact_owners, dim3(n_owners * bpo), dim3(WG), 0, c->stream, c->tb,
+                     c->tb.cap / n_owners, (const unsigned long long *)doff, dcur, (uint64_t *)d_buf,
+                     (uint32_t *)nullptr, 0ull, skip_owner < 0 ? ~0u : (uint32_t)skip_owner, bpo,
+                     (const unsigned long long *)dcnt);
+  HIPC(c, hipGetLastError());
+  return SHK_OK;  // (asynchronous on the context's stream: run the collective on shk_stream())
 }
 
 int shk_merge_entries(shk_ctx *c, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride) {
@@ -2310,9 +2341,11 @@ int shk_merge_entries(shk_ctx *c, const void *d_keys, const void *d_vals, uint64
     hipLaunchKernelGGL(k_merge, dim3(grid_for(n, WG, 8192)), dim3(WG), 0, c->stream, c->tb, n, vals_lane_stride,
                        (const uint64_t *)d_keys, (const uint32_t *)d_vals, c->d_stats, sp);
   }
-  int rc = read_stats(c);
-  if (rc != SHK_OK) return rc;
-  return drain_spill(c, n * c->n_lanes);
+  // (nothing is waited for: the outcome — spilled entries, load factor — is looked at by the next call that
+  // needs the table, at the latest finalize)
+  c->unsettled = true;
+  c->unsettled_spill_cap = n * c->n_lanes;
+  return SHK_OK;
 }
 
 int shk_set_owned_pages(shk_ctx *c, uint64_t p0, uint64_t p1) {

@@ -265,6 +265,22 @@ class DistCounter:
             assert n_pages == P, (n_pages, P)
         recv = [int(x) for x in got[:, 1]]                              # what every peer holds of MY range
         send = [int(x) for x in counts]
+        if hasattr(self.eng, "compact_owner_packed") and self.device is not None:
+            # k-mers and ALL lanes' counts of a peer in ONE collective: every owner's entries are one
+            # self-contained piece [k-mers][lane 0]…[lane L-1]; compaction, the all_to_all and the merges are
+            # queued on the engine's own HIP stream (no host-side synchronisation in between)
+            ext = torch.cuda.ExternalStream(self.eng.stream(), device=f"cuda:{self.device}")
+            with torch.cuda.stream(ext):
+                buf, L = self.eng.compact_owner_packed(counts, self.rank)
+                w = 2 + L
+                rbuf = torch.empty(max(sum(recv) * w, 1), dtype=torch.int32, device=buf.device)[:sum(recv) * w]
+                dist.all_to_all_single(rbuf, buf, output_split_sizes=[r * w for r in recv], input_split_sizes=[x * w for x in send])
+                at = 0
+                for src in range(W):
+                    self.eng.merge_packed_piece(rbuf[at:at + recv[src] * w], recv[src], L)
+                    at += recv[src] * w
+                self._keep = (buf, rbuf)  # (alive until the stream has passed the merges: the next sync is finalize's)
+            return self._own(P)
         keys, vals = self.eng.compact_owner_tensors(counts, self.rank)  # [sum(send)], [L, sum(send)]
         n_recv = sum(recv)
         rk = keys.new_empty(n_recv)

@@ -107,7 +107,7 @@ ABI_SYMBOLS = [
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
     "shk_run_error", "shk_run_files",
     "shk_xchg_scatter_device", "shk_xchg_absorb", "shk_xchg_spill", "shk_xchg_spill_clear", "shk_insert_device",
-    "shk_stream",
+    "shk_stream", "shk_compact_owners_packed",
 ]
 
 _lib = None
@@ -175,6 +175,7 @@ def load_library():
     L.shk_owner_counts.argtypes = [vp, u32, vp]
     L.shk_compact_owners.argtypes = [vp, u32, vp, vp, vp, u64, C.c_int32]
     L.shk_merge_entries.argtypes = [vp, vp, vp, u64, u64]
+    L.shk_compact_owners_packed.argtypes = [vp, u32, vp, vp, C.c_int32]
     L.shk_table_geometry.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
     L.shk_table_reserve_pages.argtypes = [vp, u64]
     L.shk_table_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -513,6 +514,25 @@ class KmerEngine:
         self._check(self._L.shk_compact_owners(self._h, len(counts), off.ctypes.data, keys.data_ptr(),
                                                vals.data_ptr(), vals.stride(0), skip_owner))
         return keys[:n], vals[:, :n]
+
+    def compact_owner_packed(self, counts, skip_owner: int = -1):
+        """Every owner's occupied entries as one self-contained piece of ONE int32 CUDA tensor (include/shk.h,
+        shk_compact_owners_packed): piece o = [k-mers 2·c ints][lane 0 counts c ints]…, c = counts[o].
+        Queued on the engine's stream."""
+        import torch
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        _, _, n_lanes = self.table_geometry()
+        n = int(counts.sum())
+        buf = torch.empty(max(n * (2 + n_lanes), 1), dtype=torch.int32, device="cuda")
+        self._check(self._L.shk_compact_owners_packed(self._h, len(counts), counts.ctypes.data, buf.data_ptr(), skip_owner))
+        return buf[:n * (2 + n_lanes)], n_lanes
+
+    def merge_packed_piece(self, piece_t, c: int, n_lanes: int):
+        """KmerCounts::extend of one received piece (c entries: k-mers, then each lane's counts)."""
+        if c:
+            assert piece_t.is_contiguous() and piece_t.numel() == c * (2 + n_lanes)
+            p = piece_t.data_ptr()
+            self._check(self._L.shk_merge_entries(self._h, p, p + 8 * c, c, c))
 
     def merge_entry_tensors(self, keys_t, vals_t):
         """KmerCounts::extend of received entries (keys_t int64[n], vals_t int32[n_lanes, n], unit stride)."""
