@@ -8,6 +8,13 @@ shard of reads (weak scaling: per-GPU work fixed); the per-rank tables are excha
 page range over RCCL (all_to_all), merged, scanned, and the histograms all-reduced, so the
 emitted histogram is that of the union of all reads.
 
+Before the W warm-up steps an untimed RAMP of steps (≈0.25 s of device work) lets the card reach its
+steady clocks — the first ≈20 ms after idling run ≈4 % slower; `ramp_steps` is reported.  The timed region
+is exactly K steps.  After it, outside the timed region and at N = 1 only, `extras` puts the other timing
+points of SURVEY.md §8d on record: pinned host buffers → histogram (ii), FASTQ file → histogram (iii),
+BASELINE configs[2] (k = 31, 100 M reads) from HBM and streamed from pinned host memory, and the
+chunk-lane / large-table shapes.  --no-extras skips them.
+
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events
 on the engine's own stream inside libshk (SHK_FLAG_TIMING); `cpu_baseline` times the CPU
 oracle (a single-threaded C restatement of the reference algorithm — "port") on the same
@@ -68,6 +75,189 @@ def cpu_all_cores(orc, hb, ho, k, histo_max, n_bases):
                       f"({n_unique} distinct k-mers)"}
 
 
+def _timings_ms(eng, reps):
+    return {k_: round(v[0] / reps, 4) for k_, v in eng.timings().items()}
+
+
+def extras(sa, torch, dev):
+    """The other timing points (SURVEY.md §8d ii / iii, BASELINE configs[2], chunk lanes, large tables), each
+    OUTSIDE the headline's timed region; wall clock around whole jobs, best of a few repetitions, inputs
+    generated on the device (untimed).  A failure in one of them is recorded, never raised."""
+    import tempfile
+    out = {}
+    L = 150
+
+    def device_reads(eng, spec, first, n):
+        db = torch.empty(n * L, dtype=torch.uint8, device=f"cuda:{dev}")
+        do = torch.empty(n + 1, dtype=torch.int64, device=f"cuda:{dev}")
+        eng.synth_reads_device(spec, first, n, db.data_ptr(), do.data_ptr())
+        eng.sync()
+        return db, do
+
+    def guarded(name, fn):
+        try:
+            t0 = time.perf_counter()
+            out[name] = fn()
+            out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    # ---- (ii) pinned host buffers → histogram: config-2 reads in batches of 4 M, PCIe inclusive --------
+    def host_pinned():
+        n = 4_000_000
+        spec = sa.SynthSpec(genome_len=3_000_000, read_len=L)
+        res = {"workload": f"{n} reads x {L} bp (config 2's genome) handed over as HOST buffers: shk_ingest_reads + finalize"}
+        with sa.KmerEngine(21, 1, 10000, device=dev, capacity_hint=3_000_000) as eng:
+            db, do = device_reads(eng, spec, 0, n)
+            hb = torch.empty(n * L, dtype=torch.uint8, pin_memory=True)
+            hb.copy_(db)
+            ho = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+            del db, do
+            for kind, arr in (("pinned", hb.numpy()), ("pageable", hb.numpy().copy())):
+                eng.reset()
+                eng.ingest_reads(arr, ho)
+                eng.finalize()
+                best = None
+                for _ in range(3):
+                    eng.reset()
+                    t0 = time.perf_counter()
+                    eng.ingest_reads(arr, ho)
+                    eng.finalize()
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None else min(best, dt)
+                res[kind] = {"Gbases_per_s": round(n * L / best / 1e9, 2), "bound": "PCIe H2D, 1 B/base ASCII",
+                             "pcie_GB_per_s": round(n * L / best / 1e9, 2)}
+            if hasattr(eng, "ingest_packed"):
+                pk = sa.pack_reads(hb.numpy(), ho)
+                eng.reset()
+                eng.ingest_packed(pk)
+                eng.finalize()
+                best = None
+                for _ in range(3):
+                    eng.reset()
+                    t0 = time.perf_counter()
+                    eng.ingest_packed(pk)
+                    eng.finalize()
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None else min(best, dt)
+                res["pinned_packed"] = {"Gbases_per_s": round(n * L / best / 1e9, 2),
+                                        "bound": "2-bit packed stream + masks (shk_pack_reads, untimed), 0.28 B/base over PCIe",
+                                        "pcie_GB_per_s": round(pk.nbytes / best / 1e9, 2)}
+        return res
+    guarded("host_pinned", host_pinned)
+
+    # ---- (iii) FASTQ(.gz) file → histogram + output files (shk_run_files), host parse inclusive --------
+    def file_path():
+        import gzip
+        n = 2_000_000
+        spec = sa.SynthSpec(genome_len=3_000_000, read_len=L)
+        with sa.KmerEngine(21, 1, 10000, device=dev, capacity_hint=3_000_000) as eng:
+            db, _ = device_reads(eng, spec, 0, n)
+            bases = db.cpu().numpy()
+        tmp = tempfile.mkdtemp(prefix="shk_bench_")
+        rec = np.empty((n, 2 * L + 7), dtype=np.uint8)  # "@r\n" + seq + "\n+\n" + qual + "\n"
+        rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+        rec[:, 3:3 + L] = bases.reshape(n, L)
+        rec[:, 3 + L:6 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, 6 + L:6 + 2 * L] = ord("I")
+        rec[:, 6 + 2 * L] = ord("\n")
+        plain = os.path.join(tmp, "reads.fastq")
+        rec.tofile(plain)
+        half = n // 2 * (2 * L + 7)
+        parts = []
+        for i, (a, b) in enumerate(((0, half), (half, n * (2 * L + 7)))):  # two gzip members files: the multi-file case
+            pth = os.path.join(tmp, f"part{i}.fastq.gz")
+            with gzip.open(pth, "wb", compresslevel=1) as g:
+                g.write(rec.reshape(-1)[a:b].tobytes())
+            parts.append(pth)
+        res = {"workload": f"{n} reads x {L} bp as FASTQ on local disk → shk_run_files (parse + count + .histo/.stats.yaml)"}
+        for name, paths in (("plain", [plain]), ("gzip_2_files", parts)):
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                sa.run_files(paths, k=21, chunks=1, histo_max=10000, sample="s", outdir=tmp, capacity_hint=3_000_000)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            res[name] = {"Gbases_per_s": round(n * L / best / 1e9, 3), "file_MB": round(sum(os.path.getsize(p_) for p_ in paths) / 1e6, 1),
+                         "bound": "host: read + inflate + line split"}
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+        return res
+    guarded("file_path", file_path)
+
+    # ---- BASELINE configs[2]: 100 M reads, k = 31, a 300 Mb genome; from HBM, and streamed from pinned host memory
+    def config3():
+        n, k, batch = 100_000_000, 31, 4_000_000
+        spec = sa.SynthSpec(genome_len=300_000_000, read_len=L)
+        res = {"workload": f"BASELINE.json configs[2]: {n} synthetic {L}bp reads, k={k}, 300 Mb genome (2^30-slot table), batches of {batch} reads"}
+        with sa.KmerEngine(k, 1, 10000, device=dev, capacity_hint=300_000_000, flags=sa.FLAG_TIMING) as eng:
+            d_all = torch.empty(n * L, dtype=torch.uint8, device=f"cuda:{dev}")
+            d_off = torch.empty(batch + 1, dtype=torch.int64, device=f"cuda:{dev}")
+            for b in range(n // batch):
+                eng.synth_reads_device(spec, b * batch, batch, d_all.data_ptr() + b * batch * L, d_off.data_ptr())
+            eng.sync()
+            for rep in range(2):
+                eng.reset()
+                eng.reset_timings()
+                t0 = time.perf_counter()
+                for b in range(n // batch):
+                    eng.ingest_reads_device(d_all.data_ptr() + b * batch * L, d_off.data_ptr(), batch, batch * L)
+                eng.finalize()
+                dt = time.perf_counter() - t0
+            c = eng.counters()
+            res["from_hbm"] = {"Gbases_per_s": round(n * L / dt / 1e9, 2), "seconds": round(dt, 4), "kernels_ms": _timings_ms(eng, 1),
+                               "n_kmers": c["n_kmers_ingested"], "kmers_as_expected": c["n_kmers_ingested"] == (L - k + 1) * n,
+                               "n_unique": c["n_unique_kmers"]}
+            # host-streamed: the first 24 M reads from pinned memory (the same engine, the table already sized)
+            nh = 24_000_000
+            hb = torch.empty(nh * L, dtype=torch.uint8, pin_memory=True)
+            hb.copy_(d_all[:nh * L])
+            del d_all
+            torch.cuda.empty_cache()
+            ho = np.arange(batch + 1, dtype=np.uint64) * np.uint64(L)
+            eng.reset()
+            eng.ingest_reads(hb.numpy()[:batch * L], ho)  # (untimed: the staging buffers of the host path are allocated here)
+            eng.reset()
+            t0 = time.perf_counter()
+            for b in range(nh // batch):
+                eng.ingest_reads(hb.numpy()[b * batch * L:(b + 1) * batch * L], ho)
+            eng.finalize()
+            dt = time.perf_counter() - t0
+            res["host_streamed"] = {"reads": nh, "Gbases_per_s": round(nh * L / dt / 1e9, 2), "pcie_GB_per_s": round(nh * L / dt / 1e9, 2),
+                                    "bound": "PCIe H2D, 1 B/base ASCII; copy of slice i+1 overlaps the counting of slice i"}
+        return res
+    guarded("config3", config3)
+
+    # ---- chunk lanes and large tables (the shapes BASELINE configs[3]/[4] put on every GPU) -----------------
+    def shapes():
+        res = {}
+        for name, genome, n, chunks, steps in (("config2_10_lanes", 3_000_000, 1_000_000, 10, 30),
+                                               ("genome_30Mb_1_lane", 30_000_000, 1_700_000, 1, 10),
+                                               ("genome_30Mb_10_lanes", 30_000_000, 1_700_000, 10, 10)):
+            spec = sa.SynthSpec(genome_len=genome, read_len=L)
+            with sa.KmerEngine(21, chunks, 10000, device=dev, capacity_hint=genome, flags=sa.FLAG_TIMING) as eng:
+                db, do = device_reads(eng, spec, 0, n)
+
+                def one():
+                    eng.reset()
+                    eng.ingest_reads_device(db.data_ptr(), do.data_ptr(), n, n * L)
+                    eng.finalize()
+                for _ in range(3):
+                    one()
+                eng.reset_timings()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    one()
+                dt = time.perf_counter() - t0
+                res[name] = {"workload": f"{n} reads, {genome} bp genome, {chunks} chunk lane(s); step = reset + count + histogram emit, input in HBM",
+                             "Gbases_per_s": round(n * L * steps / dt / 1e9, 2), "ms_per_step": round(dt / steps * 1e3, 4),
+                             "kernels_ms_per_step": _timings_ms(eng, steps)}
+        return res
+    guarded("shapes", shapes)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +272,8 @@ def main():
     ap.add_argument("--histo-max", type=int, default=10000)
     ap.add_argument("--path", choices=["auto", "direct", "paged"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra timing points (host / file / config 3 …)")
+    ap.add_argument("--ramp-ms", type=float, default=250.0, help="untimed clock ramp before the warm-up steps")
     ap.add_argument("--cpu-sample-reads", type=int, default=0,
                     help="reads for the CPU baseline (0 = the whole step batch of rank 0)")
     args = ap.parse_args()
@@ -144,6 +336,17 @@ def main():
         eng.finalize()
         return eng.histograms()
 
+    ramp_steps = 0
+    if dist is not None:
+        # every step ends in collectives: all ranks must run the SAME number of ramp steps
+        for _ in range(max(int(args.ramp_ms / 1.2), 0)):
+            step()
+            ramp_steps += 1
+    else:
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms and ramp_steps < 2000:  # untimed: clocks up
+            step()
+            ramp_steps += 1
     for _ in range(args.warmup):
         step()
     eng.reset_timings()
@@ -202,15 +405,21 @@ def main():
         roof = None
         if dom:
             d = per_kernel[dom]
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath):  # PMC bytes of the same command, collected by tools/profile_round.sh
+            # HBM bytes per launch from the PMC passes of THIS round's build (tools/profile_round.sh →
+            # tools/collect_profile.py → profiles/<round>_traffic.json, FETCH_SIZE doubled per the gfx950 note of
+            # MI355X_MICROARCH.md): a committed measurement of the same command, named here; null when the
+            # newest file on record is for another workload
+            traffic, traffic_src = None, None
+            import glob
+            for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True):
                 tj = json.load(open(tpath))
-                if tj.get("reads") == n_reads and tj.get("k") == args.k:
-                    traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+                if tj.get("reads") == n_reads and tj.get("k") == args.k and dom in tj.get("kernels", {}):
+                    traffic = tj["kernels"][dom].get("hbm_bytes_per_launch")
+                    traffic_src = os.path.relpath(tpath, ROOT)
+                break  # (only the newest round's file counts: an older one would be a stale constant)
             roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(d["achieved_GBps"] / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "alg_bytes_per_launch": d["alg_bytes_per_launch"],
+                    "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": d["alg_bytes_per_launch"],
                     "avg_launch_ms": d["avg_launch_ms"]}
         # the whole counting path against SURVEY.md §8d's B_alg (1 B/base + 16 B/k-mer + 8 B/distinct
         # + one table scan per emit), over the summed device time of its kernels
@@ -259,7 +468,13 @@ def main():
             "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in tim.items()},
             "table": {"capacity": cnt["table_capacity"], "n_unique": cnt["n_unique_kmers"],
                       "n_grows": cnt["n_grows"], "n_spilled": cnt["n_spilled"]},
+            "ramp_steps": ramp_steps,
         }
+        if world == 1 and dist is None and not args.no_extras:
+            eng.close()
+            del d_bases, d_offsets
+            torch.cuda.empty_cache()
+            out["extras"] = extras(sa, torch, dev)
         print(json.dumps(out))
     eng.close()
     if dist is not None:

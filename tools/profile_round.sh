@@ -6,7 +6,7 @@
 # Outputs land under gpurun_out/<tag>/ ; copy the summaries into profiles/ afterwards.
 set -e
 TAG=${1:-r01}
-ARGS=${2:-"--no-cpu-baseline"}  # bench.py's own defaults: the averages in profiles/ are of the same command
+ARGS=${2:-"--no-cpu-baseline --no-extras"}  # bench.py's own defaults: the averages in profiles/ are of the same command
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$TAG
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/trace -- python3 bench.py $ARGS > gpurun_out/$TAG/trace.log 2>&1
