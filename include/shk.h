@@ -156,6 +156,32 @@ int shk_ingest_batch(shk_ctx *ctx, uint32_t chunk_id, const uint8_t *bases,
 int shk_ingest_reads(shk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets,
                      uint64_t n_seqs);
 
+/* ---- 2-bit packed input ---------------------------------------------------------------------------------
+ * The layout of the reference's Read::from_str (src/kmer/encoding.rs:60-95; known-answer vectors
+ * src/kmer/mod.rs:61-156) applied to a batch's concatenated bases as ONE sequence: 4 bases per byte, the first
+ * base in the two most significant bits (A 00, C 01, G 10, T 11), the tail left-aligned in its byte; plus an
+ * N mask — bit p % 32 of word p / 32 set where base p is N (code 00 in the stream) — because
+ * kmers_from_ascii, unlike from_str, takes N (encoding.rs:346-352).  0.28 B/base instead of 1 over PCIe.
+ * shk_pack_reads (host, n_threads = 0: all cores) validates like encoding.rs:353-356: the first byte outside
+ * ACGTN in input order ⇒ SHK_ERR_INVALID_CHAR, message from shk_run_error().  packed: (n_bases+3)/4 bytes,
+ * nmask: (n_bases+31)/32 words (shk_packed_sizes). */
+void shk_packed_sizes(uint64_t n_bases, uint64_t *packed_bytes, uint64_t *nmask_words);
+int shk_pack_reads(const uint8_t *bases, uint64_t n_bases, uint8_t *packed, uint32_t *nmask, uint32_t n_threads);
+/* shk_ingest_reads for a packed batch: offsets[n_seqs+1] are BASE indices into the stream (offsets[0] is
+ * where the batch starts in it).  Host buffers. */
+int shk_ingest_packed(shk_ctx *ctx, const uint8_t *packed, const uint32_t *nmask, const uint64_t *offsets,
+                      uint64_t n_seqs);
+/* The same with everything resident in device memory (the stream starts at base 0; d_offsets as in
+ * shk_ingest_reads_device).  Asynchronous like shk_ingest_reads_device. */
+int shk_ingest_packed_device(shk_ctx *ctx, const void *d_packed, const void *d_nmask, const void *d_offsets,
+                             uint64_t n_seqs, uint64_t n_bases);
+/* The packer and its inverse on the device (ASCII bytes ↔ stream + mask, all device pointers): what the
+ * device-side buffer of a batch looks like, pinned by the reference's vectors in tests/test_gpu_packed.py.
+ * shk_pack_reads_device reports an invalid byte like shk_pack_reads (message from shk_last_error) and leaves
+ * the context usable. */
+int shk_pack_reads_device(shk_ctx *ctx, const void *d_bases, uint64_t n_bases, void *d_packed, void *d_nmask);
+int shk_unpack_reads_device(shk_ctx *ctx, const void *d_packed, const void *d_nmask, uint64_t n_bases, void *d_bases);
+
 /* Set the running read index used by shk_ingest_reads* for chunk striping (default 0).  A
  * host that shards one input stream over several contexts/GPUs gives each shard the global
  * index of its first read, so that read i still lands in chunk (i / 1000) % n_chunks. */

@@ -716,6 +716,72 @@ __global__ void __launch_bounds__(WG) k_fill(FillSegs f) {
 }
 
 // ==========================================================================================
+// K_PACK / K_UNPACK: the 2-bit packed input format.  A batch's concatenated bases as ONE sequence in the
+// layout of the reference's Read::from_str (src/kmer/encoding.rs:60-95): 4 bases per byte, first base in
+// the two most significant bits (A 00, C 01, G 10, T 11), the tail left-aligned in its byte — plus what
+// from_str has no room for and kmers_from_ascii needs (encoding.rs:346-352): an N mask, bit p % 32 of word
+// p / 32 set where base p is N (its 2-bit code is then 00).  0.28 B/base instead of 1: what a host sends
+// over PCIe when it packs (shk_pack_reads) before it hands a batch over (shk_ingest_packed).
+// k_unpack restores the ASCII batch in HBM for the counting kernels; k_pack is the device-side packer
+// (validation as in encoding.rs:353-356: the first offender in input order through stats->bad).
+// ==========================================================================================
+__global__ void __launch_bounds__(WG) k_pack(const uint8_t *__restrict__ bases, uint64_t n_bases,
+                                             uint8_t *__restrict__ packed, uint32_t *__restrict__ nmask,
+                                             DevStats *__restrict__ stats) {
+  const uint64_t g = (uint64_t)blockIdx.x * WG + threadIdx.x;  // one 32-base group = 8 packed bytes + 1 mask word
+  const uint64_t p0 = g * 32;
+  if (p0 >= n_bases) return;
+  const uint32_t n = n_bases - p0 < 32 ? (uint32_t)(n_bases - p0) : 32u;
+  uint32_t nm = 0;
+  uint64_t bits = 0;  // 32 bases, first base on top
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t c = bases[p0 + i];
+    if (!byte_is_acgtn(c)) atomicMin(&stats->bad, ((unsigned long long)(p0 + i) << 8) | c);
+    const uint32_t isn = c == 'N';
+    nm |= isn << i;
+    bits |= (uint64_t)(isn ? 0u : (((c >> 1) ^ (c >> 2)) & 3u)) << (62 - 2 * i);
+  }
+  nmask[g] = nm;
+  for (uint32_t j = 0; j < (n + 3) / 4; ++j) packed[g * 8 + j] = (uint8_t)(bits >> (56 - 8 * j));
+}
+
+// (a slice of a batch starts at a read boundary, not at a byte or word boundary of the streams: pk_base0, nm_base0)
+__global__ void __launch_bounds__(WG) k_unpack(const uint8_t *__restrict__ packed, uint32_t pk_base0,
+                                               const uint32_t *__restrict__ nmask, uint32_t nm_base0,
+                                               uint64_t n_bases, uint8_t *__restrict__ out) {
+  const uint64_t q = ((uint64_t)blockIdx.x * WG + threadIdx.x) * 16;  // 16 bases → one 16-byte store
+  if (q >= n_bases) return;
+  // output position 0 is base pk_base0 (0-3) of packed[0] and bit nm_base0 (0-31) of nmask[0]
+  const uint64_t sp = pk_base0 + q;
+  const uint64_t by = sp >> 2;
+  const uint32_t r = (uint32_t)sp & 3u;
+  // 16 bases = 32 bits from bit 2r of byte `by` on: five bytes, first base on top
+  uint64_t five = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) five = (five << 8) | packed[by + j];  // (the staging buffers are padded: no read past the allocation)
+  const uint32_t w = (uint32_t)(five >> (8 - 2 * r));
+  const uint64_t sn = nm_base0 + q;
+  const uint64_t nw = sn >> 5;
+  const uint32_t nsh = (uint32_t)sn & 31u;
+  const uint64_t two = (uint64_t)nmask[nw] | ((uint64_t)nmask[nw + 1] << 32);
+  const uint32_t nm = (uint32_t)(two >> nsh) & 0xFFFFu;
+  uint32_t o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t c8 = (w >> (24 - 8 * j)) & 0xFFu, n4 = (nm >> (4 * j)) & 0xFu;
+    // selector byte = 2-bit code | N bit << 2: 0-3 → A C G T, 4-7 → N
+    const uint32_t sel = ((c8 >> 6) & 3u) | (((c8 >> 4) & 3u) << 8) | (((c8 >> 2) & 3u) << 16) | ((c8 & 3u) << 24) |
+                         ((n4 & 1u) << 2) | ((n4 & 2u) << 9) | ((n4 & 4u) << 16) | ((n4 & 8u) << 23);
+    o[j] = __builtin_amdgcn_perm(0x4E4E4E4Eu /* N N N N */, 0x54474341u /* T G C A */, sel);
+  }
+  if (q + 16 <= n_bases) {
+    *reinterpret_cast<uint4 *>(out + q) = make_uint4(o[0], o[1], o[2], o[3]);
+  } else {
+    for (uint32_t i = 0; q + i < n_bases; ++i) out[q + i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
+  }
+}
+
+// ==========================================================================================
 // K_MARK: read-start bitmap.  One thread per read, NO atomics and no zeroed bitmap to start from:
 // the reads are in offset order, so the first read of every 32-position word (the "leader")
 // gathers the start bits of all reads that begin in that word, stores the word, and zero-fills

@@ -121,6 +121,7 @@ struct shk_ctx {
   bool lds_attr_scatter = false, lds_attr_rescatter = false, lds_attr_scatter_own = false;  // hipFuncSetAttribute done for this context's device
   HostBuf h_rebased[2];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
   DevBuf in_bases, in_offsets, in_bases2, in_offsets2, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
+  DevBuf pk_stage[2], nm_stage[2], pk_ascii;  // packed input: the staged streams of a slice; a whole batch unpacked (device-resident packed ingest)
   DevBuf xbuf, xspill;            // owner layout: the level-1 records of a launch by [owner][lane][super-page]; the foreign spill list
   uint64_t xspill_cap = 0;
   // host counters
@@ -1426,6 +1427,8 @@ void shk_destroy(shk_ctx *c) {
   c->acc_cur.release();
   c->xbuf.release();
   c->xspill.release();
+  for (int i = 0; i < 2; ++i) c->pk_stage[i].release(), c->nm_stage[i].release();
+  c->pk_ascii.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1472,14 +1475,17 @@ int shk_reset(shk_ctx *c) {
 // device staging buffers: slice i+1 crosses PCIe on the copy stream while slice i is being
 // counted on the engine stream (BASELINE.json configs[2]: "streamed chunks with copy/compute
 // overlap").  Striping is unaffected: ingest_core advances the running read index per slice.
+// packed != nullptr: the batch comes as the 2-bit stream + N mask of shk_pack_reads (offsets count BASES of
+// that stream); every slice's share of both crosses PCIe instead of its ASCII bytes and is unpacked in HBM.
 static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
-                       int64_t lane_fixed) {
+                       int64_t lane_fixed, const uint8_t *packed = nullptr, const uint32_t *nmask = nullptr) {
   if (!c) return SHK_ERR_BAD_ARG;
   if (n_seqs && (!offsets)) return fail(c, SHK_ERR_BAD_ARG, "null offsets");
   HIPC(c, hipSetDevice(c->cfg.device));
   if (n_seqs == 0) return ingest_core(c, nullptr, nullptr, 0, 0, lane_fixed);
   const uint64_t n_bases_all = offsets[n_seqs] - offsets[0];
-  if (n_bases_all && !bases) return fail(c, SHK_ERR_BAD_ARG, "null bases");
+  if (n_bases_all && !bases && !packed) return fail(c, SHK_ERR_BAD_ARG, "null bases");
+  if (packed && !nmask) return fail(c, SHK_ERR_BAD_ARG, "null N mask");
   const uint64_t slice_kb = (uint64_t)env_int("SHK_SLICE_KB", 256 << 10);  // test hook: tiny slices
   const uint64_t slice_bases = slice_kb << 10;
   // slice boundaries at read boundaries, ≈ slice_bases each
@@ -1509,7 +1515,14 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     HIPC(c, dof.ensure((ns + 1) * 8));
     HIPC(c, c->h_rebased[bsel].ensure((ns + 1) * 8));  // (free: the copy that read it last has completed, see below)
     uint64_t *rebased = (uint64_t *)c->h_rebased[bsel].p;  // device code indexes the staged copy from 0
-    if (nb) HIPC(c, hipMemcpyAsync(db.p, bases + o0, nb, hipMemcpyHostToDevice, c->copy_stream));
+    if (nb && packed) {  // the slice's bytes of the 2-bit stream and words of the N mask (+ pad: k_unpack reads a few bytes on)
+      const uint64_t b0 = o0 >> 2, b1 = (o0 + nb + 3) >> 2, w0 = o0 >> 5, w1 = (o0 + nb + 31) >> 5;
+      HIPC(c, c->pk_stage[bsel].ensure(b1 - b0 + 16));
+      HIPC(c, c->nm_stage[bsel].ensure((w1 - w0 + 2) * 4));
+      HIPC(c, hipMemcpyAsync(c->pk_stage[bsel].p, packed + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream));
+      HIPC(c, hipMemcpyAsync(c->nm_stage[bsel].p, nmask + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, c->copy_stream));
+    } else if (nb)
+      HIPC(c, hipMemcpyAsync(db.p, bases + o0, nb, hipMemcpyHostToDevice, c->copy_stream));
     for (uint64_t j = 0; j <= ns; ++j) rebased[j] = offsets[r0 + j] - o0;  // (while the bases are on their way)
     HIPC(c, hipMemcpyAsync(dof.p, rebased, (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
     HIPC(c, hipEventRecord(c->copy_done[bsel], c->copy_stream));
@@ -1536,6 +1549,14 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
     DevBuf &db = bsel ? c->in_bases2 : c->in_bases;
     DevBuf &dof = bsel ? c->in_offsets2 : c->in_offsets;
+    if (packed && offsets[r1] > offsets[r0]) {  // 2-bit stream + N mask → the slice's ASCII bytes, in HBM
+      const uint64_t o0 = offsets[r0], nb = offsets[r1] - o0;
+      // (the staged copies start at byte o0/4 resp. word o0/32 of the streams; what k_unpack reads past their
+      // end only ever feeds positions ≥ nb, which it does not write)
+      hipLaunchKernelGGL(k_unpack, dim3((uint32_t)((nb + 16ull * WG - 1) / (16ull * WG))), dim3(WG), 0, c->stream,
+                         (const uint8_t *)c->pk_stage[bsel].p, (uint32_t)(o0 & 3), (const uint32_t *)c->nm_stage[bsel].p,
+                         (uint32_t)(o0 & 31), nb, (uint8_t *)db.p);
+    }
     rc = ingest_core(c, (const uint8_t *)db.p, (const uint64_t *)dof.p, r1 - r0, offsets[r1] - offsets[r0],
                      lane_fixed);
     if (rc != SHK_OK) {
@@ -1558,6 +1579,67 @@ int shk_ingest_batch(shk_ctx *c, uint32_t chunk_id, const uint8_t *bases, const 
 int shk_ingest_reads(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs) {
   if (c && c->group) return group_ingest(c, bases, offsets, n_seqs, -1);
   return ingest_host(c, bases, offsets, n_seqs, -1);
+}
+
+// ---- 2-bit packed input (the reference's Read::from_str layout, encoding.rs:60-95, + an N mask) ----------
+int shk_ingest_packed(shk_ctx *c, const uint8_t *packed, const uint32_t *nmask, const uint64_t *offsets, uint64_t n_seqs) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "a multi-device context takes ASCII host buffers");
+  if (n_seqs && !packed) return fail(c, SHK_ERR_BAD_ARG, "null packed stream");
+  return ingest_host(c, nullptr, offsets, n_seqs, -1, packed, nmask);
+}
+
+int shk_pack_reads_device(shk_ctx *c, const void *d_bases, uint64_t n_bases, void *d_packed, void *d_nmask) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (n_bases == 0) return SHK_OK;
+  if (!d_bases || !d_packed || !d_nmask) return fail(c, SHK_ERR_BAD_ARG, "null buffer");
+  HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle(c);  // (stats->bad below belongs to this call alone)
+    if (rcs != SHK_OK) return rcs;
+  }
+  hipLaunchKernelGGL(k_pack, dim3((uint32_t)((n_bases + 32ull * WG - 1) / (32ull * WG))), dim3(WG), 0, c->stream,
+                     (const uint8_t *)d_bases, n_bases, (uint8_t *)d_packed, (uint32_t *)d_nmask, c->d_stats);
+  int rc = read_stats(c);
+  if (rc != SHK_OK) return rc;
+  if (c->h_stats->bad != ~0ull) {  // encoding.rs:353-356; the context's table was not touched: no poisoning
+    const char bad = (char)(c->h_stats->bad & 0xFF);
+    HIPC(c, hipMemsetAsync(&c->d_stats->bad, 0xFF, 8, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->h_stats->bad = ~0ull;
+    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%c' in sequence. Only ACGTN allowed.", bad);
+  }
+  return SHK_OK;
+}
+
+int shk_unpack_reads_device(shk_ctx *c, const void *d_packed, const void *d_nmask, uint64_t n_bases, void *d_bases) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (n_bases == 0) return SHK_OK;
+  if (!d_bases || !d_packed || !d_nmask) return fail(c, SHK_ERR_BAD_ARG, "null buffer");
+  HIPC(c, hipSetDevice(c->cfg.device));
+  hipLaunchKernelGGL(k_unpack, dim3((uint32_t)((n_bases + 16ull * WG - 1) / (16ull * WG))), dim3(WG), 0, c->stream,
+                     (const uint8_t *)d_packed, 0u, (const uint32_t *)d_nmask, 0u, n_bases, (uint8_t *)d_bases);
+  HIPC(c, hipGetLastError());
+  return SHK_OK;
+}
+
+int shk_ingest_packed_device(shk_ctx *c, const void *d_packed, const void *d_nmask, const void *d_offsets, uint64_t n_seqs,
+                             uint64_t n_bases) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "a multi-device context takes host buffers");
+  if (!c) return SHK_ERR_BAD_ARG;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcs = settle_light(c);  // (the previous launch may still be reading the unpacked copy of ITS batch)
+    if (rcs != SHK_OK) return rcs;
+    HIPC(c, hipStreamSynchronize(c->stream));
+  }
+  HIPC(c, c->pk_ascii.ensure(n_bases + 64));
+  if (n_bases) {
+    int rc = shk_unpack_reads_device(c, d_packed, d_nmask, n_bases, c->pk_ascii.p);
+    if (rc != SHK_OK) return rc;
+  }
+  return ingest_core(c, (const uint8_t *)c->pk_ascii.p, (const uint64_t *)d_offsets, n_seqs, n_bases, -1);
 }
 
 int shk_set_read_index(shk_ctx *c, uint64_t next_read_index) {

@@ -484,6 +484,69 @@ int shk_validate_args(uint32_t k, uint64_t histo_max, const char *sample) {
   return SHK_OK;
 }
 
+// ---- 2-bit packing on the host (the reference's Read::from_str layout, encoding.rs:60-95, over the whole
+// batch as ONE sequence, + the N mask kmers_from_ascii's N handling needs, encoding.rs:346-352) -------------
+void shk_packed_sizes(uint64_t n_bases, uint64_t *packed_bytes, uint64_t *nmask_words) {
+  if (packed_bytes) *packed_bytes = (n_bases + 3) / 4;
+  if (nmask_words) *nmask_words = (n_bases + 31) / 32;
+}
+
+int shk_pack_reads(const uint8_t *bases, uint64_t n_bases, uint8_t *packed, uint32_t *nmask, uint32_t n_threads) {
+  g_run_error.clear();
+  if (n_bases == 0) return SHK_OK;
+  if (!bases || !packed || !nmask) {
+    g_run_error = "null buffer";
+    return SHK_ERR_BAD_ARG;
+  }
+  // 256-entry table: 0-3 the code, 4 = N, 0xFF = invalid (encoding.rs:341-356)
+  static const struct Lut {
+    uint8_t t[256];
+    Lut() {
+      memset(t, 0xFF, sizeof t);
+      t[(unsigned)'A'] = 0, t[(unsigned)'C'] = 1, t[(unsigned)'G'] = 2, t[(unsigned)'T'] = 3, t[(unsigned)'N'] = 4;
+    }
+  } lut;
+  const uint64_t n_words = (n_bases + 31) / 32;  // a thread's share is whole 32-base groups: no shared byte or word
+  uint32_t T = n_threads ? n_threads : std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  if (n_words < 4096) T = 1;
+  T = (uint32_t)std::min<uint64_t>(T, n_words);
+  std::vector<uint64_t> bad(T, ~0ull);  // first offender of each share: position << 8 | byte
+  auto work = [&](uint32_t t) {
+    const uint64_t w0 = n_words * t / T, w1 = n_words * (t + 1) / T;
+    for (uint64_t w = w0; w < w1; ++w) {
+      const uint64_t p0 = w * 32;
+      const uint32_t n = (uint32_t)std::min<uint64_t>(32, n_bases - p0);
+      uint64_t bits = 0;
+      uint32_t nm = 0;
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint8_t c = lut.t[bases[p0 + i]];
+        if (c == 0xFF) {
+          if (bad[t] == ~0ull) bad[t] = ((p0 + i) << 8) | bases[p0 + i];
+          continue;
+        }
+        nm |= (uint32_t)(c >> 2) << i;
+        bits |= (uint64_t)(c & 3u) << (62 - 2 * i);
+      }
+      nmask[w] = nm;
+      for (uint32_t j = 0; j < (n + 3) / 4; ++j) packed[w * 8 + j] = (uint8_t)(bits >> (56 - 8 * j));
+    }
+  };
+  if (T == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  uint64_t first = ~0ull;
+  for (uint64_t b : bad) first = std::min(first, b);
+  if (first != ~0ull) {  // identical text to encoding.rs:353-356
+    g_run_error = fmt("Invalid character '%c' in sequence. Only ACGTN allowed.", (char)(first & 0xFF));
+    return SHK_ERR_INVALID_CHAR;
+  }
+  return SHK_OK;
+}
+
 int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
   if (!rc) return SHK_ERR_BAD_ARG;
   g_run_error.clear();

@@ -108,6 +108,8 @@ ABI_SYMBOLS = [
     "shk_run_error", "shk_run_files",
     "shk_xchg_scatter_device", "shk_xchg_absorb", "shk_xchg_spill", "shk_xchg_spill_clear", "shk_insert_device",
     "shk_stream", "shk_compact_owners_packed",
+    "shk_packed_sizes", "shk_pack_reads", "shk_ingest_packed", "shk_ingest_packed_device", "shk_pack_reads_device",
+    "shk_unpack_reads_device",
 ]
 
 _lib = None
@@ -189,6 +191,13 @@ def load_library():
     L.shk_insert_device.argtypes = [vp, vp, vp, vp, u64]
     L.shk_stream.argtypes = [vp]
     L.shk_stream.restype = vp
+    L.shk_packed_sizes.argtypes = [u64, C.POINTER(u64), C.POINTER(u64)]
+    L.shk_packed_sizes.restype = None
+    L.shk_pack_reads.argtypes = [vp, u64, vp, vp, u32]
+    L.shk_ingest_packed.argtypes = [vp, vp, vp, vp, u64]
+    L.shk_ingest_packed_device.argtypes = [vp, vp, vp, vp, u64, u64]
+    L.shk_pack_reads_device.argtypes = [vp, vp, u64, vp, vp]
+    L.shk_unpack_reads_device.argtypes = [vp, vp, vp, u64, vp]
     L.shk_set_owned_pages.argtypes = [vp, u64, u64]
     L.shk_alloc_pinned.argtypes = [C.c_size_t]
     L.shk_alloc_pinned.restype = vp
@@ -291,6 +300,20 @@ class KmerEngine:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self._check(self._L.shk_ingest_reads(self._h, bases.ctypes.data, offsets.ctypes.data,
                                              len(offsets) - 1))
+
+    def ingest_packed(self, pk: "PackedReads"):
+        """shk_ingest_packed: a batch packed by pack_reads (2-bit stream + N mask + base offsets)."""
+        self._check(self._L.shk_ingest_packed(self._h, pk.packed.ctypes.data, pk.nmask.ctypes.data,
+                                              pk.offsets.ctypes.data, len(pk.offsets) - 1))
+
+    def ingest_packed_device(self, d_packed: int, d_nmask: int, d_offsets: int, n_seqs: int, n_bases: int):
+        self._check(self._L.shk_ingest_packed_device(self._h, d_packed, d_nmask, d_offsets, n_seqs, n_bases))
+
+    def pack_reads_device(self, d_bases: int, n_bases: int, d_packed: int, d_nmask: int):
+        self._check(self._L.shk_pack_reads_device(self._h, d_bases, n_bases, d_packed, d_nmask))
+
+    def unpack_reads_device(self, d_packed: int, d_nmask: int, n_bases: int, d_bases: int):
+        self._check(self._L.shk_unpack_reads_device(self._h, d_packed, d_nmask, n_bases, d_bases))
 
     def ingest_seqs(self, seqs):
         """Convenience: a list of str/bytes sequences in input order."""
@@ -595,6 +618,45 @@ class KmerEngine:
                    sub_per_64k=spec.sub_per_64k, n_per_64k=spec.n_per_64k)
         self._check(self._L.shk_synth_reads_device(self._h, C.byref(s), first_read, n_reads,
                                                    d_bases, d_offsets))
+
+
+# ---- 2-bit packed batches (include/shk.h: the reference's Read::from_str layout + an N mask) --------------
+
+class PackedReads:
+    """A batch as shk_pack_reads leaves it: packed u8[(n+3)//4] (4 bases per byte, first base on top),
+    nmask u32[(n+31)//32] (bit p%32 of word p//32 ⇔ base p is N), offsets u64[n_seqs+1] in bases."""
+
+    def __init__(self, packed, nmask, offsets, n_bases):
+        self.packed, self.nmask, self.offsets, self.n_bases = packed, nmask, offsets, n_bases
+
+    @property
+    def nbytes(self):
+        return self.packed.nbytes + self.nmask.nbytes + self.offsets.nbytes
+
+
+def pack_reads(bases: np.ndarray, offsets: np.ndarray, threads: int = 0, pinned: bool = False) -> PackedReads:
+    """shk_pack_reads over a batch of concatenated ASCII reads (host, multi-threaded).  pinned: the
+    output arrays live in pinned host memory (shk_alloc_pinned; freed with the process)."""
+    L = load_library()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = int(offsets[-1]) if len(offsets) else 0
+    assert len(offsets) == 0 or int(offsets[0]) == 0
+    nb, nw = (n + 3) // 4, (n + 31) // 32
+    if pinned:
+        pp = L.shk_alloc_pinned(max(nb, 1) + 16)
+        pm = L.shk_alloc_pinned(max(nw, 1) * 4 + 16)
+        po = L.shk_alloc_pinned(offsets.nbytes + 16)
+        packed = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint8)), shape=(nb,))
+        nmask = np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint32)), shape=(nw,))
+        offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(len(offsets),))
+        offs[:] = offsets
+    else:
+        packed, nmask, offs = np.zeros(nb, dtype=np.uint8), np.zeros(nw, dtype=np.uint32), offsets
+    rc = L.shk_pack_reads(bases.ctypes.data, n, packed.ctypes.data, nmask.ctypes.data, threads)
+    if rc != 0:
+        raise ShkError(rc, (L.shk_run_error() or b"").decode("utf-8", "replace"))
+    return PackedReads(packed, nmask, offs, n)
 
 
 # ---- host side either side of the path: FASTQ front-end, writers, whole-run driver -----------------
