@@ -111,9 +111,11 @@ def extras(sa, torch, dev):
             db, do = device_reads(eng, spec, 0, n)
             hb = torch.empty(n * L, dtype=torch.uint8, pin_memory=True)
             hb.copy_(db)
-            ho = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+            ho_t = torch.empty(n + 1, dtype=torch.int64, pin_memory=True)
+            ho_t.copy_(torch.arange(n + 1, dtype=torch.int64) * L)
+            ho = ho_t.numpy().view(np.uint64)
             del db, do
-            for kind, arr in (("pinned", hb.numpy()), ("pageable", hb.numpy().copy())):
+            for kind, arr, ho in (("pinned", hb.numpy(), ho), ("pageable", hb.numpy().copy(), ho.copy())):
                 eng.reset()
                 eng.ingest_reads(arr, ho)
                 eng.finalize()

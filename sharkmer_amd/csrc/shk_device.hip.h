@@ -794,18 +794,20 @@ __global__ void __launch_bounds__(WG) k_mark_starts(const uint64_t *__restrict__
                                                     uint64_t n_seqs, uint64_t n_bases,
                                                     uint32_t *__restrict__ startbits, uint64_t sb_words,
                                                     unsigned int *__restrict__ zero_u32, uint32_t n_zero,
-                                                    unsigned long long *__restrict__ zero_u64) {
+                                                    unsigned long long *__restrict__ zero_u64, uint64_t off_bias) {
+  // off_bias: what the offsets are ahead of the batch's first byte by (a slice of a host batch is handed on with
+  // the caller's own offsets: no re-based copy is made on the host)
   const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
   for (uint64_t j = i; j < n_zero; j += (uint64_t)gridDim.x * WG) zero_u32[j] = 0;
   if (i == 0 && zero_u64) *zero_u64 = 0;
   if (i >= n_seqs) return;
-  const uint64_t o = offsets[i];
+  const uint64_t o = offsets[i] - off_bias;
   const uint64_t w = o >> 5;
-  if (i > 0 && (offsets[i - 1] >> 5) == w) return;  // not the first read of its word
+  if (i > 0 && ((offsets[i - 1] - off_bias) >> 5) == w) return;  // not the first read of its word
   uint32_t bits = 0;
   uint64_t j = i, oj = o;
   while (j < n_seqs && (oj >> 5) == w) {  // usually one iteration: reads are longer than a word
-    const uint64_t ej = offsets[j + 1];
+    const uint64_t ej = offsets[j + 1] - off_bias;
     if (ej > oj && oj < n_bases) bits |= 1u << (oj & 31);  // empty reads start nothing
     oj = ej;
     ++j;
@@ -828,7 +830,7 @@ __global__ void __launch_bounds__(TB_WG) k_build_tiles(const uint64_t *__restric
                                                        uint64_t n_seqs, uint64_t g0,
                                                        uint32_t n_chunks, uint64_t n_blocks,
                                                        TileDesc *__restrict__ tiles,
-                                                       DevStats *__restrict__ stats) {
+                                                       DevStats *__restrict__ stats, uint64_t off_bias) {
   __shared__ uint64_t sc[TB_WG];
   __shared__ uint64_t running;
   if (threadIdx.x == 0) running = 0;
@@ -842,8 +844,8 @@ __global__ void __launch_bounds__(TB_WG) k_build_tiles(const uint64_t *__restric
       uint64_t r0 = j == 0 ? 0 : first + (j - 1) * 1000;
       uint64_t r1 = first + j * 1000;
       if (r1 > n_seqs) r1 = n_seqs;
-      b0 = offsets[r0];
-      b1 = offsets[r1];
+      b0 = offsets[r0] - off_bias;
+      b1 = offsets[r1] - off_bias;
       nt = (b1 - b0 + TILE_T - 1) / TILE_T;
       lane = (uint32_t)(((g0 + r0) / 1000) % n_chunks);
     }

@@ -392,7 +392,7 @@ constexpr uint64_t MAX_SUB_BASES = 1ull << 28;  // bases per counting launch (bo
 // (drain_batch, io.rs:356-358); lane_fixed < 0: stripe by running read index
 // (read i → chunk (i/1000) % n_chunks, io.rs:340-343,355-361).
 int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_seqs,
-                uint64_t n_bases, int64_t lane_fixed, XchgOut *xo = nullptr) {
+                uint64_t n_bases, int64_t lane_fixed, XchgOut *xo = nullptr, uint64_t off_bias = 0) {
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
   {
     int rc0 = settle_light(c);  // the previous launch's spill list / scratch must be done with
@@ -457,10 +457,10 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     ScopedTimer t(c, SHK_K_MARK);
     hipLaunchKernelGGL(k_mark_starts, dim3((uint32_t)((n_seqs + WG - 1) / WG)), dim3(WG), 0,
                        c->stream, d_offsets, n_seqs, n_bases, (uint32_t *)c->startbits.p, (uint64_t)sb_words,
-                       (unsigned int *)c->part_meta.p, n_cursor_words, &c->d_stats->spill_count);
+                       (unsigned int *)c->part_meta.p, n_cursor_words, &c->d_stats->spill_count, off_bias);
     if (multi)
       hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(TB_WG), 0, c->stream, d_offsets, n_seqs, g0,
-                         NL, n_blocks, (TileDesc *)c->tiles.p, c->d_stats);
+                         NL, n_blocks, (TileDesc *)c->tiles.p, c->d_stats, off_bias);
   }
   c->chain_from_mark = true;  // (reset by the first scatter; nothing is enqueued in between)
   BatchRef b{};
@@ -1486,13 +1486,16 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   const uint64_t n_bases_all = offsets[n_seqs] - offsets[0];
   if (n_bases_all && !bases && !packed) return fail(c, SHK_ERR_BAD_ARG, "null bases");
   if (packed && !nmask) return fail(c, SHK_ERR_BAD_ARG, "null N mask");
-  const uint64_t slice_kb = (uint64_t)env_int("SHK_SLICE_KB", 256 << 10);  // test hook: tiny slices
+  // slices of 256 M bases of ASCII; a packed batch moves a third of the bytes per base, so the exposed copy
+  // of the first slice and the exposed count of the last one weigh more: 64 M bases per slice there
+  // the first slice is a quarter: its copy is the one nothing overlaps
+  const uint64_t slice_kb = (uint64_t)env_int("SHK_SLICE_KB", packed ? 128 << 10 : 256 << 10);  // test hook: tiny slices
   const uint64_t slice_bases = slice_kb << 10;
   // slice boundaries at read boundaries, ≈ slice_bases each
   std::vector<uint64_t> cut{0};
   while (cut.back() < n_seqs) {
     uint64_t lo = cut.back(), hi = n_seqs;
-    const uint64_t limit = offsets[lo] + slice_bases;
+    const uint64_t limit = offsets[lo] + (lo == 0 && packed ? std::max<uint64_t>(slice_bases / 4, 1) : slice_bases);
     if (offsets[n_seqs] > limit) {  // largest hi with offsets[hi] ≤ limit, at least one read
       hi = (uint64_t)(std::upper_bound(offsets + lo, offsets + n_seqs + 1, limit) - offsets) - 1;
       if (hi <= lo) hi = lo + 1;
@@ -1505,6 +1508,12 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     HIPC(c, hipEventCreateWithFlags(&c->copy_done[0], hipEventDisableTiming));
     HIPC(c, hipEventCreateWithFlags(&c->copy_done[1], hipEventDisableTiming));
   }
+  bool offsets_pinned = false;
+  {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, offsets) == hipSuccess) offsets_pinned = at.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();  // (ordinary host memory: not an error)
+  }
   auto issue_copy = [&](size_t i) -> int {
     const int bsel = (int)(i & 1);
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
@@ -1513,8 +1522,6 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     DevBuf &dof = bsel ? c->in_offsets2 : c->in_offsets;
     HIPC(c, db.ensure(nb + 64));
     HIPC(c, dof.ensure((ns + 1) * 8));
-    HIPC(c, c->h_rebased[bsel].ensure((ns + 1) * 8));  // (free: the copy that read it last has completed, see below)
-    uint64_t *rebased = (uint64_t *)c->h_rebased[bsel].p;  // device code indexes the staged copy from 0
     if (nb && packed) {  // the slice's bytes of the 2-bit stream and words of the N mask (+ pad: k_unpack reads a few bytes on)
       const uint64_t b0 = o0 >> 2, b1 = (o0 + nb + 3) >> 2, w0 = o0 >> 5, w1 = (o0 + nb + 31) >> 5;
       HIPC(c, c->pk_stage[bsel].ensure(b1 - b0 + 16));
@@ -1523,8 +1530,16 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
       HIPC(c, hipMemcpyAsync(c->nm_stage[bsel].p, nmask + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, c->copy_stream));
     } else if (nb)
       HIPC(c, hipMemcpyAsync(db.p, bases + o0, nb, hipMemcpyHostToDevice, c->copy_stream));
-    for (uint64_t j = 0; j <= ns; ++j) rebased[j] = offsets[r0 + j] - o0;  // (while the bases are on their way)
-    HIPC(c, hipMemcpyAsync(dof.p, rebased, (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
+    // the caller's own offsets, as they are (the kernels that read them subtract the slice's first: off_bias) —
+    // straight from the caller's memory when that is pinned, through a pinned staging copy otherwise (a pageable
+    // source makes the copy synchronous and holds up the slice's other transfers)
+    const uint64_t *osrc = offsets + r0;
+    if (!offsets_pinned) {
+      HIPC(c, c->h_rebased[bsel].ensure((ns + 1) * 8));  // (free: the copy that read it last has completed, see below)
+      memcpy(c->h_rebased[bsel].p, osrc, (ns + 1) * 8);
+      osrc = (const uint64_t *)c->h_rebased[bsel].p;
+    }
+    HIPC(c, hipMemcpyAsync(dof.p, osrc, (ns + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
     HIPC(c, hipEventRecord(c->copy_done[bsel], c->copy_stream));
     return SHK_OK;
   };
@@ -1558,7 +1573,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
                          (uint32_t)(o0 & 31), nb, (uint8_t *)db.p);
     }
     rc = ingest_core(c, (const uint8_t *)db.p, (const uint64_t *)dof.p, r1 - r0, offsets[r1] - offsets[r0],
-                     lane_fixed);
+                     lane_fixed, nullptr, offsets[r0]);
     if (rc != SHK_OK) {
       (void)hipStreamSynchronize(c->copy_stream);  // do not leave a copy reading `rebased` behind
       return rc;
