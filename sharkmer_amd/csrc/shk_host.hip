@@ -19,6 +19,8 @@
 #include <zlib.h>
 
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -27,6 +29,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -46,221 +51,444 @@ std::string fmt(const char *f, ...) {
 }  // namespace
 
 // ---- FASTQ reader --------------------------------------------------------------------------------
-// Read-ahead: a background thread does the gzread()s (file I/O + inflate, the slowest stage of the
-// host front-end) into a small ring of blocks while the caller's thread splits lines, fills the
-// batch and feeds the GPU.  The parser's view is unchanged: a stream of bytes, EOF, or a read error.
-struct ReadAhead {
-  static constexpr int NB = 4;
-  static constexpr size_t BLOCK = 4u << 20;
-  std::vector<char> blk[NB];
-  int len[NB];                 // bytes in the block; 0 = EOF marker; < 0 = gzread error
-  unsigned head = 0, tail = 0; // produced / consumed block counts
-  bool stop = false;
-  std::mutex m;
-  std::condition_variable cv;
-  std::thread th;
-  gzFile f = nullptr;
-  int fd = -1;  // ≥ 0: plain file, read() straight into the blocks (no pass through zlib's buffer)
+// Front-end at speed, order-preserving.  Every input file has a PRODUCER that turns
+// it into chunks of sequences (bases back to back + lengths) and notes what is wrong with which record;
+// the caller's thread (shk_fastq_next_batch) CONSUMES the files strictly in input order, so the global
+// read index — and with it the 1000-read chunk striping (io.rs:340-361), the validation cadence
+// (io.rs:321-332) and --max-reads (io.rs:345-348) — is exactly the sequential reader's:
+//   * plain files: mmap + a parallel parse of 128 MiB windows by a pool of threads — newline positions
+//     per thread share, a prefix sum gives every share its line number (a FASTQ record is exactly four lines,
+//     BufRead::lines: io.rs:271-352), then the sequence lines are sized and copied out in parallel;
+//   * gzip streams and stdin: one inflate + line-split thread per stream; the streams of LATER files run
+//     ahead (up to 8 at a time, each bounded by its queue), which is the only parallelism zlib allows.
+// A record is only ever looked at beyond its sequence when the cadence says so; producers check every
+// record (it costs nothing next to the line split) but only record WHAT they found — the consumer raises
+// a flaw when the flawed record turns out to be one the reference would have validated, with the reference's
+// text and the global record number.
+namespace {
 
-  void start(gzFile file, int raw_fd) {
-    f = file;
-    fd = raw_fd;
-    head = tail = 0;
-    stop = false;
-    for (auto &b : blk)
-      if (b.size() != BLOCK) b.resize(BLOCK);
-    th = std::thread([this] {
-      for (;;) {
-        unsigned slot;
-        {
-          std::unique_lock<std::mutex> lk(m);
-          cv.wait(lk, [this] { return stop || head - tail < (unsigned)NB; });
-          if (stop) return;
-          slot = head % NB;
-        }
-        int n;
-        if (fd >= 0) {
-          ssize_t got = 0, r = 0;  // fill the block: short reads would only shrink the blocks
-          while ((size_t)got < BLOCK && (r = ::read(fd, blk[slot].data() + got, BLOCK - (size_t)got)) > 0) got += r;
-          n = r < 0 ? -1 : (int)got;
-        } else {
-          n = gzread(f, blk[slot].data(), (unsigned)BLOCK);
-        }
-        {
-          std::lock_guard<std::mutex> lk(m);
-          len[slot] = n;
-          ++head;
-        }
-        cv.notify_all();
-        if (n <= 0) return;  // EOF or error: nothing more to produce
-      }
-    });
+struct Pool {  // a small persistent pool: parallel_for over [0, n)
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_job, cv_done;
+  std::function<void(uint32_t)> job;
+  uint32_t n_jobs = 0, next = 0, running = 0;
+  uint64_t gen = 0;
+  bool quit = false;
+  explicit Pool(uint32_t T) {
+    for (uint32_t t = 0; t < T; ++t) th.emplace_back([this] { run(); });
   }
-  // next block for the consumer (releases the previous one); n = its length, 0 = EOF, < 0 = error
-  const char *next(bool release_prev, int *n) {
-    std::unique_lock<std::mutex> lk(m);
-    if (release_prev) {
-      ++tail;
-      cv.notify_all();
-    }
-    cv.wait(lk, [this] { return head > tail; });
-    const unsigned slot = tail % NB;
-    *n = len[slot];
-    return blk[slot].data();
-  }
-  void shutdown() {
+  ~Pool() {
     {
       std::lock_guard<std::mutex> lk(m);
-      stop = true;
+      quit = true;
     }
-    cv.notify_all();
-    if (th.joinable()) th.join();
+    cv_job.notify_all();
+    for (auto &t : th) t.join();
+  }
+  void run() {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv_job.wait(lk, [&] { return quit || next < n_jobs; });
+      if (quit) return;
+      const uint32_t i = next++;
+      ++running;
+      lk.unlock();
+      job(i);
+      lk.lock();
+      if (--running == 0 && next >= n_jobs) cv_done.notify_all();
+    }
+  }
+  void parallel_for(uint32_t n, std::function<void(uint32_t)> f) {
+    if (n == 0) return;
+    std::unique_lock<std::mutex> lk(m);
+    job = std::move(f);
+    n_jobs = n;
+    next = 0;
+    cv_job.notify_all();
+    cv_done.wait(lk, [&] { return next >= n_jobs && running == 0; });
+    n_jobs = 0;
   }
 };
 
-struct shk_fastq {
-  std::vector<std::string> paths;
-  size_t file_idx = 0;
-  gzFile f = nullptr;
-  int fd = -1;  // plain (not gzip) regular file: read without zlib
-  std::string cur_name;
-  ReadAhead ra;
-  const char *buf = nullptr;  // current read-ahead block
-  bool have_block = false;
-  size_t buf_pos = 0, buf_len = 0;
-  bool file_eof = false;
-  uint64_t max_reads = 0, validate_every = 0;
-  uint64_t n_reads_read = 0, n_bases_read = 0;  // FastqReadState, io.rs:205-206
-  bool reached_max = false, done = false, pending = false;  // pending: line[] holds an undelivered record
-  std::string err;
-  int err_code = 0;
-  std::string line[4];
+enum FlawKind : uint8_t { FLAW_FASTA, FLAW_HEADER, FLAW_SEP, FLAW_LEN };
+struct Flaw {  // what validate_fastq_record (io.rs:161-198) would say about local record `rec` of a file
+  uint64_t rec;
+  FlawKind kind;
+  std::string text;  // the header or separator line
+  size_t seq_len = 0, qual_len = 0;
+};
+struct SeqChunk {
+  std::vector<uint8_t> bases;
+  std::vector<uint32_t> lens;
+  std::vector<Flaw> flaws;   // ascending by rec
+  uint64_t first_rec = 0;    // local index (within the file) of the chunk's first record
+};
+// how a file ended
+struct FileEnd {
+  int kind = 0;  // 0 clean EOF, 1 truncated record (missing line `role`), 2 read error (line `role`), 3 cannot open
+  int role = 0;
+};
 
-  void close_file() {
-    ra.shutdown();
-    if (f) gzclose(f);
-    if (fd >= 0) ::close(fd);
-    f = nullptr;
-    fd = -1;
-    have_block = false;
+// first failing check of validate_fastq_record on a record's four lines
+static bool find_flaw(const char *h, size_t hl, const char *sq, size_t sl, const char *sp, size_t spl, const char *q, size_t ql,
+                      uint64_t rec, Flaw *out) {
+  (void)sq;
+  (void)q;
+  if (hl && h[0] == '>') {
+    *out = Flaw{rec, FLAW_FASTA, std::string(), 0, 0};
+    return true;
   }
-  ~shk_fastq() { close_file(); }
+  if (!hl || h[0] != '@') {
+    *out = Flaw{rec, FLAW_HEADER, std::string(h, hl), 0, 0};
+    return true;
+  }
+  if (!spl || sp[0] != '+') {
+    *out = Flaw{rec, FLAW_SEP, std::string(sp, spl), 0, 0};
+    return true;
+  }
+  if (ql != sl) {
+    *out = Flaw{rec, FLAW_LEN, std::string(), sl, ql};
+    return true;
+  }
+  return false;
+}
 
-  // BufRead::lines(): split on '\n', strip one trailing '\r'.  1 = line, 0 = EOF, -1 = I/O error.
-  // keep = false: the line's text is not needed (header / separator / quality of a record that is
-  // not validated, io.rs:321-332), only that it exists.
-  int next_line(std::string &out, bool keep = true) {
-    out.clear();
-    bool got_any = false;
+struct Producer {
+  std::string path, name;  // name: what error messages call it ("stdin" for "-")
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<SeqChunk> q;
+  size_t q_bytes = 0;
+  bool finished = false, cancel = false;
+  FileEnd end;
+  static constexpr size_t Q_MAX = 384u << 20;  // bases buffered ahead per file
+
+  void push(SeqChunk &&c) {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return cancel || q_bytes < Q_MAX; });
+    if (cancel) return;
+    q_bytes += c.bases.size() + c.lens.size() * 4;
+    q.emplace_back(std::move(c));
+    cv.notify_all();
+  }
+  void finish(FileEnd e) {
+    std::lock_guard<std::mutex> lk(m);
+    end = e;
+    finished = true;
+    cv.notify_all();
+  }
+  bool cancelled() {
+    std::lock_guard<std::mutex> lk(m);
+    return cancel;
+  }
+
+  // ---- gzip / stdin / anything zlib reads: one thread, inflate + line split ------------------------------
+  void run_stream() {
+    gzFile f = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+    if (!f) return finish(FileEnd{3, 0});
+    gzbuffer(f, 1 << 20);
+    std::vector<char> buf(4u << 20);
+    std::string line[4];
+    int li = 0;           // which line of the record is being assembled
+    bool partial = false;  // line[li] holds the beginning of an unterminated line
+    uint64_t rec = 0;
+    SeqChunk c;
+    c.first_rec = 0;
+    auto flush = [&]() {
+      if (!c.lens.empty()) {
+        SeqChunk out = std::move(c);
+        c = SeqChunk();
+        c.first_rec = rec;
+        push(std::move(out));
+      }
+    };
+    auto end_line = [&](bool strip_cr) {
+      std::string &l = line[li];
+      if (strip_cr && !l.empty() && l.back() == '\r') l.pop_back();
+      if (li == 3) {
+        Flaw fl;
+        if (find_flaw(line[0].data(), line[0].size(), line[1].data(), line[1].size(), line[2].data(), line[2].size(),
+                      line[3].data(), line[3].size(), rec, &fl))
+          c.flaws.emplace_back(std::move(fl));
+        c.bases.insert(c.bases.end(), line[1].begin(), line[1].end());
+        c.lens.push_back((uint32_t)line[1].size());
+        ++rec;
+        for (auto &x : line) x.clear();
+        li = 0;
+        if (c.bases.size() >= (8u << 20)) flush();
+      } else {
+        ++li;
+      }
+      partial = false;
+    };
     for (;;) {
-      if (buf_pos == buf_len) {
-        if (file_eof) break;
-        int n = 0;
-        buf = ra.next(have_block, &n);
-        have_block = true;
-        if (n < 0) return -1;
-        if (n == 0) {
-          file_eof = true;
-          buf_pos = buf_len = 0;
+      if (cancelled()) break;
+      const int n = gzread(f, buf.data(), (unsigned)buf.size());
+      if (n < 0) {
+        flush();
+        gzclose(f);
+        return finish(FileEnd{2, li});
+      }
+      if (n == 0) break;
+      const char *p = buf.data(), *e = p + n;
+      while (p < e) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+        if (!nl) {
+          line[li].append(p, (size_t)(e - p));
+          partial = true;
           break;
         }
-        buf_pos = 0;
-        buf_len = (size_t)n;
+        line[li].append(p, (size_t)(nl - p));
+        p = nl + 1;
+        end_line(true);
       }
-      const char *p = buf + buf_pos;
-      const char *nl = (const char *)memchr(p, '\n', buf_len - buf_pos);
-      if (nl) {
-        if (keep) {
-          out.append(p, nl - p);
-          if (!out.empty() && out.back() == '\r') out.pop_back();
+    }
+    gzclose(f);
+    if (partial) end_line(false);  // a last line without '\n' is a line (BufRead::lines); its '\r', if any, stays
+    flush();
+    finish(li == 0 ? FileEnd{0, 0} : FileEnd{1, li});
+  }
+
+  // ---- plain files: mmap + parallel parse -----------------------------------------------------------------
+  void run_plain(int fd, Pool *pool, uint32_t T) {
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+      ::close(fd);
+      return finish(FileEnd{3, 0});
+    }
+    const size_t size = (size_t)st.st_size;
+    if (size == 0) {
+      ::close(fd);
+      return finish(FileEnd{0, 0});
+    }
+    const char *data = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (data == MAP_FAILED) {  // (a pipe or a special file: the stream reader takes it)
+      ::close(fd);
+      return run_stream();
+    }
+    (void)madvise((void *)data, size, MADV_SEQUENTIAL);
+    size_t WINDOW = 128u << 20;
+    if (const char *wk = getenv("SHK_FASTQ_WINDOW_KB")) WINDOW = std::max<size_t>(1, (size_t)atoll(wk)) << 10;  // test hook
+    size_t pos = 0;       // start of the first line not yet delivered (a record boundary)
+    uint64_t rec = 0;     // local index of the record that starts at pos
+    FileEnd fe{0, 0};
+    std::vector<std::vector<uint32_t>> nlp(T);  // newline positions (relative to pos) per share
+    while (pos < size && !cancelled()) {
+      const size_t wend = std::min(size, pos + WINDOW);
+      const size_t wlen = wend - pos;
+      // 1. newline positions, one share of the window per thread
+      pool->parallel_for(T, [&](uint32_t t) {
+        const size_t a = wlen * t / T, b = wlen * (t + 1) / T;
+        auto &v = nlp[t];
+        v.clear();
+        const char *p = data + pos + a, *e = data + pos + b;
+        while (p < e) {
+          const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+          if (!nl) break;
+          v.push_back((uint32_t)(nl - (data + pos)));
+          p = nl + 1;
         }
-        buf_pos += (size_t)(nl - p) + 1;
-        return 1;
+      });
+      std::vector<size_t> first(T + 1, 0);
+      for (uint32_t t = 0; t < T; ++t) first[t + 1] = first[t] + nlp[t].size();
+      size_t M = first[T];  // complete ('\n'-terminated) lines in the window
+      std::vector<uint32_t> NL(M + 1);
+      pool->parallel_for(T, [&](uint32_t t) {
+        if (!nlp[t].empty()) memcpy(NL.data() + first[t], nlp[t].data(), nlp[t].size() * 4);
+      });
+      bool last_unterminated = false;
+      if (wend == size && (M == 0 ? wlen > 0 : (size_t)NL[M - 1] + 1 < wlen)) {  // a last line without '\n' (it has ≥ 1 byte)
+        NL[M] = (uint32_t)wlen;
+        ++M;
+        last_unterminated = true;
       }
-      if (keep) out.append(p, buf_len - buf_pos);
-      got_any = got_any || buf_len > buf_pos;
-      buf_pos = buf_len;
+      const size_t R = M / 4;  // whole records in the window
+      if (R == 0 && wend < size) {  // a record longer than the window: look at a longer stretch
+        WINDOW *= 2;
+        continue;
+      }
+      // line ℓ = [ℓ ? NL[ℓ-1]+1 : 0, NL[ℓ]) relative to pos, '\r' stripped (not from an unterminated last line)
+      auto line_at = [&](size_t l, const char **p, size_t *len) {
+        const size_t s0 = l ? (size_t)NL[l - 1] + 1 : 0, s1 = NL[l];
+        size_t n = s1 - s0;
+        const bool strip = !(last_unterminated && l == M - 1);
+        if (strip && n && data[pos + s1 - 1] == '\r') --n;
+        *p = data + pos + s0;
+        *len = n;
+      };
+      SeqChunk c;
+      c.first_rec = rec;
+      c.lens.resize(R);
+      std::vector<std::vector<Flaw>> fl(T);
+      std::vector<size_t> share_bases(T + 1, 0);
+      // 2. sequence lengths + flaws, records shared out evenly
+      pool->parallel_for(T, [&](uint32_t t) {
+        const size_t r0 = R * t / T, r1 = R * (t + 1) / T;
+        size_t tot = 0;
+        for (size_t r = r0; r < r1; ++r) {
+          const char *h, *sq, *sp, *ql;
+          size_t hl, sl, spl, qll;
+          line_at(4 * r, &h, &hl);
+          line_at(4 * r + 1, &sq, &sl);
+          line_at(4 * r + 2, &sp, &spl);
+          line_at(4 * r + 3, &ql, &qll);
+          c.lens[r] = (uint32_t)sl;
+          tot += sl;
+          Flaw f;
+          if (find_flaw(h, hl, sq, sl, sp, spl, ql, qll, rec + r, &f)) fl[t].emplace_back(std::move(f));
+        }
+        share_bases[t + 1] = tot;
+      });
+      for (uint32_t t = 0; t < T; ++t) share_bases[t + 1] += share_bases[t];
+      c.bases.resize(share_bases[T]);
+      // 3. the sequences, copied out in parallel
+      pool->parallel_for(T, [&](uint32_t t) {
+        const size_t r0 = R * t / T, r1 = R * (t + 1) / T;
+        uint8_t *o = c.bases.data() + share_bases[t];
+        for (size_t r = r0; r < r1; ++r) {
+          const char *sq;
+          size_t sl;
+          line_at(4 * r + 1, &sq, &sl);
+          memcpy(o, sq, sl);
+          o += sl;
+        }
+      });
+      for (uint32_t t = 0; t < T; ++t)
+        for (auto &f : fl[t]) c.flaws.emplace_back(std::move(f));
+      rec += R;
+      if (R) push(std::move(c));
+      if (wend == size) {
+        if (M % 4) fe = FileEnd{1, (int)(M % 4)};  // the file ends inside a record
+        pos = size;
+      } else {
+        pos += (size_t)NL[4 * R - 1] + 1;
+      }
     }
-    if (!out.empty() || got_any) return 1;  // last line without newline
-    return 0;
+    munmap((void *)data, size);
+    ::close(fd);
+    finish(fe);
   }
+};
 
-  int open_next() {  // open_fastq_reader, io.rs:598-625 (gzread passes plain files through)
-    close_file();
-    if (file_idx >= paths.size()) return 0;
-    cur_name = paths[file_idx++];
-    if (cur_name != "-") {  // a file that does not start with the gzip magic is read directly
-      fd = ::open(cur_name.c_str(), O_RDONLY);
-      unsigned char magic[2] = {0, 0};
-      if (fd >= 0 && (::pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b))) {
-        ::close(fd);
-        fd = -1;
+}  // namespace
+
+struct shk_fastq {
+  std::vector<std::string> paths;
+  std::vector<std::unique_ptr<Producer>> prod;  // one per path; started up to LOOKAHEAD files ahead of the consumer
+  size_t file_idx = 0;        // the file being consumed
+  size_t started = 0;         // producers started so far
+  std::unique_ptr<Pool> pool;
+  uint32_t T = 1;
+  SeqChunk cur;               // the chunk being handed out
+  bool have_cur = false;
+  size_t cur_seq = 0, cur_byte = 0, cur_flaw = 0;
+  uint64_t file_rec = 0;      // local index of the next record of the current file
+  uint64_t max_reads = 0, validate_every = 0;
+  uint64_t n_reads_read = 0, n_bases_read = 0;  // FastqReadState, io.rs:205-206
+  bool reached_max = false, done = false;
+  std::string err;
+  int err_code = 0;
+  static constexpr size_t LOOKAHEAD = 8;
+
+  ~shk_fastq() { stop_all(); }
+  void stop_all() {
+    for (auto &p : prod)
+      if (p) {
+        {
+          std::lock_guard<std::mutex> lk(p->m);
+          p->cancel = true;
+        }
+        p->cv.notify_all();
       }
-    }
-    if (fd < 0) {
-      f = cur_name == "-" ? gzdopen(0, "rb") : gzopen(cur_name.c_str(), "rb");
-      if (!f) {
-        err = fmt("Failed to open file: %s", cur_name.c_str());
-        err_code = SHK_ERR_IO;
-        return -1;
-      }
-      gzbuffer(f, 1 << 20);
-    }
-    buf_pos = buf_len = 0;
-    file_eof = false;
-    ra.start(f, fd);
-    if (cur_name == "-") cur_name = "stdin";
-    return 1;
+    for (auto &p : prod)
+      if (p && p->th.joinable()) p->th.join();
   }
-
   int fail(int code, const std::string &m) {
     err = m;
     err_code = code;
     return code;
   }
-
-  // validate_fastq_record, io.rs:161-198
-  int validate() {
-    const unsigned long long rec = n_reads_read + 1;
-    const std::string &h = line[0], &sep = line[2];
-    if (!h.empty() && h[0] == '>')
-      return fail(SHK_ERR_FASTQ,
-                  fmt("Input appears to be FASTA format, not FASTQ (record %llu starts with '>'). "
-                      "sharkmer requires FASTQ input with quality scores.",
-                      rec));
-    if (h.empty() || h[0] != '@')
-      return fail(SHK_ERR_FASTQ, fmt("FASTQ record %llu has invalid header (expected '@', got '%c'): %s", rec,
-                                     h.empty() ? ' ' : h[0], h.c_str()));
-    if (sep.empty() || sep[0] != '+')
-      return fail(SHK_ERR_FASTQ,
-                  fmt("FASTQ record %llu has invalid separator line (expected '+', got '%c'): %s", rec,
-                      sep.empty() ? ' ' : sep[0], sep.c_str()));
-    if (line[3].size() != line[1].size())
-      return fail(SHK_ERR_FASTQ, fmt("FASTQ record %llu has mismatched sequence (%zu) and quality (%zu) lengths",
-                                     rec, line[1].size(), line[3].size()));
-    return SHK_OK;
-  }
-
-  // One record into line[0..3].  1 = record, 0 = end of this file, <0 = error
-  int next_record() {
-    // io.rs:321-332: only record 0 and every validate_every-th are looked at beyond their sequence
-    const bool keep = n_reads_read == 0 || (validate_every > 0 && n_reads_read % validate_every == 0);
-    int g = next_line(line[0], keep);
-    if (g == 0) return 0;
-    static const char *role[4] = {"header", "sequence", "separator", "quality"};
-    if (g < 0)
-      return fail(SHK_ERR_IO, fmt("Failed to read %s line of record %llu in %s", role[0],
-                                  (unsigned long long)n_reads_read + 1, cur_name.c_str()));
-    for (int i = 1; i < 4; ++i) {
-      g = next_line(line[i], keep || i == 1);
-      if (g == 0)  // io.rs:291-317
-        return fail(SHK_ERR_FASTQ, fmt("Truncated FASTQ record at record %llu in %s: missing %s line",
-                                       (unsigned long long)n_reads_read + 1, cur_name.c_str(), role[i]));
-      if (g < 0)
-        return fail(SHK_ERR_IO, fmt("Failed to read %s line of record %llu in %s", role[i],
-                                    (unsigned long long)n_reads_read + 1, cur_name.c_str()));
+  void start_producers() {
+    if (!pool) {
+      T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+      pool.reset(new Pool(T));
     }
-    return 1;
+    // plain files go through the shared pool one after the other (each is parsed at memory speed); streams
+    // get a thread each and run ahead
+    while (started < paths.size() && started < file_idx + LOOKAHEAD) {
+      auto p = std::make_unique<Producer>();
+      p->path = paths[started];
+      p->name = p->path == "-" ? "stdin" : p->path;
+      Producer *pp = p.get();
+      int fd = -1;
+      if (pp->path != "-") {  // a file that does not start with the gzip magic is read directly (open_fastq_reader, io.rs:598-625)
+        fd = ::open(pp->path.c_str(), O_RDONLY);
+        unsigned char magic[2] = {0, 0};
+        struct stat st;
+        const bool regular = fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+        if (fd >= 0 && (!regular || (st.st_size >= 2 && (::pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b))))) {
+          ::close(fd);
+          fd = -1;
+        }
+      }
+      if (fd >= 0) {
+        // (plain files share the pool: a second one starts when the first is done — the pool is not re-entrant)
+        Producer *prev = plain_tail;
+        plain_tail = pp;
+        Pool *pl = pool.get();
+        const uint32_t t = T;
+        pp->th = std::thread([pp, prev, fd, pl, t] {
+          if (prev) {
+            std::unique_lock<std::mutex> lk(prev->m);
+            prev->cv.wait(lk, [&] { return prev->finished || prev->cancel; });
+          }
+          pp->run_plain(fd, pl, t);
+        });
+      } else {
+        pp->th = std::thread([pp] { pp->run_stream(); });
+      }
+      prod.emplace_back(std::move(p));
+      ++started;
+    }
+  }
+  Producer *plain_tail = nullptr;
+
+  // next chunk of the current file into `cur`; 1 = got one, 0 = file finished (its end is in *fe)
+  int next_chunk(FileEnd *fe) {
+    Producer *p = prod[file_idx].get();
+    std::unique_lock<std::mutex> lk(p->m);
+    p->cv.wait(lk, [&] { return !p->q.empty() || p->finished; });
+    if (!p->q.empty()) {
+      cur = std::move(p->q.front());
+      p->q.pop_front();
+      p->q_bytes -= cur.bases.size() + cur.lens.size() * 4;
+      p->cv.notify_all();
+      have_cur = true;
+      cur_seq = cur_byte = cur_flaw = 0;
+      return 1;
+    }
+    *fe = p->end;
+    return 0;
+  }
+  // validate_fastq_record's message for a flaw, with the GLOBAL record number (io.rs:161-198)
+  int raise(const Flaw &f) {
+    const unsigned long long rec = n_reads_read + 1;
+    switch (f.kind) {
+      case FLAW_FASTA:
+        return fail(SHK_ERR_FASTQ, fmt("Input appears to be FASTA format, not FASTQ (record %llu starts with '>'). "
+                                       "sharkmer requires FASTQ input with quality scores.", rec));
+      case FLAW_HEADER:
+        return fail(SHK_ERR_FASTQ, fmt("FASTQ record %llu has invalid header (expected '@', got '%c'): %s", rec,
+                                       f.text.empty() ? ' ' : f.text[0], f.text.c_str()));
+      case FLAW_SEP:
+        return fail(SHK_ERR_FASTQ, fmt("FASTQ record %llu has invalid separator line (expected '+', got '%c'): %s", rec,
+                                       f.text.empty() ? ' ' : f.text[0], f.text.c_str()));
+      default:
+        return fail(SHK_ERR_FASTQ, fmt("FASTQ record %llu has mismatched sequence (%zu) and quality (%zu) lengths", rec,
+                                       f.seq_len, f.qual_len));
+    }
   }
 };
 
@@ -287,7 +515,7 @@ int shk_fastq_stats(const shk_fastq *r, uint64_t *n_reads_read, uint64_t *n_base
   if (n_reads_read) *n_reads_read = r->n_reads_read;
   if (n_bases_read) *n_bases_read = r->n_bases_read;
   if (reached_max) *reached_max = r->reached_max;
-  if (done) *done = r->done && !r->pending;
+  if (done) *done = r->done;
   return SHK_OK;
 }
 
@@ -300,48 +528,62 @@ int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint6
   *n_seqs = 0;
   offsets[0] = 0;
   if (r->err_code) return r->err_code;
+  static const char *role[4] = {"header", "sequence", "separator", "quality"};
   uint64_t used = 0, n = 0;
   while (!r->done && n < max_seqs) {
-    if (!r->f && r->fd < 0 && !r->pending) {
-      int o = r->open_next();
-      if (o < 0) return r->err_code;
-      if (o == 0) {
-        r->done = true;
-        break;
-      }
-    }
-    if (!r->pending) {
-      int g = r->next_record();
-      if (g < 0) return g;
-      if (g == 0) {  // this file is exhausted; state persists into the next one (io.rs:498-512)
-        r->close_file();
-        continue;
-      }
-      // io.rs:321-332
-      const bool should_validate =
-          r->n_reads_read == 0 || (r->validate_every > 0 && r->n_reads_read % r->validate_every == 0);
-      if (should_validate) {
-        int v = r->validate();
-        if (v != SHK_OK) return v;
-      }
-    }
-    const std::string &seq = r->line[1];
-    if (seq.size() > bases_cap) return r->fail(SHK_ERR_BAD_ARG, "sequence longer than the batch buffer");
-    if (used + seq.size() > bases_cap) {  // does not fit: deliver it first thing next call
-      r->pending = true;
+    if (r->file_idx >= r->paths.size()) {
+      r->done = true;
       break;
     }
-    r->pending = false;
-    memcpy(bases + used, seq.data(), seq.size());
-    used += seq.size();
-    offsets[++n] = used;
-    r->n_bases_read += seq.size();  // io.rs:335 (N included)
-    r->n_reads_read += 1;           // io.rs:337
-    if (r->max_reads > 0 && r->n_reads_read >= r->max_reads) {  // io.rs:345-348
-      r->reached_max = true;
-      r->done = true;
+    r->start_producers();
+    if (!r->have_cur) {
+      FileEnd fe;
+      if (r->next_chunk(&fe) == 0) {  // this file is exhausted; state persists into the next one (io.rs:498-512)
+        Producer *p = r->prod[r->file_idx].get();
+        if (fe.kind == 3) return r->fail(SHK_ERR_IO, fmt("Failed to open file: %s", p->path.c_str()));
+        if (fe.kind == 1)  // io.rs:291-317
+          return r->fail(SHK_ERR_FASTQ, fmt("Truncated FASTQ record at record %llu in %s: missing %s line",
+                                             (unsigned long long)r->n_reads_read + 1, p->name.c_str(), role[fe.role]));
+        if (fe.kind == 2)
+          return r->fail(SHK_ERR_IO, fmt("Failed to read %s line of record %llu in %s", role[fe.role],
+                                         (unsigned long long)r->n_reads_read + 1, p->name.c_str()));
+        if (p->th.joinable()) p->th.join();
+        ++r->file_idx;
+        r->file_rec = 0;
+        continue;
+      }
+    }
+    // hand out what fits of the current chunk
+    SeqChunk &c = r->cur;
+    while (r->cur_seq < c.lens.size() && n < max_seqs) {
+      const uint64_t len = c.lens[r->cur_seq];
+      // io.rs:321-332: record 0 and every validate_every-th are validated — by global record index
+      const bool cadence = r->n_reads_read == 0 || (r->validate_every > 0 && r->n_reads_read % r->validate_every == 0);
+      const uint64_t local = c.first_rec + r->cur_seq;
+      while (r->cur_flaw < c.flaws.size() && c.flaws[r->cur_flaw].rec < local) ++r->cur_flaw;
+      if (cadence && r->cur_flaw < c.flaws.size() && c.flaws[r->cur_flaw].rec == local) return r->raise(c.flaws[r->cur_flaw]);
+      if (len > bases_cap) return r->fail(SHK_ERR_BAD_ARG, "sequence longer than the batch buffer");
+      if (used + len > bases_cap) goto full;  // does not fit: it is delivered first thing next call
+      memcpy(bases + used, c.bases.data() + r->cur_byte, len);
+      used += len;
+      r->cur_byte += len;
+      ++r->cur_seq;
+      offsets[++n] = used;
+      r->n_bases_read += len;  // io.rs:335 (N included)
+      r->n_reads_read += 1;    // io.rs:337
+      if (r->max_reads > 0 && r->n_reads_read >= r->max_reads) {  // io.rs:345-348
+        r->reached_max = true;
+        r->done = true;
+        r->stop_all();
+        goto full;
+      }
+    }
+    if (r->cur_seq >= c.lens.size()) {
+      r->have_cur = false;
+      r->cur = SeqChunk();
     }
   }
+full:
   *n_seqs = n;
   return SHK_OK;
 }

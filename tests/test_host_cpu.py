@@ -122,6 +122,68 @@ def test_validate_every(orc, tmp_path):
     assert len(offs) - 1 == 6
 
 
+def _ragged_fastq(rng, n, crlf_every=0, last_newline=True):
+    recs, seqs = [], []
+    for i in range(n):
+        L = int(rng.integers(0, 300))
+        seq = "".join(rng.choice(list("ACGTN"), size=L, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        eol = "\r\n" if crlf_every and i % crlf_every == 0 else "\n"
+        recs.append(f"@read{i} some description{eol}{seq}{eol}+{eol}{'I' * L}{eol}")
+        seqs.append(seq)
+    text = "".join(recs)
+    if not last_newline:
+        text = text[:-1]
+    return text, seqs
+
+
+@pytest.mark.parametrize("window_kb,last_newline", [(64, True), (3, True), (64, False), (0, True)])
+def test_parallel_plain_parse_equals_sequential_semantics(tmp_path, monkeypatch, window_kb, last_newline):
+    """Plain files are parsed in windows by a pool of threads (newline scan per share, prefix sum of line
+    numbers, parallel copy-out): the sequences, their order and the counters must be what the line-by-line
+    reader gives — windows of 64 KiB and 3 KiB here, so records straddle shares and windows; CRLF every
+    7th record; an unterminated last line."""
+    if window_kb:
+        monkeypatch.setenv("SHK_FASTQ_WINDOW_KB", str(window_kb))
+    rng = np.random.default_rng(window_kb + 1)
+    text, seqs = _ragged_fastq(rng, 6_000, crlf_every=7, last_newline=last_newline)
+    if not last_newline and seqs[-1] == "":   # (an empty unterminated last line is no line at all)
+        pytest.skip("degenerate tail")
+    p = _tmp(tmp_path, "ragged.fastq", text)
+    bases, offs, st = read_all([p])
+    got = [bases[int(offs[i]):int(offs[i + 1])].tobytes().decode() for i in range(len(offs) - 1)]
+    assert got == seqs
+    assert st["n_reads_read"] == len(seqs) and st["n_bases_read"] == sum(len(x) for x in seqs)
+
+
+def test_later_streams_run_ahead_but_order_and_errors_stay_sequential(tmp_path, monkeypatch):
+    """Five inputs — gzip, plain, gzip, gzip, plain — are produced concurrently and consumed in order; a flaw
+    in the fourth file surfaces with the GLOBAL record number and only if the cadence reaches it."""
+    monkeypatch.setenv("SHK_FASTQ_WINDOW_KB", "16")
+    rng = np.random.default_rng(5)
+    paths, all_seqs = [], []
+    for i in range(5):
+        text, seqs = _ragged_fastq(rng, 900 + 37 * i)
+        paths.append(_tmp(tmp_path, f"f{i}.fastq" + ("" if i in (1, 4) else ".gz"), text, gz=i not in (1, 4)))
+        all_seqs += seqs
+    bases, offs, st = read_all(paths)
+    got = [bases[int(offs[i]):int(offs[i + 1])].tobytes().decode() for i in range(len(offs) - 1)]
+    assert got == all_seqs and st["n_reads_read"] == len(all_seqs)
+    _, offs, st = read_all(paths, max_reads=2_000)   # stops inside the third file; the producers are cancelled
+    assert st["n_reads_read"] == 2_000 and st["reached_max"]
+    # a record with a short quality line in the fourth file: global index 900 + 937 + 974 + 5 = 2816
+    text, _ = _ragged_fastq(np.random.default_rng(9), 300)
+    lines = text.split("\n")
+    lines[4 * 5 + 1] = "ACGTACGT"
+    lines[4 * 5 + 3] = "III"
+    bad = _tmp(tmp_path, "bad.fastq.gz", "\n".join(lines), gz=True)
+    paths2 = paths[:3] + [bad] + paths[4:]
+    read_all(paths2)                                   # cadence: record 0 only → not looked at
+    with pytest.raises(sa.ShkError) as e:
+        read_all(paths2, validate_every=2816)
+    assert "FASTQ record 2817 has mismatched sequence (8) and quality (3) lengths" in e.value.msg
+    read_all(paths2, validate_every=2815)              # 2815 and 5630 are fine records
+
+
 def test_empty_file_yields_no_reads(tmp_path):
     p = _tmp(tmp_path, "empty.fastq", "")
     _, offs, st = read_all([p])
@@ -218,3 +280,11 @@ def test_cli_rejects_bad_arguments_before_touching_the_gpu():
     assert r.returncode == 1 and "--sample is required" in r.stderr
     r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
     assert r.returncode == 2
+
+
+def test_record_longer_than_a_parse_window(tmp_path, monkeypatch):
+    monkeypatch.setenv("SHK_FASTQ_WINDOW_KB", "1")
+    seqs = ["ACGT" * 700, "TTGCA" * 900, "A" * 10]
+    p = _tmp(tmp_path, "wide.fastq", "".join(f"@r\n{s}\n+\n{'I' * len(s)}\n" for s in seqs))
+    bases, offs, _ = read_all([p])
+    assert [bases[int(offs[i]):int(offs[i + 1])].tobytes().decode() for i in range(3)] == seqs
