@@ -154,11 +154,12 @@ def extras(sa, torch, dev):
     # ---- (iii) FASTQ(.gz) file → histogram + output files (shk_run_files), host parse inclusive --------
     def file_path():
         import gzip
-        n = 2_000_000
+        n = 8_000_000
         spec = sa.SynthSpec(genome_len=3_000_000, read_len=L)
         with sa.KmerEngine(21, 1, 10000, device=dev, capacity_hint=3_000_000) as eng:
             db, _ = device_reads(eng, spec, 0, n)
             bases = db.cpu().numpy()
+            del db
         tmp = tempfile.mkdtemp(prefix="shk_bench_")
         rec = np.empty((n, 2 * L + 7), dtype=np.uint8)  # "@r\n" + seq + "\n+\n" + qual + "\n"
         rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
@@ -168,22 +169,24 @@ def extras(sa, torch, dev):
         rec[:, 6 + 2 * L] = ord("\n")
         plain = os.path.join(tmp, "reads.fastq")
         rec.tofile(plain)
-        half = n // 2 * (2 * L + 7)
         parts = []
-        for i, (a, b) in enumerate(((0, half), (half, n * (2 * L + 7)))):  # two gzip members files: the multi-file case
+        NP = 8
+        for i in range(NP):  # eight gzip files: the multi-file case (one inflate thread per stream, later streams run ahead)
+            a, b = n * i // NP * (2 * L + 7), n * (i + 1) // NP * (2 * L + 7)
             pth = os.path.join(tmp, f"part{i}.fastq.gz")
             with gzip.open(pth, "wb", compresslevel=1) as g:
                 g.write(rec.reshape(-1)[a:b].tobytes())
             parts.append(pth)
-        res = {"workload": f"{n} reads x {L} bp as FASTQ on local disk → shk_run_files (parse + count + .histo/.stats.yaml)"}
-        for name, paths in (("plain", [plain]), ("gzip_2_files", parts)):
+        res = {"workload": f"{n} reads x {L} bp as FASTQ in the page cache → shk_run_files (parse + count + .histo/.stats.yaml), best of 2"}
+        for name, paths in (("plain", [plain]), ("gzip_8_files", parts), ("gzip_1_file", parts[:1])):
             best = None
             for _ in range(2):
                 t0 = time.perf_counter()
                 sa.run_files(paths, k=21, chunks=1, histo_max=10000, sample="s", outdir=tmp, capacity_hint=3_000_000)
                 dt = time.perf_counter() - t0
                 best = dt if best is None else min(best, dt)
-            res[name] = {"Gbases_per_s": round(n * L / best / 1e9, 3), "file_MB": round(sum(os.path.getsize(p_) for p_ in paths) / 1e6, 1),
+            nn = n if name != "gzip_1_file" else n // NP
+            res[name] = {"Gbases_per_s": round(nn * L / best / 1e9, 3), "file_MB": round(sum(os.path.getsize(p_) for p_ in paths) / 1e6, 1),
                          "bound": "host: read + inflate + line split"}
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)

@@ -24,6 +24,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -99,8 +101,10 @@ struct Pool {  // a small persistent pool: parallel_for over [0, n)
       if (--running == 0 && next >= n_jobs) cv_done.notify_all();
     }
   }
+  std::mutex use;  // one parallel_for at a time (the file producers and the consumer share the pool)
   void parallel_for(uint32_t n, std::function<void(uint32_t)> f) {
     if (n == 0) return;
+    std::lock_guard<std::mutex> only(use);
     std::unique_lock<std::mutex> lk(m);
     job = std::move(f);
     n_jobs = n;
@@ -119,10 +123,25 @@ struct Flaw {  // what validate_fastq_record (io.rs:161-198) would say about loc
   size_t seq_len = 0, qual_len = 0;
 };
 struct SeqChunk {
-  std::vector<uint8_t> bases;
+  std::vector<uint8_t> bases;  // stream producers: the sequences back to back
+  // plain-file producers hand on no copy of the sequences, only where they lie in the mapped file: line ℓ of
+  // the window is [ℓ ? nl[ℓ-1]+1 : 0, nl[ℓ]) from `src` on, record r's sequence line ℓ = 4r+1; the consumer's
+  // thread pool copies them straight into the caller's batch buffer
+  const char *src = nullptr;
+  std::vector<uint32_t> nl;
+  bool last_unterminated = false;
   std::vector<uint32_t> lens;
   std::vector<Flaw> flaws;   // ascending by rec
   uint64_t first_rec = 0;    // local index (within the file) of the chunk's first record
+  size_t bytes() const { return bases.size() + lens.size() * 4 + nl.size() * 4; }
+  void seq_line(size_t r, const char **p, size_t *len) const {
+    const size_t l = 4 * r + 1;
+    const size_t s0 = (size_t)nl[l - 1] + 1, s1 = nl[l];
+    size_t n = s1 - s0;
+    if (!(last_unterminated && l == nl.size() - 1) && n && src[s1 - 1] == '\r') --n;
+    *p = src + s0;
+    *len = n;
+  }
 };
 // how a file ended
 struct FileEnd {
@@ -163,13 +182,20 @@ struct Producer {
   size_t q_bytes = 0;
   bool finished = false, cancel = false;
   FileEnd end;
-  static constexpr size_t Q_MAX = 384u << 20;  // bases buffered ahead per file
+  static constexpr size_t Q_MAX = 384u << 20;  // bytes buffered ahead per file
+  const char *map = nullptr;  // plain files: the mapping the chunks point into (released with the producer)
+  size_t map_size = 0;
+  int map_fd = -1;
+  ~Producer() {
+    if (map) munmap((void *)map, map_size);
+    if (map_fd >= 0) ::close(map_fd);
+  }
 
   void push(SeqChunk &&c) {
     std::unique_lock<std::mutex> lk(m);
     cv.wait(lk, [&] { return cancel || q_bytes < Q_MAX; });
     if (cancel) return;
-    q_bytes += c.bases.size() + c.lens.size() * 4;
+    q_bytes += c.bytes();
     q.emplace_back(std::move(c));
     cv.notify_all();
   }
@@ -269,34 +295,50 @@ struct Producer {
       return run_stream();
     }
     (void)madvise((void *)data, size, MADV_SEQUENTIAL);
+    map = data;
+    map_size = size;
+    map_fd = fd;
     size_t WINDOW = 128u << 20;
     if (const char *wk = getenv("SHK_FASTQ_WINDOW_KB")) WINDOW = std::max<size_t>(1, (size_t)atoll(wk)) << 10;  // test hook
     size_t pos = 0;       // start of the first line not yet delivered (a record boundary)
     uint64_t rec = 0;     // local index of the record that starts at pos
     FileEnd fe{0, 0};
-    std::vector<std::vector<uint32_t>> nlp(T);  // newline positions (relative to pos) per share
     while (pos < size && !cancelled()) {
       const size_t wend = std::min(size, pos + WINDOW);
       const size_t wlen = wend - pos;
-      // 1. newline positions, one share of the window per thread
+      const bool dbg = getenv("SHK_FASTQ_DEBUG") != nullptr;
+      auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+      const double t_a = now();
+      // 1. newline positions: every share of the window is scanned twice — counted, then, its place among all the
+      // lines known from a prefix sum, written straight into the window's line table
+      std::vector<size_t> first(T + 1, 0);
       pool->parallel_for(T, [&](uint32_t t) {
-        const size_t a = wlen * t / T, b = wlen * (t + 1) / T;
-        auto &v = nlp[t];
-        v.clear();
-        const char *p = data + pos + a, *e = data + pos + b;
+        const char *p = data + pos + wlen * t / T, *e = data + pos + wlen * (t + 1) / T;
+        size_t cnt = 0;
         while (p < e) {
           const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
           if (!nl) break;
-          v.push_back((uint32_t)(nl - (data + pos)));
+          ++cnt;
           p = nl + 1;
         }
+        first[t + 1] = cnt;
       });
-      std::vector<size_t> first(T + 1, 0);
-      for (uint32_t t = 0; t < T; ++t) first[t + 1] = first[t] + nlp[t].size();
+      const double t_b = now();
+      for (uint32_t t = 0; t < T; ++t) first[t + 1] += first[t];
       size_t M = first[T];  // complete ('\n'-terminated) lines in the window
-      std::vector<uint32_t> NL(M + 1);
+      std::vector<uint32_t> NL;
+      NL.reserve(M + 1);
+      NL.resize(M + 1);     // (value-initialised by one thread: 4 B per line, ≈ 5 % of the window's bytes)
       pool->parallel_for(T, [&](uint32_t t) {
-        if (!nlp[t].empty()) memcpy(NL.data() + first[t], nlp[t].data(), nlp[t].size() * 4);
+        const char *base = data + pos;
+        const char *p = base + wlen * t / T, *e = base + wlen * (t + 1) / T;
+        uint32_t *o = NL.data() + first[t];
+        while (p < e) {
+          const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+          if (!nl) break;
+          *o++ = (uint32_t)(nl - base);
+          p = nl + 1;
+        }
       });
       bool last_unterminated = false;
       if (wend == size && (M == 0 ? wlen > 0 : (size_t)NL[M - 1] + 1 < wlen)) {  // a last line without '\n' (it has ≥ 1 byte)
@@ -318,15 +360,14 @@ struct Producer {
         *p = data + pos + s0;
         *len = n;
       };
+      const double t_c = now();
       SeqChunk c;
       c.first_rec = rec;
       c.lens.resize(R);
       std::vector<std::vector<Flaw>> fl(T);
-      std::vector<size_t> share_bases(T + 1, 0);
-      // 2. sequence lengths + flaws, records shared out evenly
+      // 2. sequence lengths + flaws, records shared out evenly (the sequences themselves stay where they are)
       pool->parallel_for(T, [&](uint32_t t) {
         const size_t r0 = R * t / T, r1 = R * (t + 1) / T;
-        size_t tot = 0;
         for (size_t r = r0; r < r1; ++r) {
           const char *h, *sq, *sp, *ql;
           size_t hl, sl, spl, qll;
@@ -335,39 +376,27 @@ struct Producer {
           line_at(4 * r + 2, &sp, &spl);
           line_at(4 * r + 3, &ql, &qll);
           c.lens[r] = (uint32_t)sl;
-          tot += sl;
           Flaw f;
           if (find_flaw(h, hl, sq, sl, sp, spl, ql, qll, rec + r, &f)) fl[t].emplace_back(std::move(f));
-        }
-        share_bases[t + 1] = tot;
-      });
-      for (uint32_t t = 0; t < T; ++t) share_bases[t + 1] += share_bases[t];
-      c.bases.resize(share_bases[T]);
-      // 3. the sequences, copied out in parallel
-      pool->parallel_for(T, [&](uint32_t t) {
-        const size_t r0 = R * t / T, r1 = R * (t + 1) / T;
-        uint8_t *o = c.bases.data() + share_bases[t];
-        for (size_t r = r0; r < r1; ++r) {
-          const char *sq;
-          size_t sl;
-          line_at(4 * r + 1, &sq, &sl);
-          memcpy(o, sq, sl);
-          o += sl;
         }
       });
       for (uint32_t t = 0; t < T; ++t)
         for (auto &f : fl[t]) c.flaws.emplace_back(std::move(f));
+      c.src = data + pos;
+      c.last_unterminated = last_unterminated;
+      const size_t next_pos = wend == size ? size : pos + (size_t)NL[4 * R - 1] + 1;
+      const size_t M_all = M;
+      NL.resize(4 * R);  // (only whole records' lines are handed on)
+      c.nl = std::move(NL);
+      if (c.last_unterminated && 4 * R != M_all) c.last_unterminated = false;  // the unterminated line is not among them
       rec += R;
+      const double t_d = now();
       if (R) push(std::move(c));
-      if (wend == size) {
-        if (M % 4) fe = FileEnd{1, (int)(M % 4)};  // the file ends inside a record
-        pos = size;
-      } else {
-        pos += (size_t)NL[4 * R - 1] + 1;
-      }
+      if (dbg) fprintf(stderr, "[fastq window %zu MB] scan %.1f ms  gather %.1f ms  lens %.1f ms  push(wait) %.1f ms\n", wlen >> 20,
+                       (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (t_d - t_c) * 1e3, (now() - t_d) * 1e3);
+      if (wend == size && (M_all % 4)) fe = FileEnd{1, (int)(M_all % 4)};  // the file ends inside a record
+      pos = next_pos;
     }
-    munmap((void *)data, size);
-    ::close(fd);
     finish(fe);
   }
 };
@@ -379,7 +408,7 @@ struct shk_fastq {
   std::vector<std::unique_ptr<Producer>> prod;  // one per path; started up to LOOKAHEAD files ahead of the consumer
   size_t file_idx = 0;        // the file being consumed
   size_t started = 0;         // producers started so far
-  std::unique_ptr<Pool> pool;
+  std::unique_ptr<Pool> pool, cpool;  // the producers' pool (window parse) and the consumer's (copy-out): they overlap
   uint32_t T = 1;
   SeqChunk cur;               // the chunk being handed out
   bool have_cur = false;
@@ -414,6 +443,7 @@ struct shk_fastq {
     if (!pool) {
       T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
       pool.reset(new Pool(T));
+      cpool.reset(new Pool(T));
     }
     // plain files go through the shared pool one after the other (each is parsed at memory speed); streams
     // get a thread each and run ahead
@@ -463,7 +493,7 @@ struct shk_fastq {
     if (!p->q.empty()) {
       cur = std::move(p->q.front());
       p->q.pop_front();
-      p->q_bytes -= cur.bases.size() + cur.lens.size() * 4;
+      p->q_bytes -= cur.bytes();
       p->cv.notify_all();
       have_cur = true;
       cur_seq = cur_byte = cur_flaw = 0;
@@ -555,6 +585,9 @@ int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint6
     }
     // hand out what fits of the current chunk
     SeqChunk &c = r->cur;
+    const size_t seq_begin = r->cur_seq;
+    const uint64_t n_begin = n;
+    bool stop = false;
     while (r->cur_seq < c.lens.size() && n < max_seqs) {
       const uint64_t len = c.lens[r->cur_seq];
       // io.rs:321-332: record 0 and every validate_every-th are validated — by global record index
@@ -563,8 +596,11 @@ int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint6
       while (r->cur_flaw < c.flaws.size() && c.flaws[r->cur_flaw].rec < local) ++r->cur_flaw;
       if (cadence && r->cur_flaw < c.flaws.size() && c.flaws[r->cur_flaw].rec == local) return r->raise(c.flaws[r->cur_flaw]);
       if (len > bases_cap) return r->fail(SHK_ERR_BAD_ARG, "sequence longer than the batch buffer");
-      if (used + len > bases_cap) goto full;  // does not fit: it is delivered first thing next call
-      memcpy(bases + used, c.bases.data() + r->cur_byte, len);
+      if (used + len > bases_cap) {  // does not fit: it is delivered first thing next call
+        stop = true;
+        break;
+      }
+      if (!c.src) memcpy(bases + used, c.bases.data() + r->cur_byte, len);  // (a plain file's sequences: copied out below, in parallel)
       used += len;
       r->cur_byte += len;
       ++r->cur_seq;
@@ -574,16 +610,32 @@ int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint6
       if (r->max_reads > 0 && r->n_reads_read >= r->max_reads) {  // io.rs:345-348
         r->reached_max = true;
         r->done = true;
-        r->stop_all();
-        goto full;
+        stop = true;
+        break;
       }
     }
+    if (c.src && r->cur_seq > seq_begin) {  // the sequences of records [seq_begin, cur_seq): mapped file → batch buffer
+      const size_t cnt = r->cur_seq - seq_begin;
+      const uint32_t TT = cnt >= 4096 ? r->T : 1;
+      auto copy = [&](uint32_t t) {
+        const size_t j0 = cnt * t / TT, j1 = cnt * (t + 1) / TT;
+        for (size_t j = j0; j < j1; ++j) {
+          const char *sq;
+          size_t sl;
+          c.seq_line(seq_begin + j, &sq, &sl);
+          memcpy(bases + offsets[n_begin + j], sq, sl);
+        }
+      };
+      if (TT == 1) copy(0);
+      else r->cpool->parallel_for(TT, copy);
+    }
+    if (r->done) r->stop_all();
     if (r->cur_seq >= c.lens.size()) {
       r->have_cur = false;
       r->cur = SeqChunk();
     }
+    if (stop) break;
   }
-full:
   *n_seqs = n;
   return SHK_OK;
 }
@@ -796,9 +848,17 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
   if (v != SHK_OK) return v;
   std::string dir = rc->outdir ? rc->outdir : "./";  // main.rs:74-78
   if (dir.empty() || dir.back() != '/') dir += '/';
-  {
-    std::string cmd = "mkdir -p '" + dir + "'";
-    if (system(cmd.c_str()) != 0) {
+  {  // create_dir_all (main.rs:80-84)
+    std::string acc;
+    bool ok = true;
+    for (size_t i = 0; i <= dir.size() && ok; ++i) {
+      if (i == dir.size() || dir[i] == '/') {
+        if (!acc.empty() && acc != "." && acc != "/" && mkdir(acc.c_str(), 0777) != 0 && errno != EEXIST) ok = false;
+      }
+      if (i < dir.size()) acc += dir[i];
+    }
+    struct stat st;
+    if (!ok || stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) {
       g_run_error = fmt("Failed to create output directory: %s", dir.c_str());
       return SHK_ERR_IO;
     }
@@ -829,38 +889,69 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
   // which is exactly drain_batch's cadence (io.rs:340-343,355-361) whatever the batch size
   const uint64_t max_seqs = rc->batch_reads ? rc->batch_reads : 1000000;
   const uint64_t cap_bases = rc->batch_bases ? rc->batch_bases : (256ull << 20);
-  uint8_t *bases = (uint8_t *)shk_alloc_pinned(cap_bases);
-  uint64_t *offs = (uint64_t *)shk_alloc_pinned((max_seqs + 1) * 8);
+  // two batch buffers: while the engine takes batch i (copy + count), the front-end fills batch i+1
+  uint8_t *bases2[2] = {(uint8_t *)shk_alloc_pinned(cap_bases), nullptr};
+  uint64_t *offs2[2] = {(uint64_t *)shk_alloc_pinned((max_seqs + 1) * 8), nullptr};
+  std::thread ingest_th;
+  int ingest_rc = SHK_OK;
+  auto join_ingest = [&]() {
+    if (ingest_th.joinable()) ingest_th.join();
+    return ingest_rc;
+  };
   auto cleanup = [&]() {
-    shk_free_pinned(bases);
-    shk_free_pinned(offs);
+    (void)join_ingest();
+    for (int i = 0; i < 2; ++i) {
+      shk_free_pinned(bases2[i]);
+      shk_free_pinned(offs2[i]);
+    }
     shk_destroy(ctx);
     shk_fastq_close(rd);
   };
-  if (!bases || !offs) {
+  if (!bases2[0] || !offs2[0]) {
     cleanup();
     g_run_error = "pinned buffer allocation failed";
     return SHK_ERR_NOMEM;
   }
-  for (;;) {  // any batch size keeps the striping: the engine counts reads itself
+  for (int cur = 0;; cur ^= 1) {  // any batch size keeps the striping: the engine counts reads itself
+    if (!bases2[cur]) {  // (the second pair is only allocated when there is a second batch)
+      bases2[cur] = (uint8_t *)shk_alloc_pinned(cap_bases);
+      offs2[cur] = (uint64_t *)shk_alloc_pinned((max_seqs + 1) * 8);
+      if (!bases2[cur] || !offs2[cur]) {
+        cleanup();
+        g_run_error = "pinned buffer allocation failed";
+        return SHK_ERR_NOMEM;
+      }
+    }
     uint64_t n = 0;
-    v = shk_fastq_next_batch(rd, bases, cap_bases, offs, max_seqs, &n);
+    v = shk_fastq_next_batch(rd, bases2[cur], cap_bases, offs2[cur], max_seqs, &n);
+    // the batch before this one: its outcome comes first, as in the reference, which ingests what it has read
+    // before it reads on (io.rs:340-343)
+    const int prev = join_ingest();
+    if (prev != SHK_OK) {
+      g_run_error = shk_last_error(ctx);
+      cleanup();
+      return prev;
+    }
     if (v != SHK_OK) {
       g_run_error = shk_fastq_error(rd);
       cleanup();
       return v;
     }
     if (n) {
-      v = shk_ingest_reads(ctx, bases, offs, n);
-      if (v != SHK_OK) {
-        g_run_error = shk_last_error(ctx);
-        cleanup();
-        return v;
-      }
+      uint8_t *bb = bases2[cur];
+      uint64_t *oo = offs2[cur];
+      ingest_rc = SHK_OK;
+      ingest_th = std::thread([&ingest_rc, ctx, bb, oo, n] { ingest_rc = shk_ingest_reads(ctx, bb, oo, n); });
     }
     int done = 0;
     shk_fastq_stats(rd, nullptr, nullptr, nullptr, &done);
     if (done) break;
+  }
+  v = join_ingest();
+  if (v != SHK_OK) {
+    g_run_error = shk_last_error(ctx);
+    cleanup();
+    return v;
   }
   v = shk_finalize(ctx);
   if (v != SHK_OK) {
