@@ -142,6 +142,7 @@ struct shk_ctx {
   hipEvent_t done_ev = nullptr;   // finalize: "the control block has been copied back"
   hipEvent_t chain_ev = nullptr;  // end event of the last timer (see ScopedTimer)
   uint64_t cur_blocks = 1;        // 1000-read blocks in the batch being counted (ingest_core)
+  double cur_kmer_ratio = 1.0;    // (k-mers ÷ bases) of the batch being counted if every read has ≥ k bases: n_bases − (k−1)·n_seqs over n_bases
   // Deferred page passes (see count_tiles): partitioned records of several batches wait here
   DevBuf acc_buf, acc_cur;        // page regions (4-B records block-interleaved, or 8-B records lane by lane) and their cursors
   bool acc_rec32 = true;          // which kind of record the regions were planned for
@@ -441,6 +442,10 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     if (rc != SHK_OK) return rc;
   }
   c->cur_blocks = n_blocks;
+  {
+    const double cut = (double)(c->cfg.k - 1) * (double)n_seqs;
+    c->cur_kmer_ratio = cut < (double)n_bases ? std::max(0.125, 1.0 - cut / (double)n_bases) : 0.125;
+  }
   uint32_t n_cursor_words = 0;
   if (xo) {  // exchange round: level-1 scatter only, every owner's records (shk_xchg_scatter_device)
     if (n_tiles_ub > tiles_per_sub) return fail(c, SHK_ERR_BAD_ARG, "an exchange batch takes at most %llu bases", (unsigned long long)MAX_SUB_BASES);
@@ -663,6 +668,11 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
   const double per_rec = std::max(0.02, std::min(1.0, c->acc_new_frac * 1.3));
   uint64_t budget = room > 0 ? (uint64_t)(room / per_rec) : 0;
   budget = std::min<uint64_t>(std::max<uint64_t>(budget, c->tb.cap / 4), c->tb.cap * 8);
+  // A capacity hint is the caller's word on how many distinct k-mers (of this context's share) there will be:
+  // when even all of them fit the pages at ≤ 80 %, no window has to end for the table's sake — one page pass
+  // (which streams the whole table: 45 ms on a 2^33-slot one) counts whatever the regions can hold.  (A hint
+  // that was too low costs time, not exactness: new keys beyond a page's fill limit take the spill path.)
+  if (c->cfg.table_capacity_hint && (double)c->cfg.table_capacity_hint <= 0.8 * (double)c->tb.cap) budget = ~0ull >> 1;
   budget = std::max<uint64_t>(budget, kmers_ub);
   if (env_int("SHK_DEFER_BUDGET", 0) > 0)  // test hook: flush early and often
     budget = std::max<uint64_t>((uint64_t)env_int("SHK_DEFER_BUDGET", 0), kmers_ub);
@@ -674,11 +684,11 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
   if (!(c->acc_buf.p && c->acc_lp == c->tb.log_pages && c->acc_rec32 == rec32 && c->acc_region_lanes == NL &&
         kmers_ub <= c->acc_budget_max && acc_lane_add(c, kmers_ub, lane_one, lane_add_exact) <= c->acc_lane_budget)) {
     // lanes each get a full-size region set; 8-byte records also need k_pages' miss queues
-    const uint64_t rec_bytes = rec32 ? 4ull * 2 + 1 : 8ull * 2 + 8 + 1;  // (lanes: 1.5 × 1.25 shares of the window together)
-    const uint64_t mem_records = (uint64_t)(free_b / 2 + c->acc_buf.cap) / rec_bytes;
+    const uint64_t rec_bytes = rec32 ? (NL > 1 ? 8ull : 5ull) + 1 : (NL > 1 ? 15ull : 10ull) + 8 + 1;  // regions are 1.25 × the window (× 1.5 over several lanes: each lane's share + 50 %)
+    const uint64_t mem_records = (uint64_t)(free_b / 3 * 2 + c->acc_buf.cap) / rec_bytes;
     // up to eight tables' worth of records while that is a few GiB, two tables' worth beyond
     const uint64_t few_gib = (8ull << 30) / (rec32 ? 4 : 8) / NL;
-    uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), c->tb.cap * 2);
+    uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), c->tb.cap * 5 / 2);
     bmax = std::max<uint64_t>(std::min(bmax, mem_records), kmers_ub);
     // a lane's regions take a lane's share of the window (+ 50 %: blocks of uneven read lengths), but at
     // least what one launch can put into a single lane
@@ -1134,8 +1144,12 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
 // owner share keeps the k-mers of one owner in W, owners being hash bits — about 1/W of them (+ 1/8 +
 // slack; a region that overflows all the same spills, exactly).
 static uint64_t acc_records_est(const shk_ctx *c, uint64_t kmers_ub) {
-  if (!c->owner_bits) return kmers_ub;
-  const uint64_t share = kmers_ub >> c->owner_bits;
+  // (kmers_ub counts one record per base of the launch's tiles; a batch of reads of ≥ k bases has k-1 fewer per
+  // read — cur_kmer_ratio, from the batch's read count.  An estimate that is too low costs nothing but time:
+  // a region that overflows spills, exactly.)
+  const uint64_t est = (uint64_t)((double)kmers_ub * c->cur_kmer_ratio) + 65536;
+  if (!c->owner_bits) return std::min(kmers_ub, est);
+  const uint64_t share = std::min(kmers_ub, est) >> c->owner_bits;
   return std::min<uint64_t>(kmers_ub, share + share / 8 + 65536);
 }
 
@@ -1462,9 +1476,9 @@ int shk_reset(shk_ctx *c) {
   c->zero_count_keys = false;
   c->finalized = c->poisoned = c->hist_ready = false;
   c->unsettled = false;  // the memsets above are ordered behind any launch still in flight
-  c->acc_active = false;  // (the regions' cursors are cleared when they are planned again)
-  c->acc_records_ub = 0;
-  c->acc_lp = ~0u;
+  c->acc_active = false;  // (the regions' cursors are cleared when they are planned again; the regions themselves —
+  c->acc_records_ub = 0;  // tens of GB on a large table — stay as they were sized: re-planning them from the free memory
+                          // of the moment re-allocated them, which stalls the host for seconds)
   c->acc_new_frac = 1.0;
   c->poison_code = 0;
   c->err.clear();
