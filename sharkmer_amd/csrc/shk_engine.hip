@@ -10,6 +10,7 @@
 #include "shk_device.hip.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -903,8 +904,14 @@ static XlPlan xchg_plan(const shk_ctx *c, const PartGeom &g, uint64_t layout_bas
   x.log_p1w = g.log_p1 - g.lw;
   x.n_grp = NL << x.log_p1w;
   const uint64_t B = (layout_bases + TILE_T - 1) / TILE_T * TILE_T;
-  const uint64_t lane_kmers_ub = NL > 1 ? std::min<uint64_t>(B, B / NL * 3 / 2 + 262144) : B;
-  x.cap1 = (region_cap(lane_kmers_ub, g.P1, 0) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
+  // What crosses the links is the segments as they are sized, full or not, so they are sized tightly: a lane's
+  // share of a round is its blocks' (1000-read blocks go round the lanes: + 10 % and two blocks' worth of slack
+  // for uneven read lengths), a region's share of that the mean + 5 % + 8 σ of a Poisson count + a block.  What
+  // still overflows goes to the foreign spill list — exact, just slower.
+  const uint64_t lane_kmers_ub = NL > 1 ? std::min<uint64_t>(B, B / NL * 11 / 10 + 262144) : B;
+  const double mean = (double)lane_kmers_ub / (double)g.P1;
+  const uint64_t cap = (uint64_t)(mean * 1.05 + 8.0 * std::sqrt(mean)) + 1024;
+  x.cap1 = (uint32_t)std::min<uint64_t>((cap + (1u << RB_LOG) - 1u) & ~(uint64_t)((1u << RB_LOG) - 1u), 0x7FFFF000ull);
   x.n_seg = 1u << g.lw;
   x.seg_recs = (uint64_t)x.n_grp * x.cap1;
   return x;
