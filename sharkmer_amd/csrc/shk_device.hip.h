@@ -2912,8 +2912,11 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     // that, not by the chain of round trips.  Not kept.)
     constexpr int WB = PAGE_SLOTS / 4 / PG_WG;
     uint4 gvv[WB];
+    const bool prefetch = lane_hi - lane_lo > 1;  // (one lane: nothing stands between two lanes; the quads that did not change are then not read at all)
+    if (prefetch) {
 #pragma unroll
-    for (int u = 0; u < WB; ++u) gvv[u] = reinterpret_cast<const uint4 *>(gv)[threadIdx.x + u * PG_WG];
+      for (int u = 0; u < WB; ++u) gvv[u] = reinterpret_cast<const uint4 *>(gv)[threadIdx.x + u * PG_WG];
+    }
     // Main loop: one 16-B load = four records per thread per step, the next step's load in flight.
     // No barrier in here: queues are per wave, and a slot's count of this pass is a full 32-bit word
     // (a page sees < 2^31 records), so nothing has to be folded away mid-pass.
@@ -2979,6 +2982,11 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
       uint4 d[WB];
 #pragma unroll
       for (int u = 0; u < WB; ++u) d[u] = reinterpret_cast<const uint4 *>(dl)[threadIdx.x + u * PG_WG];
+      if (!prefetch) {
+#pragma unroll
+        for (int u = 0; u < WB; ++u)
+          if (d[u].x | d[u].y | d[u].z | d[u].w) gvv[u] = reinterpret_cast<const uint4 *>(gv)[threadIdx.x + u * PG_WG];
+      }
 #pragma unroll
       for (int u = 0; u < WB; ++u)
         if (d[u].x | d[u].y | d[u].z | d[u].w) {
