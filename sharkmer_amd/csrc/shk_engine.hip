@@ -132,6 +132,7 @@ struct shk_ctx {
   uint64_t own_p0 = 0, own_p1 = 0;  // owned page range for finalize (0,0 = all)
   bool own_set = false;
   bool finalized = false, poisoned = false;
+  bool finalize_redone = false;  // the last finalize repeated its histogram scan after repairing spills
   bool hist_ready = false;  // finalize got as far as the histograms and totals (then failed an invariant, io.rs:1042-1047: the reference has its histo_vecs by then)
   bool unsettled = false;  // a counting launch whose outcome the host has not looked at yet
   uint64_t unsettled_spill_cap = 0;
@@ -1890,6 +1891,16 @@ int shk_finalize(shk_ctx *c) {
     int rcf = settle(c);
     if (rcf != SHK_OK) return rcf;
   }
+  // The scan below is queued optimistically behind a counting launch nobody has looked at yet; if that launch
+  // spilled, the scan is repeated over the repaired table.  A context whose LAST finalize had to do that (the
+  // same input shape tends to spill the same few records again: one k-mer ≥ 7 buckets from home is enough)
+  // looks first this time — one host round trip instead of a second scan of the table.
+  if (c->unsettled && c->finalize_redone) {
+    const uint64_t before = c->n_spilled;
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+    c->finalize_redone = c->n_spilled != before;  // (nothing spilled this time: back to the optimistic order)
+  }
   const uint32_t n_cols = c->cfg.chunks;
   const uint64_t hlen = c->cfg.histo_max + 2;
   // d_hist and d_tot are zero here: they are zeroed by reset and again right after every read-back
@@ -1941,6 +1952,7 @@ int shk_finalize(shk_ctx *c) {
     const bool redo = c->h_stats->bad != ~0ull || c->h_stats->spill_count > 0;
     int rcs = settle_checked(c);
     if (rcs != SHK_OK) return rcs;
+    c->finalize_redone = redo;
     if (redo) return shk_finalize(c);
   }
   c->hist_ready = true;
