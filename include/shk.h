@@ -292,6 +292,25 @@ int shk_merge_entries(shk_ctx *ctx, const void *d_keys, const void *d_vals, uint
  * in one all-to-all.  A received piece goes to shk_merge_entries(piece, piece + 8·c, c, c).  Asynchronous on
  * the context's stream (shk_stream). */
 int shk_compact_owners_packed(shk_ctx *ctx, uint32_t n_owners, const uint64_t *counts, void *d_buf, int32_t skip_owner);
+/* The same with pieces of a FIXED capacity (entries) at fixed places, so that nobody has to know anybody's counts
+ * before the all-to-all (no host read-back in front of it).  Piece o lies at byte offset o·(8 + capacity·(8 +
+ * 4·n_lanes)): an 8-byte header, then [k-mers][lane 0]…[lane L-1] with unused places holding EMPTY k-mers (all
+ * ones).  Entries beyond the capacity are NOT written; the header of every piece holds how many entries the
+ * fullest owner range of this sender had.  Asynchronous on the context's stream. */
+int shk_compact_owners_fixed(shk_ctx *ctx, uint32_t n_owners, uint64_t capacity, void *d_buf, int32_t skip_owner);
+/* KmerCounts::extend of the n_pieces received fixed-capacity pieces lying back to back (what the equal-split
+ * all-to-all of shk_compact_owners_fixed buffers delivers, this rank's own piece included at skip_piece) in ONE
+ * launch.  All or nothing: if ANY header says a range had more entries than the capacity, nothing is merged —
+ * every rank receives a piece from every sender, so every rank decides alike — and the caller repeats the exchange
+ * with exact counts (shk_owner_counts / shk_compact_owners_packed).  Asynchronous like shk_merge_entries;
+ * shk_merge_pieces_max reports the largest header seen (valid after the next shk_finalize or shk_sync):
+ * > capacity ⇒ nothing was merged. */
+int shk_merge_pieces(shk_ctx *ctx, const void *d_buf, uint32_t n_pieces, uint64_t capacity, int32_t skip_piece);
+int shk_merge_pieces_max(shk_ctx *ctx, uint64_t *max_count);
+/* The owned range of shk_set_owned_pages as share `owner` of `n_owners` (a power of two) equal parts of the pages,
+ * worked out when the histogram scan is launched — so it needs no look at the table geometry (which would have to
+ * wait for the counting launches) and follows the table when a merge grows it. */
+int shk_set_owner_share(shk_ctx *ctx, uint32_t n_owners, uint32_t owner);
 /* Restrict finalize's histogram scan to pages [p0,p1) (owner shard). */
 int shk_set_owned_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1);
 

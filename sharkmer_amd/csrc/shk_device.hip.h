@@ -1389,7 +1389,8 @@ __global__ void __launch_bounds__(WG) k_compact_owners(TableRef tb, uint64_t spo
                                                        uint64_t *__restrict__ out_keys,
                                                        uint32_t *__restrict__ out_vals, uint64_t lane_stride,
                                                        uint32_t skip_owner, uint32_t OWNER_BLOCKS,
-                                                       const unsigned long long *__restrict__ packed) {
+                                                       const unsigned long long *__restrict__ packed,
+                                                       unsigned long long hdr_bytes, unsigned long long *__restrict__ max_count) {
   __shared__ uint32_t red[WG / 64];
   __shared__ uint32_t wbase[WG / 64];
   __shared__ unsigned long long blk_base;
@@ -1401,7 +1402,11 @@ __global__ void __launch_bounds__(WG) k_compact_owners(TableRef tb, uint64_t spo
   uint32_t n = 0;
   for (uint64_t s = s0 + threadIdx.x; s < s1; s += WG) n += tb.keys[s] != EMPTY;
   const uint32_t tot = wg_sum<WG>(n, red);  // valid in thread 0
-  if (threadIdx.x == 0) blk_base = seg_offset[o] + (tot ? atomicAdd(&seg_cursor[o], (unsigned long long)tot) : 0ull);
+  if (threadIdx.x == 0) {
+    const unsigned long long at0 = tot ? atomicAdd(&seg_cursor[o], (unsigned long long)tot) : 0ull;
+    blk_base = seg_offset[o] + at0;
+    if (max_count && tot) atomicMax(max_count, at0 + tot);  // (fixed-capacity pieces: the sender learns how many entries an owner really had)
+  }
   __syncthreads();
   unsigned long long at = blk_base;
   const uint32_t wave = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
@@ -1422,11 +1427,15 @@ __global__ void __launch_bounds__(WG) k_compact_owners(TableRef tb, uint64_t spo
         // PACKED: owner o's entries are one self-contained piece — [keys 8·c][lane 0 counts 4·c]…[lane L-1] at
         // byte offset seg_offset[o]·(8 + 4L), c = packed[o] — so keys and every lane's counts cross the
         // links in ONE collective; i counts from seg_offset[o]
+        // (fixed-capacity pieces: hdr_bytes in front of every piece, entries beyond the capacity are not written
+        // — max_count tells the receivers, who then leave ALL pieces alone: shk_compact_owners_fixed)
         const unsigned long long so = seg_offset[o], c_o = packed[o], j = i - so;
-        char *const seg = reinterpret_cast<char *>(out_keys) + so * (8ull + 4ull * tb.n_lanes);
-        __builtin_memcpy(seg + j * 8ull, &key, 8);  // (4-byte aligned when L and the offset are odd)
-        for (uint32_t l = 0; l < tb.n_lanes; ++l)
-          *reinterpret_cast<uint32_t *>(seg + c_o * 8ull + ((unsigned long long)l * c_o + j) * 4ull) = tb.vals[(uint64_t)l * tb.cap + s];
+        if (j < c_o) {
+          char *const seg = reinterpret_cast<char *>(out_keys) + so * (8ull + 4ull * tb.n_lanes) + (o + 1ull) * hdr_bytes;
+          __builtin_memcpy(seg + j * 8ull, &key, 8);  // (4-byte aligned when L and the offset are odd)
+          for (uint32_t l = 0; l < tb.n_lanes; ++l)
+            *reinterpret_cast<uint32_t *>(seg + c_o * 8ull + ((unsigned long long)l * c_o + j) * 4ull) = tb.vals[(uint64_t)l * tb.cap + s];
+        }
       } else {
         out_keys[i] = key;
         for (uint32_t l = 0; l < tb.n_lanes; ++l) out_vals[(uint64_t)l * lane_stride + i] = tb.vals[(uint64_t)l * tb.cap + s];
@@ -1443,12 +1452,39 @@ __global__ void __launch_bounds__(WG) k_compact_owners(TableRef tb, uint64_t spo
 // ==========================================================================================
 __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t n_slots, uint64_t lane_stride,
                                               const uint64_t *__restrict__ pkeys,
-                                              const uint32_t *__restrict__ pvals,
-                                              DevStats *__restrict__ stats, SpillRef sp) {
+                                              const uint32_t *__restrict__ pvals_,
+                                              DevStats *__restrict__ stats, SpillRef sp,
+                                              uint64_t piece_cap, uint32_t skip_piece) {
+  if (piece_cap) {
+    // Every piece's header holds how many entries its sender's fullest owner range had.  Every rank gets one
+    // piece from every sender (its own included), so every rank sees the same maximum here: beyond the capacity
+    // NOBODY merges anything (the tables stay as they were; the host repeats the exchange with exact counts).
+    const uint64_t n_pieces = n_slots / piece_cap;
+    unsigned long long most = 0;
+    for (uint64_t p = 0; p < n_pieces; ++p) {
+      unsigned long long h;
+      __builtin_memcpy(&h, reinterpret_cast<const uint32_t *>(pkeys) + p * (2ull + piece_cap * (2ull + tb.n_lanes)), 8);
+      most = h > most ? h : most;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&stats->scratch[2], most);
+    if (most > piece_cap) return;
+  }
   uint32_t n_new = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n_slots;
-       i += (uint64_t)gridDim.x * WG) {
-    uint64_t key = pkeys[i];
+  for (uint64_t i0 = (uint64_t)blockIdx.x * WG + threadIdx.x; i0 < n_slots;
+       i0 += (uint64_t)gridDim.x * WG) {
+    uint64_t i = i0, key;
+    const uint32_t *pvals = pvals_;
+    if (piece_cap) {
+      // several self-contained pieces of piece_cap entries each ([header][k-mers][lane 0]…[lane L-1]) in one launch
+      const uint64_t piece = i0 / piece_cap;
+      if (piece == skip_piece) continue;
+      i = i0 - piece * piece_cap;
+      const uint32_t *pb = reinterpret_cast<const uint32_t *>(pkeys) + piece * (2ull + piece_cap * (2ull + tb.n_lanes)) + 2;
+      __builtin_memcpy(&key, pb + 2 * i, 8);
+      pvals = pb + 2 * piece_cap;
+    } else {
+      key = pkeys[i];
+    }
     if (key == EMPTY) continue;
     const Home hm = home_of(tb, key);
     if (!hm.owned) continue;
@@ -1476,6 +1512,17 @@ __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t n_slots, uin
   }
   for (int off = 32; off > 0; off >>= 1) n_new += __shfl_down(n_new, off, 64);
   if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&stats->n_distinct, (unsigned long long)n_new);
+}
+
+__global__ void k_piece_headers(uint32_t *__restrict__ buf, uint32_t n_pieces, unsigned long long piece_ints,
+                                const DevStats *__restrict__ stats) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_pieces) {
+    // (scratch[1]: entries of the fullest owner range.  A launch before the compaction that spilled records or
+    // met an invalid byte left a table that is not what the pieces should say: nobody may merge them.)
+    const unsigned long long m = (stats->spill_count || stats->bad != ~0ull) ? ~0ull : stats->scratch[1];
+    __builtin_memcpy(buf + p * piece_ints, &m, 8);
+  }
 }
 
 // ==========================================================================================

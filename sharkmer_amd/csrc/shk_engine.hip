@@ -131,6 +131,7 @@ struct shk_ctx {
   uint64_t n_grows = 0, n_spilled = 0, n_inserted = 0;
   uint64_t own_p0 = 0, own_p1 = 0;  // owned page range for finalize (0,0 = all)
   bool own_set = false;
+  uint32_t own_share_n = 0, own_share_id = 0;  // … or as a share of the pages, resolved when a scan is launched
   bool finalized = false, poisoned = false;
   bool finalize_redone = false;  // the last finalize repeated its histogram scan after repairing spills
   bool hist_ready = false;  // finalize got as far as the histograms and totals (then failed an invariant, io.rs:1042-1047: the reference has its histo_vecs by then)
@@ -1205,6 +1206,14 @@ static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, boo
 }
 
 // Outcome of the last counting launch, h_stats already read back and synchronised.
+// An owned range given as a share (shk_set_owner_share) follows the table when it grows.
+static void own_resolve(shk_ctx *c) {
+  if (!c->own_share_n) return;
+  const uint64_t per = (1ull << c->tb.log_pages) / c->own_share_n;
+  c->own_p0 = per * c->own_share_id;
+  c->own_p1 = per * (c->own_share_id + 1);
+}
+
 static int settle_checked(shk_ctx *c) {
   c->unsettled = false;
   if (c->h_stats->bad != ~0ull) {
@@ -1481,6 +1490,7 @@ int shk_reset(shk_ctx *c) {
   c->n_reads_read = c->n_bases_read = 0;
   c->n_inserted = 0;
   c->own_set = false;
+  c->own_share_n = 0;
   c->zero_count_keys = false;
   c->finalized = c->poisoned = c->hist_ready = false;
   c->unsettled = false;  // the memsets above are ordered behind any launch still in flight
@@ -1906,6 +1916,7 @@ int shk_finalize(shk_ctx *c) {
   // d_hist and d_tot are zero here: they are zeroed by reset and again right after every read-back
   uint64_t s0 = 0, s1 = c->tb.cap;
   if (c->own_set) {
+    own_resolve(c);
     s0 = c->own_p0 << PAGE_LOG;
     s1 = c->own_p1 << PAGE_LOG;
   }
@@ -2082,6 +2093,7 @@ int shk_export_table(shk_ctx *c, uint64_t *kmers, uint32_t *counts, uint64_t cap
   HIPC(c, hipMemsetAsync(dn, 0, 8, c->stream));
   uint64_t s0 = 0, s1 = c->tb.cap;
   if (c->own_set) {
+    own_resolve(c);
     s0 = c->own_p0 << PAGE_LOG;
     s1 = c->own_p1 << PAGE_LOG;
   }
@@ -2186,6 +2198,7 @@ int shk_find_oligos(shk_ctx *c, const uint64_t *oligos, uint32_t n_oligos, uint3
   HIPC(c, hipMemcpyAsync(dsets + n_oligos, rc.data(), (size_t)n_oligos * 8, hipMemcpyHostToDevice, c->stream));
   uint64_t s0 = 0, s1 = c->tb.cap;
   if (c->own_set) {
+    own_resolve(c);
     s0 = c->own_p0 << PAGE_LOG;
     s1 = c->own_p1 << PAGE_LOG;
   }
@@ -2372,7 +2385,7 @@ int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, co
     ScopedTimer t(c, SHK_K_MERGE);
     hipLaunchKernelGGL(k_merge, dim3(grid_for(n_slots, WG, 8192)), dim3(WG), 0, c->stream, c->tb,
                        n_slots, vals_lane_stride, (const uint64_t *)d_keys, (const uint32_t *)d_vals,
-                       c->d_stats, sp);
+                       c->d_stats, sp, 0ull, ~0u);
   }
   int rc = read_stats(c);
   if (rc != SHK_OK) return rc;
@@ -2417,7 +2430,7 @@ int shk_compact_owners(shk_ctx *c, uint32_t n_owners, const uint64_t *seg_offset
   hipLaunchKernelGGL(k_compact_owners, dim3(n_owners * bpo), dim3(WG), 0, c->stream, c->tb,
                      c->tb.cap / n_owners, (const unsigned long long *)doff, dcur, (uint64_t *)d_keys,
                      (uint32_t *)d_vals, vals_lane_stride, skip_owner < 0 ? ~0u : (uint32_t)skip_owner, bpo,
-                     (const unsigned long long *)nullptr);
+                     (const unsigned long long *)nullptr, 0ull, (unsigned long long *)nullptr);
   HIPC(c, hipStreamSynchronize(c->stream));  // the caller hands the buffers to a collective next
   return SHK_OK;
 }
@@ -2447,34 +2460,109 @@ int shk_compact_owners_packed(shk_ctx *c, uint32_t n_owners, const uint64_t *cou
   hipLaunchKernelGGL(k_compact_owners, dim3(n_owners * bpo), dim3(WG), 0, c->stream, c->tb,
                      c->tb.cap / n_owners, (const unsigned long long *)doff, dcur, (uint64_t *)d_buf,
                      (uint32_t *)nullptr, 0ull, skip_owner < 0 ? ~0u : (uint32_t)skip_owner, bpo,
-                     (const unsigned long long *)dcnt);
+                     (const unsigned long long *)dcnt, 0ull, (unsigned long long *)nullptr);
   HIPC(c, hipGetLastError());
   return SHK_OK;  // (asynchronous on the context's stream: run the collective on shk_stream())
 }
+
+int shk_compact_owners_fixed(shk_ctx *c, uint32_t n_owners, uint64_t capacity, void *d_buf, int32_t skip_owner) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  if (!c || n_owners == 0 || capacity == 0 || !d_buf) return SHK_ERR_BAD_ARG;
+  const uint64_t n_pages = 1ull << c->tb.log_pages;
+  if (n_pages % n_owners) return fail(c, SHK_ERR_BAD_ARG, "%llu pages do not split over %u owners",
+                                      (unsigned long long)n_pages, n_owners);
+  HIPC(c, hipSetDevice(c->cfg.device));
+  if (c->acc_active) {  // records still waiting for their page pass
+    int rcs = settle(c);
+    if (rcs != SHK_OK) return rcs;
+  }
+  // (Otherwise nothing is waited for: a counting launch nobody has looked at yet may have spilled records, in which
+  // case the table read here is incomplete — k_piece_headers sees that on the device and poisons every header, no
+  // rank merges anything, and the finalize that follows repairs the table before the exchange is repeated.)
+  HIPC(c, c->misc.ensure((size_t)n_owners * 24));
+  HIPC(c, c->h_rebased[0].ensure((size_t)n_owners * 16));
+  unsigned long long *h = (unsigned long long *)c->h_rebased[0].p;
+  for (uint32_t o = 0; o < n_owners; ++o) {
+    h[o] = (unsigned long long)o * capacity;  // every piece at its fixed place
+    h[n_owners + o] = capacity;
+  }
+  unsigned long long *doff = (unsigned long long *)c->misc.p, *dcur = doff + n_owners, *dcnt = dcur + n_owners;
+  const size_t piece_bytes = 8 + capacity * (8 + 4 * (size_t)c->n_lanes);
+  HIPC(c, hipMemcpyAsync(doff, h, (size_t)n_owners * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(dcnt, h + n_owners, (size_t)n_owners * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemsetAsync(dcur, 0, (size_t)n_owners * 8, c->stream));
+  // unused places read as EMPTY k-mers, which the merge skips
+  HIPC(c, hipMemsetAsync(d_buf, 0xFF, (size_t)n_owners * piece_bytes, c->stream));
+  HIPC(c, hipMemsetAsync(&c->d_stats->scratch[1], 0, 16, c->stream));  // [1]: fullest range here, [2]: … anywhere (merge)
+  const uint32_t bpo = std::min<uint32_t>(1024, std::max<uint32_t>(16, 2048 / n_owners));  // blocks per owner
+  hipLaunchKernelGGL(k_compact_owners, dim3(n_owners * bpo), dim3(WG), 0, c->stream, c->tb,
+                     c->tb.cap / n_owners, (const unsigned long long *)doff, dcur, (uint64_t *)d_buf,
+                     (uint32_t *)nullptr, 0ull, skip_owner < 0 ? ~0u : (uint32_t)skip_owner, bpo,
+                     (const unsigned long long *)dcnt, 8ull, &c->d_stats->scratch[1]);
+  hipLaunchKernelGGL(k_piece_headers, dim3((n_owners + 63) / 64), dim3(64), 0, c->stream, (uint32_t *)d_buf, n_owners,
+                     (unsigned long long)(piece_bytes / 4), (const DevStats *)c->d_stats);
+  HIPC(c, hipGetLastError());
+  return SHK_OK;
+}
+
+int shk_merge_pieces_max(shk_ctx *c, uint64_t *max_count) {
+  if (!c || !max_count) return SHK_ERR_BAD_ARG;
+  if (c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  HIPC(c, hipSetDevice(c->cfg.device));
+  if (!c->finalized && !c->hist_ready) {  // (a finalize has just brought the control block back otherwise)
+    int rc = read_stats(c);
+    if (rc != SHK_OK) return rc;
+  }
+  *max_count = c->h_stats->scratch[2];
+  return SHK_OK;
+}
+
+static int merge_launch(shk_ctx *c, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride,
+                        uint64_t piece_cap, uint32_t skip_piece);
 
 int shk_merge_entries(shk_ctx *c, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride) {
   if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   if (n == 0) return SHK_OK;
+  return merge_launch(c, d_keys, d_vals, n, vals_lane_stride, 0, ~0u);
+}
+
+int shk_merge_pieces(shk_ctx *c, const void *d_buf, uint32_t n_pieces, uint64_t capacity, int32_t skip_piece) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  if (!c || !d_buf) return SHK_ERR_BAD_ARG;
+  if (n_pieces == 0 || capacity == 0) return SHK_OK;
+  return merge_launch(c, d_buf, nullptr, (uint64_t)n_pieces * capacity, capacity, capacity, skip_piece < 0 ? ~0u : (uint32_t)skip_piece);
+}
+
+static int merge_launch(shk_ctx *c, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride,
+                        uint64_t piece_cap, uint32_t skip_piece) {
   HIPC(c, hipSetDevice(c->cfg.device));
-  {
+  // Fixed-capacity pieces behind a counting launch nobody has looked at yet: nothing is waited for.  If that
+  // launch spilled, the senders' headers are poisoned and k_merge touches nothing; if not, what the merge spills
+  // goes on the same list (same capacity, the counter runs on) and the finalize that follows repairs it.
+  const bool ride_on = piece_cap && c->unsettled && !c->acc_active && c->unsettled_spill_cap > 0 &&
+                       c->spillA.cap >= c->unsettled_spill_cap * 16;
+  if (!ride_on) {
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
   }
   c->finalized = c->hist_ready = false;
   c->zero_count_keys = true;  // (a peer's table may hold keys inserted with count 0: keep reading the keys)
-  HIPC(c, c->spillA.ensure(n * c->n_lanes * 16));  // worst case every entry spills on every lane
-  SpillRef sp = spill_ref(c->spillA, n * c->n_lanes);
-  HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  const uint64_t spill_cap = ride_on ? c->unsettled_spill_cap : n * c->n_lanes;  // worst case every entry spills on every lane
+  if (!ride_on) {
+    HIPC(c, c->spillA.ensure(spill_cap * 16));
+    HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  }
+  SpillRef sp = spill_ref(c->spillA, spill_cap);
   {
     ScopedTimer t(c, SHK_K_MERGE);
     hipLaunchKernelGGL(k_merge, dim3(grid_for(n, WG, 8192)), dim3(WG), 0, c->stream, c->tb, n, vals_lane_stride,
-                       (const uint64_t *)d_keys, (const uint32_t *)d_vals, c->d_stats, sp);
+                       (const uint64_t *)d_keys, (const uint32_t *)d_vals, c->d_stats, sp, piece_cap, skip_piece);
   }
   // (nothing is waited for: the outcome — spilled entries, load factor — is looked at by the next call that
   // needs the table, at the latest finalize)
   c->unsettled = true;
-  c->unsettled_spill_cap = n * c->n_lanes;
+  c->unsettled_spill_cap = spill_cap;
   return SHK_OK;
 }
 
@@ -2484,6 +2572,19 @@ int shk_set_owned_pages(shk_ctx *c, uint64_t p0, uint64_t p1) {
   if (p1 < p0 || p1 > (1ull << c->tb.log_pages)) return fail(c, SHK_ERR_BAD_ARG, "bad page range");
   c->own_p0 = p0;
   c->own_p1 = p1;
+  c->own_set = true;
+  c->own_share_n = 0;
+  c->finalized = c->hist_ready = false;
+  return SHK_OK;
+}
+
+int shk_set_owner_share(shk_ctx *c, uint32_t n_owners, uint32_t owner) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (n_owners == 0 || (n_owners & (n_owners - 1)) || owner >= n_owners || n_owners > (1ull << c->tb.log_pages))
+    return fail(c, SHK_ERR_BAD_ARG, "bad owner share %u of %u", owner, n_owners);
+  c->own_share_n = n_owners;  // (no settle: the range is worked out from the page count of the moment a scan is launched)
+  c->own_share_id = owner;
   c->own_set = true;
   c->finalized = c->hist_ready = false;
   return SHK_OK;

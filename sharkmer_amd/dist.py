@@ -207,6 +207,14 @@ class DistCounter:
         self.rank = dist.get_rank()
         self.device = device
         self.dense = bool(int(os.environ.get("SHK_DIST_DENSE", "0")))
+        # Entries a fixed-capacity piece holds (None: the first exchange asks for exact counts and sets it).
+        # SHK_DIST_CAP pins it (tests: a capacity that is too small must still give the exact result).
+        self._cap = int(os.environ["SHK_DIST_CAP"]) if os.environ.get("SHK_DIST_CAP") else None
+        self._cap_pinned = self._cap is not None
+        self._fixed_used = 0      # capacity of the pieces the last exchange handed over (0: exact protocol)
+        self._last_max = 0
+        self.n_fixed_exchanges = 0
+        self.n_redone_exchanges = 0
 
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
         return t if self.device is None else t.to(f"cuda:{self.device}")
@@ -233,7 +241,7 @@ class DistCounter:
         self.eng.set_owned_pages(p0, p1)
         return p0, p1
 
-    def exchange_and_merge(self):
+    def exchange_and_merge(self, exact=False):
         """Steps 1-3.  After it, this rank's owned page range holds the merged counts.
         Only the occupied (key, counts) entries cross the links: per-owner entry counts first
         (one small all_to_all), then one all_to_all with those split sizes per array."""
@@ -243,6 +251,27 @@ class DistCounter:
         # Geometry and entry counts in one small all_to_all: every rank sends every peer (its page
         # count, what it holds of that peer's range).  Page counts that differ (a table grew on one
         # rank only) show up on every rank alike: all grow to the largest and go round once more.
+        self._fixed_used = 0
+        if self._cap is not None and not exact and hasattr(self.eng, "compact_owner_fixed") and self.device is not None:
+            # (not even the table geometry is asked for — that would wait for the counting launches: an earlier
+            # exact exchange has made sure there are at least W pages, and tables never shrink)
+            # Nothing to ask anybody first: pieces of a fixed capacity at fixed places, unused places EMPTY (the
+            # merge skips them).  An owner is a range of the mixed key's TOP bits, so pieces are meaningful to the
+            # receiver whatever page count either table has grown to.  Every piece's header says how many entries
+            # its sender's fullest range had; the merge is all or nothing on every rank alike, and whether it was
+            # nothing comes back with finalize's own read-back (finalize_histograms then repeats the exchange
+            # the exact way — the tables are as they were).
+            ext = torch.cuda.ExternalStream(self.eng.stream(), device=f"cuda:{self.device}")
+            with torch.cuda.stream(ext):
+                buf, L = self.eng.compact_owner_fixed(W, self._cap, self.rank)
+                rbuf = torch.empty_like(buf)
+                dist.all_to_all_single(rbuf, buf)
+                self.eng.merge_fixed_pieces(rbuf, W, self._cap, self.rank)
+                self._keep = (buf, rbuf)
+            self._fixed_used = self._cap
+            self.n_fixed_exchanges += 1
+            self.eng.set_owner_share(W, self.rank)
+            return None
         n_pages, _, n_lanes = self.eng.table_geometry()
         if n_pages < W or n_pages % W:
             self.eng.reserve_pages(max(n_pages, W))
@@ -265,6 +294,7 @@ class DistCounter:
             assert n_pages == P, (n_pages, P)
         recv = [int(x) for x in got[:, 1]]                              # what every peer holds of MY range
         send = [int(x) for x in counts]
+        self._last_max = max(max(send), max(recv))  # (finalize_histograms turns the job-wide maximum into the next capacity)
         if hasattr(self.eng, "compact_owner_packed") and self.device is not None:
             # k-mers and ALL lanes' counts of a peer in ONE collective: every owner's entries are one
             # self-contained piece [k-mers][lane 0]…[lane L-1]; compaction, the all_to_all and the merges are
@@ -320,19 +350,46 @@ class DistCounter:
     def finalize_histograms(self):
         """Steps 1-4.  Returns the (chunks, histo_max+2) uint64 histogram of the union of all
         ranks' reads — identical on every rank — and stores the reduced totals in self.totals."""
-        dist = self.dist
+        dist, W = self.dist, self.world
         self.exchange_and_merge()
         self.eng.finalize()
+        most = None
+        if self._fixed_used:
+            most = self.eng.merge_pieces_max()   # (the same number on every rank: see shk_merge_pieces)
+            if most > self._fixed_used:
+                # Nobody merged anything.  Either a sender's table was not complete when the pieces were cut (a
+                # counting launch had spilled records — poisoned headers; the finalize above has repaired it):
+                # the same again.  Or a piece was too small somewhere: once more with exact counts.
+                self.n_redone_exchanges += 1
+                poisoned = most == (1 << 64) - 1
+                self.exchange_and_merge(exact=not poisoned)
+                self.eng.finalize()
+                most = None
+                if poisoned:
+                    most = self.eng.merge_pieces_max()
+                    if most > self._fixed_used:
+                        self.n_redone_exchanges += 1
+                        self.exchange_and_merge(exact=True)
+                        self.eng.finalize()
+                        most = None
         h = self.eng.histograms()
         c = self.eng.counters()
         names = ["n_reads_ingested", "n_bases_read", "n_bases_ingested", "n_kmers_ingested",
                  "n_unique_kmers", "n_hashed_kmers", "any_saturated"]
-        # one all_reduce for the histogram and the scalar totals together (both are sums)
-        packed = np.concatenate([np.array([c[k] for k in names], dtype=np.int64),
+        # one all_reduce for the histogram, the scalar totals (both are sums) and — one slot per rank — how many
+        # entries the fullest owner range had on that rank (the next exchange's piece capacity)
+        fill = np.zeros(W, dtype=np.int64)
+        fill[self.rank] = self._last_max
+        packed = np.concatenate([fill, np.array([c[k] for k in names], dtype=np.int64),
                                  h.astype(np.int64).reshape(-1)])
         pt = self._dev(torch.from_numpy(packed))
         dist.all_reduce(pt, op=dist.ReduceOp.SUM)
         red = pt.cpu().numpy()
+        if most is None:
+            most = int(red[:W].max())
+        red = red[W:]
+        if not self._cap_pinned and not self.dense:
+            self._cap = -(-(most + most // 8 + 4096) // 1024) * 1024
         self.totals = {k: int(v) for k, v in zip(names, red[:len(names)])}
         hist = red[len(names):].astype(np.uint64).reshape(h.shape)
         if hist.shape[0] > 0:

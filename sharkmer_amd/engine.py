@@ -107,7 +107,7 @@ ABI_SYMBOLS = [
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
     "shk_run_error", "shk_run_files",
     "shk_xchg_scatter_device", "shk_xchg_absorb", "shk_xchg_spill", "shk_xchg_spill_clear", "shk_insert_device",
-    "shk_stream", "shk_compact_owners_packed",
+    "shk_stream", "shk_compact_owners_packed", "shk_compact_owners_fixed", "shk_merge_pieces_max", "shk_merge_pieces", "shk_set_owner_share",
     "shk_packed_sizes", "shk_pack_reads", "shk_ingest_packed", "shk_ingest_packed_device", "shk_pack_reads_device",
     "shk_unpack_reads_device",
 ]
@@ -178,6 +178,10 @@ def load_library():
     L.shk_compact_owners.argtypes = [vp, u32, vp, vp, vp, u64, C.c_int32]
     L.shk_merge_entries.argtypes = [vp, vp, vp, u64, u64]
     L.shk_compact_owners_packed.argtypes = [vp, u32, vp, vp, C.c_int32]
+    L.shk_compact_owners_fixed.argtypes = [vp, u32, u64, vp, C.c_int32]
+    L.shk_merge_pieces_max.argtypes = [vp, vp]
+    L.shk_merge_pieces.argtypes = [vp, vp, u32, u64, C.c_int32]
+    L.shk_set_owner_share.argtypes = [vp, u32, u32]
     L.shk_table_geometry.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
     L.shk_table_reserve_pages.argtypes = [vp, u64]
     L.shk_table_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -516,6 +520,9 @@ class KmerEngine:
     def set_owned_pages(self, p0: int, p1: int):
         self._check(self._L.shk_set_owned_pages(self._h, p0, p1))
 
+    def set_owner_share(self, n_owners: int, owner: int):
+        self._check(self._L.shk_set_owner_share(self._h, n_owners, owner))
+
     def owner_counts(self, n_owners: int) -> np.ndarray:
         """Occupied slots in each of n_owners equal page ranges."""
         out = np.zeros(n_owners, dtype=np.uint64)
@@ -549,6 +556,27 @@ class KmerEngine:
         buf = torch.empty(max(n * (2 + n_lanes), 1), dtype=torch.int32, device="cuda")
         self._check(self._L.shk_compact_owners_packed(self._h, len(counts), counts.ctypes.data, buf.data_ptr(), skip_owner))
         return buf[:n * (2 + n_lanes)], n_lanes
+
+    def compact_owner_fixed(self, n_owners: int, capacity: int, skip_owner: int = -1):
+        """The same with pieces of a fixed capacity at fixed places (include/shk.h, shk_compact_owners_fixed):
+        piece o = [header 2 ints][k-mers 2·capacity][lane counts capacity each], unused places EMPTY."""
+        import torch
+        n_lanes = max(1, self.chunks)  # (not table_geometry(): that waits for the counting launches)
+        buf = torch.empty(n_owners * (2 + capacity * (2 + n_lanes)), dtype=torch.int32, device="cuda")
+        self._check(self._L.shk_compact_owners_fixed(self._h, n_owners, capacity, buf.data_ptr(), skip_owner))
+        return buf, n_lanes
+
+    def merge_fixed_pieces(self, buf_t, n_pieces: int, capacity: int, skip_piece: int = -1):
+        """KmerCounts::extend of all received fixed-capacity pieces in one launch — or of none, if any sender had
+        more entries than a piece holds (shk_merge_pieces)."""
+        assert buf_t.is_contiguous()
+        self._check(self._L.shk_merge_pieces(self._h, buf_t.data_ptr(), n_pieces, capacity, skip_piece))
+
+    def merge_pieces_max(self) -> int:
+        """Largest piece header the last merge_fixed_pieces saw (valid after finalize): > capacity ⇒ not merged."""
+        v = C.c_uint64(0)
+        self._check(self._L.shk_merge_pieces_max(self._h, C.byref(v)))
+        return int(v.value)
 
     def merge_packed_piece(self, piece_t, c: int, n_lanes: int):
         """KmerCounts::extend of one received piece (c entries: k-mers, then each lane's counts)."""

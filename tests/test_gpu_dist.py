@@ -116,3 +116,71 @@ def test_two_contexts_merge_like_two_ranks(orc, monkeypatch, k, chunks, flags, d
         assert tot["n_unique_kmers"] == st["n_unique_kmers"]
         assert tot["n_reads_ingested"] == st["n_reads_ingested"]
         assert tot["n_bases_ingested"] == st["n_bases_ingested"]
+
+
+@pytest.mark.parametrize("cap", [None, 1024, 1 << 20])
+def test_fixed_capacity_pieces_from_the_second_job_on(orc, monkeypatch, cap):
+    """The first finalize asks every peer for its entry counts; from then on pieces have a fixed capacity learnt
+    from the job before (no host read-back in front of the all-to-all).  cap=1024 pins a capacity that is far too
+    small: nobody may merge anything then, the exchange is repeated with exact counts, and the histogram must still
+    be the oracle's.  cap=2^20 pins a capacity that is ample, on tables that start small: the exchange is queued
+    behind a counting launch nobody has looked at, that launch spills records (the table has to grow), and the
+    senders' poisoned headers must stop every merge just the same."""
+    monkeypatch.setenv("SHK_DIST_DENSE", "0")
+    if cap is not None:
+        monkeypatch.setenv("SHK_DIST_CAP", str(cap))
+    world, n_reads, histo_max, k, chunks = 2, 24_500, 300, 21, 2
+    jobs = []
+    big = cap == 1 << 20  # (nearly every k-mer distinct: the 2^20-slot table a context starts with cannot hold a shard)
+    for seed, glen in ((0, 4_000_000), (5, 5_000_000)) if big else ((0, 40_000), (5, 55_000)):  # (job 2 has MORE distinct k-mers)
+        spec = sa.SynthSpec(genome_len=glen, sub_per_64k=328, n_per_64k=66)
+        bases, offsets = sa.synth_reads(spec, seed, n_reads)
+        jobs.append((bases, offsets, orc.run_batch(bases, offsets, k, chunks, histo_max)))
+    shared = ThreadGroup.Shared(world)
+    results, errors = [[] for _ in range(world)], []
+
+    def run(rank):
+        try:
+            eng = sa.KmerEngine(k, chunks, histo_max)
+            dc = DistCounter(eng, ThreadGroup(shared, rank), device=0)
+            keep = []
+            for bases, offsets, _ in jobs + jobs[:1]:
+                eng.reset()
+                if big:  # one launch per rank, nobody looks at its outcome before the exchange is queued
+                    first, n = rank * (n_reads // 2), n_reads // 2
+                    lo, hi = int(offsets[first]), int(offsets[first + n])
+                    d_b = torch.from_numpy(bases[lo:hi].copy()).cuda()
+                    d_o = torch.from_numpy((offsets[first:first + n + 1] - offsets[first]).astype(np.int64)).cuda()
+                    torch.cuda.synchronize()
+                    eng.set_read_index(first)
+                    eng.ingest_reads_device(d_b.data_ptr(), d_o.data_ptr(), n, hi - lo)
+                    keep.append((d_b, d_o))
+                else:
+                    for first, n in shard_batches(n_reads, rank, world):
+                        eng.set_read_index(first)
+                        eng.ingest_reads(bases, offsets[first:first + n + 1])
+                results[rank].append((dc.finalize_histograms(), dict(dc.totals)))
+            results[rank].append((dc.n_fixed_exchanges, dc.n_redone_exchanges, eng.counters()["n_grows"]))
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for res in results:
+        for (hist, tot), (_, _, ref) in zip(res[:3], jobs + jobs[:1]):
+            assert np.array_equal(hist, ref.histograms())
+            assert tot["n_unique_kmers"] == ref.stats["n_unique_kmers"]
+            assert tot["n_kmers_ingested"] == ref.stats["n_kmers_ingested"]
+        n_fixed, n_rem, n_grows = res[3]
+        if cap == 1 << 20:
+            assert n_fixed >= 4 and n_rem >= 1 and n_grows >= 1  # (a poisoned exchange is repeated with fixed pieces)
+        elif cap is None:
+            assert n_fixed == 2 and n_rem <= 1  # (job 2 may outgrow the capacity learnt from job 1 — by design)
+        else:
+            assert n_fixed == 3 and n_rem == 3
