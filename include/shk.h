@@ -208,6 +208,18 @@ int shk_sync(shk_ctx *ctx);
  * (io.rs:1042-1047, 1120-1132).  SHK_ERR_NO_READS mirrors io.rs:578-580.
  * Idempotent; ingest after finalize re-opens the context. */
 int shk_finalize(shk_ctx *ctx);
+/* shk_finalize in two halves, for a caller that sums histograms over several contexts ON THE DEVICE (one process
+ * per GPU: an in-place all-reduce of *d_sum over the ranks, queued on shk_stream(), instead of a host round trip
+ * through shk_histograms).  _begin queues the scan and hands out the block a reduction may SUM — n_words u64:
+ * the totals, the per-lane base counts, four bookkeeping words (reads ingested, bases read, "my scan ran over a
+ * table that still had to be repaired", user_word), the histogram.  _end brings the block back (one host sync for
+ * everything queued so far) and repairs this context's table if its last launch had spilled records; *again = 1
+ * when ANY context's had — the same sum on every rank — in which case nothing is final and every rank repeats
+ * _begin / reduction / _end.  Afterwards shk_histograms and shk_get_counters (n_reads_ingested, n_bases_*,
+ * n_kmers_ingested, n_unique_kmers, n_hashed_kmers) report what the reduction left: the whole job's.  The
+ * io.rs:1042-1047 invariants are the caller's to check on the summed numbers.  *user_sum: Σ user_word. */
+int shk_finalize_begin(shk_ctx *ctx, uint64_t user_word, void **d_sum, uint64_t *n_words);
+int shk_finalize_end(shk_ctx *ctx, int *again, uint64_t *user_sum);
 
 /* histo_vecs of io.rs:1020-1028: chunks × (histo_max+2) u64, row-major by
  * chunk; column j = Histogram::get_vector() after merging chunks 0..j

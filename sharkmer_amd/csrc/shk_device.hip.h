@@ -1514,6 +1514,18 @@ __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t n_slots, uin
   if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&stats->n_distinct, (unsigned long long)n_new);
 }
 
+// shk_finalize_begin: the words a reduction over the ranks sums besides the totals and the histogram.
+__global__ void k_fin_extras(unsigned long long *__restrict__ extra, unsigned long long n_reads,
+                             unsigned long long n_bases_read, unsigned long long user_word,
+                             const DevStats *__restrict__ stats, uint32_t was_unsettled) {
+  if (threadIdx.x == 0) {
+    extra[0] = n_reads;
+    extra[1] = n_bases_read;
+    extra[2] = (was_unsettled && (stats->spill_count || stats->bad != ~0ull)) ? 1ull : 0ull;
+    extra[3] = user_word;
+  }
+}
+
 __global__ void k_piece_headers(uint32_t *__restrict__ buf, uint32_t n_pieces, unsigned long long piece_ints,
                                 const DevStats *__restrict__ stats) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;

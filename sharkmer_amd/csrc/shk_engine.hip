@@ -110,6 +110,10 @@ struct shk_ctx {
   DevStats *d_stats = nullptr;
   DevStats *h_stats = nullptr;
   unsigned long long *d_lane_bases = nullptr, *h_lane_bases = nullptr;
+  // 4 words behind the lane counters for shk_finalize_begin/_end: reads ingested, bases read, "my scan ran over a
+  // table that has to be repaired", the caller's word — everything from d_tot to the end of the block is a SUM
+  unsigned long long *d_extra = nullptr, *h_extra = nullptr;
+  bool fin_scanned = false, fin_was_unsettled = false, fin_summed = false;
   unsigned long long *d_hist = nullptr;
   HistoTotals *d_tot = nullptr;
   HistoTotals *h_totp = nullptr;
@@ -1394,7 +1398,7 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   HIPB(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
   const size_t hist_n = (size_t)std::max<uint32_t>(cfg->chunks, 1) * (cfg->histo_max + 2);
   {
-    size_t off = sizeof(DevStats) + sizeof(HistoTotals) + sizeof(unsigned long long) * c->n_lanes;
+    size_t off = sizeof(DevStats) + sizeof(HistoTotals) + sizeof(unsigned long long) * (c->n_lanes + 4);  // (+ d_extra)
     c->ctl_hist_off = (off + 15) & ~(size_t)15;
     c->ctl_bytes = (c->ctl_hist_off + hist_n * sizeof(unsigned long long) + 15) & ~(size_t)15;
   }
@@ -1407,6 +1411,8 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   c->h_totp = (HistoTotals *)(c->h_ctl + sizeof(DevStats));
   c->d_lane_bases = (unsigned long long *)(c->d_ctl + sizeof(DevStats) + sizeof(HistoTotals));
   c->h_lane_bases = (unsigned long long *)(c->h_ctl + sizeof(DevStats) + sizeof(HistoTotals));
+  c->d_extra = c->d_lane_bases + c->n_lanes;
+  c->h_extra = c->h_lane_bases + c->n_lanes;
   c->d_hist = (unsigned long long *)(c->d_ctl + c->ctl_hist_off);
   c->h_hist = (const uint64_t *)(c->h_ctl + c->ctl_hist_off);
   c->h_stats->bad = ~0ull;
@@ -1886,11 +1892,9 @@ int shk_sync(shk_ctx *c) {
   return settle(c);
 }
 
-int shk_finalize(shk_ctx *c) {
-  if (!c) return SHK_ERR_BAD_ARG;
-  if (c->group) return group_finalize(c);
+// The front half of finalize: everything up to and including the launch of the histogram scan.
+static int finalize_scan(shk_ctx *c) {
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
-  if (c->finalized) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
   uint64_t n_reads = 0;
   for (auto v : c->lane_reads) n_reads += v;
@@ -1934,11 +1938,15 @@ int shk_finalize(shk_ctx *c) {
                          (size_t)lds_bins * n_cols * 4, c->stream, c->tb, s0, s1, c->cfg.histo_max,
                          n_cols, lds_bins, c->d_hist, c->d_tot);
   }
-  // One copy brings back the whole control block (launch outcome, totals, non-N base counts,
-  // histogram), and one host sync serves both the last counting launch and the scan: the scan
-  // was queued optimistically; if that launch turns out to have spilled records (or hit an
-  // invalid byte) it is settled now and the scan repeated over the repaired table.
-  const bool was_unsettled = c->unsettled;
+  c->fin_scanned = true;
+  c->fin_was_unsettled = c->unsettled;
+  c->fin_summed = false;
+  return SHK_OK;
+}
+
+// The back half: one copy brings back the whole control block (launch outcome, totals, non-N base counts,
+// histogram), and one host sync serves both the last counting launch and the scan.
+static int finalize_fetch(shk_ctx *c) {
   HIPC(c, hipMemcpyAsync(c->h_ctl, c->d_ctl, c->ctl_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipEventRecord(c->done_ev, c->stream));  // the host waits for the copy, not for what follows it
   {  // histogram + totals back to zero for the next scan; nobody waits for this
@@ -1959,7 +1967,23 @@ int shk_finalize(shk_ctx *c) {
     HIPC(c, q);
   }
   c->h_tot = *c->h_totp;
-  if (was_unsettled) {
+  c->fin_scanned = false;
+  return SHK_OK;
+}
+
+int shk_finalize(shk_ctx *c) {
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (c->group) return group_finalize(c);
+  if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  if (c->finalized) return SHK_OK;
+  if (c->fin_scanned) return fail(c, SHK_ERR_STATE, "shk_finalize between shk_finalize_begin and shk_finalize_end");
+  int rc = finalize_scan(c);
+  if (rc != SHK_OK) return rc;
+  // The scan was queued optimistically; if the launch before it turns out to have spilled records (or hit an
+  // invalid byte) it is settled now and the scan repeated over the repaired table.
+  rc = finalize_fetch(c);
+  if (rc != SHK_OK) return rc;
+  if (c->fin_was_unsettled) {
     const bool redo = c->h_stats->bad != ~0ull || c->h_stats->spill_count > 0;
     int rcs = settle_checked(c);
     if (rcs != SHK_OK) return rcs;
@@ -1967,6 +1991,8 @@ int shk_finalize(shk_ctx *c) {
     if (redo) return shk_finalize(c);
   }
   c->hist_ready = true;
+  const uint32_t n_cols = c->cfg.chunks;
+  const uint64_t hlen = c->cfg.histo_max + 2;
   if (!c->own_set) {
     // io.rs:1042-1047 (and :1150-1155 for chunks==0)
     if (c->h_tot.n_hashed != c->h_tot.n_lane_sum)
@@ -1984,6 +2010,47 @@ int shk_finalize(shk_ctx *c) {
                     (unsigned long long)nu, (unsigned long long)c->h_tot.n_unique);
     }
   }
+  c->finalized = true;
+  return SHK_OK;
+}
+
+int shk_finalize_begin(shk_ctx *c, uint64_t user_word, void **d_sum, uint64_t *n_words) {
+  if (!c || !d_sum || !n_words) return SHK_ERR_BAD_ARG;
+  if (c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  c->finalized = c->hist_ready = false;
+  int rc = finalize_scan(c);
+  if (rc != SHK_OK) return rc;
+  uint64_t n_reads = 0;
+  for (auto v : c->lane_reads) n_reads += v;
+  hipLaunchKernelGGL(k_fin_extras, dim3(1), dim3(64), 0, c->stream, c->d_extra, (unsigned long long)n_reads,
+                     (unsigned long long)c->n_bases_read, (unsigned long long)user_word, (const DevStats *)c->d_stats,
+                     c->fin_was_unsettled ? 1u : 0u);
+  HIPC(c, hipGetLastError());
+  *d_sum = c->d_tot;
+  *n_words = (c->ctl_bytes - sizeof(DevStats)) / 8;
+  return SHK_OK;
+}
+
+int shk_finalize_end(shk_ctx *c, int *again, uint64_t *user_sum) {
+  if (!c || !again) return SHK_ERR_BAD_ARG;
+  if (c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  if (!c->fin_scanned) return fail(c, SHK_ERR_STATE, "shk_finalize_end without shk_finalize_begin");
+  *again = 0;
+  int rc = finalize_fetch(c);
+  if (rc != SHK_OK) return rc;
+  if (c->fin_was_unsettled) {
+    const bool redo = c->h_stats->bad != ~0ull || c->h_stats->spill_count > 0;
+    int rcs = settle_checked(c);  // (repairs this context's table if it was the one)
+    if (rcs != SHK_OK) return rcs;
+    c->finalize_redone = redo;
+  }
+  if (user_sum) *user_sum = c->h_extra[3];
+  if (c->h_extra[2] > 0) {  // somebody's scan — the same sum on every rank — ran over an incomplete table
+    *again = 1;
+    return SHK_OK;
+  }
+  c->fin_summed = true;
+  c->hist_ready = true;
   c->finalized = true;
   return SHK_OK;
 }
@@ -2015,6 +2082,10 @@ int shk_get_counters(shk_ctx *c, shk_counters *o) {
   memset(o, 0, sizeof *o);
   for (auto v : c->lane_reads) o->n_reads_ingested += v;
   o->n_bases_read = c->n_bases_read;
+  if (c->fin_summed && c->finalized) {  // (shk_finalize_end: what came back is the sum the caller's reduction left)
+    o->n_reads_ingested = c->h_extra[0];
+    o->n_bases_read = c->h_extra[1];
+  }
   if (!c->finalized && !c->hist_ready) {  // (finalize has just brought the whole control block back)
     HIPC(c, hipMemcpyAsync(c->h_lane_bases, c->d_lane_bases, sizeof(unsigned long long) * c->n_lanes,
                            hipMemcpyDeviceToHost, c->stream));

@@ -351,47 +351,50 @@ class DistCounter:
         """Steps 1-4.  Returns the (chunks, histo_max+2) uint64 histogram of the union of all
         ranks' reads — identical on every rank — and stores the reduced totals in self.totals."""
         dist, W = self.dist, self.world
-        self.exchange_and_merge()
-        self.eng.finalize()
-        most = None
-        if self._fixed_used:
-            most = self.eng.merge_pieces_max()   # (the same number on every rank: see shk_merge_pieces)
-            if most > self._fixed_used:
-                # Nobody merged anything.  Either a sender's table was not complete when the pieces were cut (a
-                # counting launch had spilled records — poisoned headers; the finalize above has repaired it):
-                # the same again.  Or a piece was too small somewhere: once more with exact counts.
-                self.n_redone_exchanges += 1
-                poisoned = most == (1 << 64) - 1
-                self.exchange_and_merge(exact=not poisoned)
-                self.eng.finalize()
-                most = None
-                if poisoned:
-                    most = self.eng.merge_pieces_max()
-                    if most > self._fixed_used:
-                        self.n_redone_exchanges += 1
-                        self.exchange_and_merge(exact=True)
-                        self.eng.finalize()
-                        most = None
-        h = self.eng.histograms()
-        c = self.eng.counters()
         names = ["n_reads_ingested", "n_bases_read", "n_bases_ingested", "n_kmers_ingested",
                  "n_unique_kmers", "n_hashed_kmers", "any_saturated"]
-        # one all_reduce for the histogram, the scalar totals (both are sums) and — one slot per rank — how many
-        # entries the fullest owner range had on that rank (the next exchange's piece capacity)
-        fill = np.zeros(W, dtype=np.int64)
-        fill[self.rank] = self._last_max
-        packed = np.concatenate([fill, np.array([c[k] for k in names], dtype=np.int64),
-                                 h.astype(np.int64).reshape(-1)])
-        pt = self._dev(torch.from_numpy(packed))
-        dist.all_reduce(pt, op=dist.ReduceOp.SUM)
-        red = pt.cpu().numpy()
-        if most is None:
-            most = int(red[:W].max())
-        red = red[W:]
-        if not self._cap_pinned and not self.dense:
-            self._cap = -(-(most + most // 8 + 4096) // 1024) * 1024
+        self.exchange_and_merge()
+        if hasattr(self.eng, "finalize_begin") and self.device is not None:
+            # The histogram never visits the host before it is summed: the scan is queued behind the merges, the
+            # all_reduce runs in place on the engine's control block on the engine's stream, and ONE read-back
+            # brings the whole job's histogram and totals.  Three things can ask for another go, each known to
+            # every rank alike: somebody's scan ran over a table that had to be repaired first (`again`), the
+            # pieces of the exchange were poisoned (a sender's table was incomplete when they were cut), or a
+            # piece was too small (then with exact counts).
+            ext = torch.cuda.ExternalStream(self.eng.stream(), device=f"cuda:{self.device}")
+            while True:
+                with torch.cuda.stream(ext):
+                    blk = self.eng.finalize_begin(self._last_max)
+                    dist.all_reduce(blk, op=dist.ReduceOp.SUM)
+                again, max_sum = self.eng.finalize_end()
+                if self._fixed_used:
+                    most = self.eng.merge_pieces_max()   # (the same number on every rank: see shk_merge_pieces)
+                    if most > self._fixed_used:
+                        self.n_redone_exchanges += 1
+                        self.exchange_and_merge(exact=most != (1 << 64) - 1)
+                        continue
+                else:
+                    most = -(-max_sum // W)  # (exact protocol: mean over the ranks of their fullest range — a guess; a
+                    #                           piece that turns out too small costs one repeated exchange, once)
+                if not again:
+                    break
+            if not self._cap_pinned and not self.dense:
+                self._cap = -(-(most + most // 8 + 4096) // 1024) * 1024
+            hist = self.eng.histograms()
+            c = self.eng.counters()
+            red = np.array([c[k] for k in names], dtype=np.int64)
+        else:
+            self.eng.finalize()
+            h = self.eng.histograms()
+            c = self.eng.counters()
+            # one all_reduce for the histogram and the scalar totals together (both are sums)
+            packed = np.concatenate([np.array([c[k] for k in names], dtype=np.int64),
+                                     h.astype(np.int64).reshape(-1)])
+            pt = self._dev(torch.from_numpy(packed))
+            dist.all_reduce(pt, op=dist.ReduceOp.SUM)
+            red = pt.cpu().numpy()
+            hist = red[len(names):].astype(np.uint64).reshape(h.shape)
         self.totals = {k: int(v) for k, v in zip(names, red[:len(names)])}
-        hist = red[len(names):].astype(np.uint64).reshape(h.shape)
         if hist.shape[0] > 0:
             self.totals["n_singleton_kmers"] = int(hist[-1, 1])
             # io.rs:1042-1047 / 1120-1132 on the merged whole

@@ -107,7 +107,7 @@ ABI_SYMBOLS = [
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
     "shk_run_error", "shk_run_files",
     "shk_xchg_scatter_device", "shk_xchg_absorb", "shk_xchg_spill", "shk_xchg_spill_clear", "shk_insert_device",
-    "shk_stream", "shk_compact_owners_packed", "shk_compact_owners_fixed", "shk_merge_pieces_max", "shk_merge_pieces", "shk_set_owner_share",
+    "shk_stream", "shk_compact_owners_packed", "shk_compact_owners_fixed", "shk_merge_pieces_max", "shk_merge_pieces", "shk_set_owner_share", "shk_finalize_begin", "shk_finalize_end",
     "shk_packed_sizes", "shk_pack_reads", "shk_ingest_packed", "shk_ingest_packed_device", "shk_pack_reads_device",
     "shk_unpack_reads_device",
 ]
@@ -182,6 +182,8 @@ def load_library():
     L.shk_merge_pieces_max.argtypes = [vp, vp]
     L.shk_merge_pieces.argtypes = [vp, vp, u32, u64, C.c_int32]
     L.shk_set_owner_share.argtypes = [vp, u32, u32]
+    L.shk_finalize_begin.argtypes = [vp, u64, C.POINTER(vp), C.POINTER(u64)]
+    L.shk_finalize_end.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(u64)]
     L.shk_table_geometry.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
     L.shk_table_reserve_pages.argtypes = [vp, u64]
     L.shk_table_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -349,6 +351,19 @@ class KmerEngine:
     def finalize(self):
         self._check(self._L.shk_finalize(self._h))
         return self
+
+    def finalize_begin(self, user_word: int = 0):
+        """shk_finalize_begin: queues the scan; returns the int64 CUDA tensor (a view of the engine's control block)
+        a reduction over the ranks may sum in place — on the engine's stream."""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._L.shk_finalize_begin(self._h, user_word, C.byref(p), C.byref(n)))
+        return self._raw_tensor(p.value, int(n.value), "<i8")
+
+    def finalize_end(self):
+        """shk_finalize_end → (again, Σ user_word)."""
+        again, usum = C.c_int(0), C.c_uint64(0)
+        self._check(self._L.shk_finalize_end(self._h, C.byref(again), C.byref(usum)))
+        return bool(again.value), int(usum.value)
 
     def histograms(self) -> np.ndarray:
         """histo_vecs (io.rs:1020-1028): (chunks, histo_max+2) u64."""
