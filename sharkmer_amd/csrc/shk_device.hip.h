@@ -2853,6 +2853,13 @@ static_assert(MQ32 >= 2 * 64 * P32_RPS, "the queue must take a whole step of mis
 // page (tags stay, the per-pass counts are written back and cleared in between); lane l's records
 // are region l·lane_stride + page of the n_regions block-interleaved regions (lane_stride = 0: the
 // buffer holds one lane, region = page).
+//
+// FRESH: the table holds nothing yet and its memory has not even been cleared (shk_reset leaves that to the first
+// page pass when that pass covers every page and every lane).  The page is then not READ at all — tags start
+// empty, counts start at zero — and written out whole at the end: every lane's counts, and the keys rebuilt from
+// the tags (a tag and the page identify the key), EMPTY where no tag is.  What a reset would have written is
+// written once, with the result in it, and a page in costs nothing.
+template <bool FRESH>
 __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo, uint32_t lane_hi,
                                                    uint32_t lane_stride, uint32_t n_regions_,
                                                    const unsigned int *__restrict__ cursor, uint32_t cap_p,
@@ -2863,7 +2870,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
   __shared__ __attribute__((aligned(16))) uint32_t mqs[(PG_WG / 64) * MQ32];
   if (stats->bad != ~0ull) return;
   const uint32_t page = blockIdx.x;
-  {
+  if (!FRESH) {
     uint32_t any = 0;
     for (uint32_t l = lane_lo; l < lane_hi; ++l) any |= cursor[l * lane_stride + page];
     if (any == 0) return;  // nothing for this page in any lane: leave it untouched in HBM
@@ -2877,6 +2884,10 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
   // page keys → tags, counting occupied slots on the way
   uint32_t my_occ = 0;
   constexpr int LD = PAGE_SLOTS / 2 / PG_WG;  // 16-B loads per thread: all issued before the first is used
+  if (FRESH) {
+#pragma unroll
+    for (int u = 0; u < LD; ++u) reinterpret_cast<uint2 *>(tags)[threadIdx.x + u * PG_WG] = make_uint2(TAG_EMPTY, TAG_EMPTY);
+  } else {
   ulonglong2 pv[LD];
 #pragma unroll
   for (int u = 0; u < LD; ++u) pv[u] = reinterpret_cast<const ulonglong2 *>(gk)[threadIdx.x + u * PG_WG];
@@ -2898,7 +2909,8 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     }
     reinterpret_cast<uint2 *>(tags)[i] = make_uint2(tg[0], tg[1]);
   }
-  const uint32_t occ0 = pg_wg_sum(my_occ, dl);
+  }
+  const uint32_t occ0 = FRESH ? 0u : pg_wg_sum(my_occ, dl);
   const uint32_t room = occ0 < PAGE_FILL_CAP ? (PAGE_FILL_CAP - occ0) / (PG_WG / 64) : 0u;
   for (uint32_t i = threadIdx.x; i < PAGE_SLOTS; i += PG_WG) dl[i] = 0;
   __syncthreads();
@@ -2936,7 +2948,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
         const uint32_t prev = atomicCAS(&tags[sl], TAG_EMPTY, fp3 | d);
         if (prev == TAG_EMPTY) {
           n_new++;
-          gk[sl] = unmix_key((gpage << R) | rec, bits);
+          if (!FRESH) gk[sl] = unmix_key((gpage << R) | rec, bits);
           cur = fp3 | d;
         } else {
           cur = prev;
@@ -2961,9 +2973,16 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
       const uint32_t filled = cursor[lane * lane_stride + page];
       n = filled < cap_p ? filled : cap_p;  // beyond cap_p: spilled
     }
-    if (n == 0) continue;  // (uniform across the workgroup)
-    region = (uint64_t)lane * lane_stride + page;
     gv = tb.vals + (uint64_t)lane * tb.cap + ((uint64_t)page << PAGE_LOG);
+    if (n == 0) {  // (uniform across the workgroup)
+      if (FRESH) {
+#pragma unroll
+        for (int u = 0; u < PAGE_SLOTS / 4 / PG_WG; ++u)
+          reinterpret_cast<uint4 *>(gv)[threadIdx.x + u * PG_WG] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      continue;
+    }
+    region = (uint64_t)lane * lane_stride + page;
     // this lane's counts of the page: asked for NOW, needed when the lane's records have been counted — the
     // HBM round trip hides behind the record loop instead of standing between two lanes.  (A deeper pipeline —
     // the next lane's first records and counts in flight over this lane's tail — was measured: ten lanes on a
@@ -2971,7 +2990,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     // that, not by the chain of round trips.  Not kept.)
     constexpr int WB = PAGE_SLOTS / 4 / PG_WG;
     uint4 gvv[WB];
-    const bool prefetch = lane_hi - lane_lo > 1;  // (one lane: nothing stands between two lanes; the quads that did not change are then not read at all)
+    const bool prefetch = !FRESH && lane_hi - lane_lo > 1;  // (one lane: nothing stands between two lanes; the quads that did not change are then not read at all)
     if (prefetch) {
 #pragma unroll
       for (int u = 0; u < WB; ++u) gvv[u] = reinterpret_cast<const uint4 *>(gv)[threadIdx.x + u * PG_WG];
@@ -3041,14 +3060,22 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
       uint4 d[WB];
 #pragma unroll
       for (int u = 0; u < WB; ++u) d[u] = reinterpret_cast<const uint4 *>(dl)[threadIdx.x + u * PG_WG];
-      if (!prefetch) {
+      if (FRESH) {  // counts start at zero: every quad is written, none is read
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+          reinterpret_cast<uint4 *>(gv)[threadIdx.x + u * PG_WG] = d[u];
+          if (d[u].x | d[u].y | d[u].z | d[u].w)
+            reinterpret_cast<uint4 *>(dl)[threadIdx.x + u * PG_WG] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+      if (!FRESH && !prefetch) {
 #pragma unroll
         for (int u = 0; u < WB; ++u)
           if (d[u].x | d[u].y | d[u].z | d[u].w) gvv[u] = reinterpret_cast<const uint4 *>(gv)[threadIdx.x + u * PG_WG];
       }
 #pragma unroll
       for (int u = 0; u < WB; ++u)
-        if (d[u].x | d[u].y | d[u].z | d[u].w) {
+        if (!FRESH && (d[u].x | d[u].y | d[u].z | d[u].w)) {
           uint4 v = gvv[u];
           v.x = sat_add_u32(v.x, d[u].x);
           v.y = sat_add_u32(v.y, d[u].y);
@@ -3061,6 +3088,29 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     __syncthreads();
   }
   __syncthreads();
+  if (FRESH) {  // the page's keys, rebuilt from the tags: home bucket = bucket - d, fingerprint = the tag's upper bits
+#pragma unroll
+    for (int u = 0; u < LD; ++u) {
+      const uint32_t i = threadIdx.x + u * PG_WG;
+      const uint2 tg = reinterpret_cast<const uint2 *>(tags)[i];
+      const uint32_t t2[2] = {tg.x, tg.y};
+      ulonglong2 kv;
+      unsigned long long ko[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        ko[q] = EMPTY;
+        if (t2[q] != TAG_EMPTY) {
+          const uint32_t home = (((2 * i + q) >> 2) - (t2[q] & 7u)) & (PAGE_SLOTS / 4 - 1);
+          const uint32_t rec = (home << fpb) | (t2[q] >> 3);
+          ko[q] = unmix_key((gpage << R) | rec, bits);
+        }
+      }
+      kv.x = ko[0];
+      kv.y = ko[1];
+      reinterpret_cast<ulonglong2 *>(gk)[i] = kv;
+    }
+    __syncthreads();
+  }
   const uint32_t nnew = pg_wg_sum(n_new, dl);
   if (nnew && threadIdx.x == 0) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
 }

@@ -135,6 +135,9 @@ struct shk_ctx {
   uint64_t n_grows = 0, n_spilled = 0, n_inserted = 0;
   uint64_t own_p0 = 0, own_p1 = 0;  // owned page range for finalize (0,0 = all)
   bool own_set = false;
+  // shk_reset does not clear the table: the first page pass that covers every page and lane writes it whole
+  // (k_pages32<true>); anything else that touches the table first clears it then (tb_fresh)
+  bool tb_stale = false;
   uint32_t own_share_n = 0, own_share_id = 0;  // … or as a share of the pages, resolved when a scan is launched
   bool finalized = false, poisoned = false;
   bool finalize_redone = false;  // the last finalize repeated its histogram scan after repairing spills
@@ -272,6 +275,13 @@ int fill_state(shk_ctx *c, const TableRef &t, bool ctl) {
   return SHK_OK;
 }
 
+// The table as everybody but a FRESH page pass needs it: cleared, if the last reset left that for later.
+int tb_fresh(shk_ctx *c) {
+  if (!c->tb_stale) return SHK_OK;
+  c->tb_stale = false;
+  return fill_state(c, c->tb, false);
+}
+
 int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out) {
   TableRef t{};
   t.log_pages = log_pages;
@@ -307,7 +317,9 @@ int grow_to(shk_ctx *c, uint32_t new_log_pages) {
   TableRef nt{};
   int rc = alloc_table(c, new_log_pages, &nt);
   if (rc != SHK_OK) return rc;
-  {
+  if (c->tb_stale) {
+    c->tb_stale = false;  // (nothing to carry over: the new table is the cleared one)
+  } else {
     ScopedTimer t(c, SHK_K_GROW);
     hipLaunchKernelGGL(k_grow, dim3(grid_for(c->tb.cap, WG, 8192)), dim3(WG), 0, c->stream, c->tb, nt);
   }
@@ -349,6 +361,10 @@ SpillRef spill_ref(DevBuf &b, uint64_t cap) {
 // found its page full, and from then on the table at least doubles per round.
 int drain_spill(shk_ctx *c, uint64_t spill_cap) {
   DevBuf *cur = &c->spillA, *nxt = &c->spillB;
+  if (c->h_stats->spill_count > 0) {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   for (uint32_t round = 0; c->h_stats->spill_count > 0; ++round) {
     uint64_t n = c->h_stats->spill_count;
     if (n > spill_cap)
@@ -1124,10 +1140,21 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
                            log_sub, 2 * c->cfg.k, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp);
     }
     if (!defer) {
+      const uint32_t l_lo = all_lanes ? 0u : lane, l_hi = all_lanes ? NL : lane + 1;
+      const bool fresh = c->tb_stale && rec32 && l_lo == 0 && l_hi == c->n_lanes && !env_int("SHK_NO_FRESH", 0);
+      if (!fresh) {
+        int rcf = tb_fresh(c);
+        if (rcf != SHK_OK) return rcf;
+      }
       ScopedTimer t(c, SHK_K_PAGES, /*chain=*/true);
-      if (rec32)
-        hipLaunchKernelGGL(k_pages32, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, all_lanes ? 0u : lane,
-                           all_lanes ? NL : lane + 1, all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
+      if (rec32 && fresh) {
+        hipLaunchKernelGGL(k_pages32<true>, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
+                           all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
+                           (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
+        c->tb_stale = false;
+      } else if (rec32)
+        hipLaunchKernelGGL(k_pages32<false>, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
+                           all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
                            (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
       else
         hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
@@ -1198,6 +1225,10 @@ static int count_tiles(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, boo
       hipLaunchKernelGGL(k_scan, dim3(grid_for(b.tile_count, 1, 4096)), dim3(WG), 0, c->stream, b,
                          c->d_stats, c->d_lane_bases);
     }
+    {
+      int rcf = tb_fresh(c);
+      if (rcf != SHK_OK) return rcf;
+    }
     ScopedTimer t(c, SHK_K_DIRECT);
     hipLaunchKernelGGL(k_direct, dim3(grid_for(b.tile_count, 1, 256 * 8)), dim3(WG), 0, c->stream, b,
                        c->tb, c->d_stats, sp);
@@ -1250,11 +1281,22 @@ static int flush_acc(shk_ctx *c) {
   const uint64_t spill_cap = c->acc_spill_cap;
   if (c->spillA.cap < spill_cap * 16) return fail(c, SHK_ERR_INVARIANT, "spill list of the accumulation window missing");
   SpillRef sp = spill_ref(c->spillA, spill_cap);
+  const bool fresh = c->tb_stale && c->acc_rec32 && NL == c->n_lanes && !env_int("SHK_NO_FRESH", 0);
+  if (!fresh) {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   if (c->acc_rec32) {
     ScopedTimer t(c, SHK_K_PAGES);
-    hipLaunchKernelGGL(k_pages32, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
-                       NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
-                       c->d_stats, sp);
+    if (fresh)
+      hipLaunchKernelGGL(k_pages32<true>, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+                         NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
+                         c->d_stats, sp);
+    else
+      hipLaunchKernelGGL(k_pages32<false>, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+                         NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
+                         c->d_stats, sp);
+    c->tb_stale = false;
   } else {  // 8-byte records: one page pass per lane over that lane's regions
     HIPC(c, c->part2.ensure((uint64_t)n_pages * std::min<uint64_t>((uint64_t)c->acc_cap + MISS_SLACK, MISS_PAGE_MAX) * 8));  // (planned with the regions)
     for (uint32_t lane = 0; lane < NL; ++lane) {
@@ -1485,8 +1527,12 @@ int shk_reset(shk_ctx *c) {
   }
   HIPC(c, hipSetDevice(c->cfg.device));
   {
-    int rc = fill_state(c, c->tb, true);  // table + control block (stats, totals, histogram) in one launch
+    // the control block (stats, totals, histogram); the TABLE is cleared by whoever touches it first — the first
+    // page pass writes it whole instead, with the counts in it (k_pages32<true>)
+    TableRef none{};
+    int rc = fill_state(c, env_int("SHK_NO_FRESH", 0) ? c->tb : none, true);
     if (rc != SHK_OK) return rc;
+    c->tb_stale = !env_int("SHK_NO_FRESH", 0);
   }
   memset(c->h_stats, 0, sizeof(DevStats));
   c->h_stats->bad = ~0ull;
@@ -1730,6 +1776,10 @@ int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, cons
   if (chunk_id >= c->n_lanes) return fail(c, SHK_ERR_BAD_ARG, "chunk_id out of range");
   if (n == 0) return SHK_OK;
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   c->finalized = c->hist_ready = false;
   const uint64_t kmax = c->cfg.k >= 32 ? ~0ull : ((1ull << (2 * c->cfg.k)) - 1);
   for (uint64_t i = 0; i < n; ++i) {
@@ -1853,6 +1903,10 @@ int shk_insert_device(shk_ctx *c, const void *d_kmers, const void *d_lanes, cons
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
   HIPC(c, hipSetDevice(c->cfg.device));
   {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
+  {
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
   }
@@ -1914,6 +1968,10 @@ static int finalize_scan(shk_ctx *c) {
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
     c->finalize_redone = c->n_spilled != before;  // (nothing spilled this time: back to the optimistic order)
+  }
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
   }
   const uint32_t n_cols = c->cfg.chunks;
   const uint64_t hlen = c->cfg.histo_max + 2;
@@ -2156,6 +2214,10 @@ int shk_export_table(shk_ctx *c, uint64_t *kmers, uint32_t *counts, uint64_t cap
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
   }
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   HIPC(c, c->misc.ensure(cap * 12 + 16));
   uint8_t *p = (uint8_t *)c->misc.p;
   unsigned long long *dn = (unsigned long long *)p;
@@ -2201,6 +2263,10 @@ int shk_lookup(shk_ctx *c, const uint64_t *kmers, uint32_t *counts, uint64_t n, 
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
   }
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   HIPC(c, c->misc.ensure(n * 12));
   uint64_t *dk = (uint64_t *)c->misc.p;
   uint32_t *dc = (uint32_t *)((uint8_t *)c->misc.p + n * 8);
@@ -2242,6 +2308,10 @@ int shk_find_oligos(shk_ctx *c, const uint64_t *oligos, uint32_t n_oligos, uint3
   {
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
+  }
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
   }
   auto rc_of = [](uint64_t x, int len) {  // reverse complement of a len-base value (host side)
     uint64_t r = 0;
@@ -2429,6 +2499,10 @@ int shk_table_device_ptrs(shk_ctx *c, void **d_keys, void **d_vals) {
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
   }
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   HIPC(c, hipStreamSynchronize(c->stream));
   if (d_keys) *d_keys = c->tb.keys;
   if (d_vals) *d_vals = c->tb.vals;
@@ -2444,6 +2518,10 @@ int shk_merge_pages(shk_ctx *c, uint64_t p0, uint64_t p1, const void *d_keys, co
   {
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
+  }
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
   }
   c->finalized = c->hist_ready = false;
   c->zero_count_keys = true;  // (a peer's table may hold keys inserted with count 0: keep reading the keys)
@@ -2474,6 +2552,10 @@ int shk_owner_counts(shk_ctx *c, uint32_t n_owners, uint64_t *counts) {
     int rcs = settle(c);
     if (rcs != SHK_OK) return rcs;
   }
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   HIPC(c, c->misc.ensure((size_t)n_owners * 16));
   unsigned long long *dc = (unsigned long long *)c->misc.p;
   HIPC(c, hipMemsetAsync(dc, 0, (size_t)n_owners * 8, c->stream));
@@ -2493,6 +2575,10 @@ int shk_compact_owners(shk_ctx *c, uint32_t n_owners, const uint64_t *seg_offset
   if (n_pages % n_owners) return fail(c, SHK_ERR_BAD_ARG, "%llu pages do not split over %u owners",
                                       (unsigned long long)n_pages, n_owners);
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   HIPC(c, c->misc.ensure((size_t)n_owners * 16));
   unsigned long long *doff = (unsigned long long *)c->misc.p, *dcur = doff + n_owners;
   HIPC(c, hipMemcpyAsync(doff, seg_offsets, (size_t)n_owners * 8, hipMemcpyHostToDevice, c->stream));
@@ -2513,6 +2599,10 @@ int shk_compact_owners_packed(shk_ctx *c, uint32_t n_owners, const uint64_t *cou
   if (n_pages % n_owners) return fail(c, SHK_ERR_BAD_ARG, "%llu pages do not split over %u owners",
                                       (unsigned long long)n_pages, n_owners);
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   // device: [seg offsets (entries) × W][cursors × W][counts × W], staged through pinned memory
   HIPC(c, c->misc.ensure((size_t)n_owners * 24));
   HIPC(c, c->h_rebased[0].ensure((size_t)n_owners * 16));
@@ -2550,6 +2640,10 @@ int shk_compact_owners_fixed(shk_ctx *c, uint32_t n_owners, uint64_t capacity, v
   // (Otherwise nothing is waited for: a counting launch nobody has looked at yet may have spilled records, in which
   // case the table read here is incomplete — k_piece_headers sees that on the device and poisons every header, no
   // rank merges anything, and the finalize that follows repairs the table before the exchange is repeated.)
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   HIPC(c, c->misc.ensure((size_t)n_owners * 24));
   HIPC(c, c->h_rebased[0].ensure((size_t)n_owners * 16));
   unsigned long long *h = (unsigned long long *)c->h_rebased[0].p;
@@ -2608,6 +2702,10 @@ int shk_merge_pieces(shk_ctx *c, const void *d_buf, uint32_t n_pieces, uint64_t 
 static int merge_launch(shk_ctx *c, const void *d_keys, const void *d_vals, uint64_t n, uint64_t vals_lane_stride,
                         uint64_t piece_cap, uint32_t skip_piece) {
   HIPC(c, hipSetDevice(c->cfg.device));
+  {
+    int rcf = tb_fresh(c);
+    if (rcf != SHK_OK) return rcf;
+  }
   // Fixed-capacity pieces behind a counting launch nobody has looked at yet: nothing is waited for.  If that
   // launch spilled, the senders' headers are poisoned and k_merge touches nothing; if not, what the merge spills
   // goes on the same list (same capacity, the counter runs on) and the finalize that follows repairs it.
