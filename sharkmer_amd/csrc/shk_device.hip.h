@@ -2843,6 +2843,9 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
 // Counts: 16-bit deltas as in k_pages.  Keys are written when inserted, so the page's keys are
 // never written back wholesale.
 // ------------------------------------------------------------------------------------------
+// A workgroup barrier that orders LDS traffic only: global stores still in flight are not waited for.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr uint32_t TAG_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t MQ32 = 512;              // miss-queue entries per wave (LDS)
 constexpr uint32_t P32_RPS = 4;             // records per thread per step (one 16-B load)
@@ -2936,32 +2939,41 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
       sp.counts[i] = 1u;
     }
   };
-  // general probe of one record: find its (fp, d) tag or insert it, add one
+  // general probe of one record: find its (fp, d) tag or insert it, add one.  Bucket by bucket — ONE 16-B LDS read
+  // brings the four tags of a bucket, which are then looked at in probe order in registers (a tag is written once,
+  // from EMPTY: what was read as occupied stays what it is; what was read as EMPTY is claimed with a CAS, whose
+  // answer is the slot's tag if somebody else was faster).  Slot by slot this was a chain of LDS round trips per
+  // record: most of a many-lane page pass (10 lanes, 30 Mb genome: 10 k cycles per lane and page in the drains).
   auto insert = [&](uint32_t rec) {
     const uint32_t home = rec >> fpb, fp3 = (rec & fpmask) << 3;
-    uint32_t sl = home << 2;
-    for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
-      const uint32_t d = ((sl >> 2) - home) & (PAGE_SLOTS / 4 - 1);
-      uint32_t cur = tags[sl];
-      if (cur == TAG_EMPTY) {
-        if (!may_insert || d >= 7) break;  // share used up, or too far out for a tag → spill
-        const uint32_t prev = atomicCAS(&tags[sl], TAG_EMPTY, fp3 | d);
-        if (prev == TAG_EMPTY) {
-          n_new++;
-          if (!FRESH) gk[sl] = unmix_key((gpage << R) | rec, bits);
-          cur = fp3 | d;
-        } else {
-          cur = prev;
-        }
+    for (uint32_t d = 0; d < 7;) {
+      const uint32_t sl0 = ((home + d) & (PAGE_SLOTS / 4 - 1)) << 2, want = fp3 | d;
+      const uint4 t4 = *reinterpret_cast<const uint4 *>(&tags[sl0]);
+      // the first slot of the bucket, in probe order, that ends the search: this key's tag, an EMPTY slot, or a far
+      // entry (low bits 7 — EMPTY has them too); one decision per bucket, the same code for every lane
+      const uint32_t s0 = (t4.x == want) | ((t4.x & 7u) == 7u), s1 = (t4.y == want) | ((t4.y & 7u) == 7u),
+                     s2 = (t4.z == want) | ((t4.z & 7u) == 7u), s3 = (t4.w == want) | ((t4.w & 7u) == 7u);
+      if (!(s0 | s1 | s2 | s3)) {
+        ++d;
+        continue;
       }
-      if ((cur & 7u) == 7u) break;  // a far entry: cannot tell whether it is this key → spill
-      if (d < 7 && cur == (fp3 | d)) {
-        atomicAdd(&dl[sl], 1u);
+      const uint32_t q = s0 ? 0u : s1 ? 1u : s2 ? 2u : 3u;
+      const uint32_t cur = s0 ? t4.x : s1 ? t4.y : s2 ? t4.z : t4.w;
+      if (cur == want) {
+        atomicAdd(&dl[sl0 + q], 1u);
         return;
       }
-      sl = (sl + 1) & (PAGE_SLOTS - 1);
+      if (cur != TAG_EMPTY || !may_insert) break;  // a far entry (cannot tell whether it is this key), or this wave's share of the page's room is used up → spill
+      const uint32_t prev = atomicCAS(&tags[sl0 + q], TAG_EMPTY, want);
+      if (prev == TAG_EMPTY) {
+        n_new++;
+        if (!FRESH) gk[sl0 + q] = unmix_key((gpage << R) | rec, bits);
+        atomicAdd(&dl[sl0 + q], 1u);
+        return;
+      }
+      // somebody else took the slot: look at the bucket again (it may be this very key)
     }
-    spill(rec);
+    spill(rec);  // (or too far out for a tag)
   };
   auto drain = [&]() {
     for (uint32_t j = lane_id; j < n_miss; j += 64) insert(mq[j]);  // this wave's own queue
@@ -2999,6 +3011,9 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     // No barrier in here: queues are per wave, and a slot's count of this pass is a full 32-bit word
     // (a page sees < 2^31 records), so nothing has to be folded away mid-pass.
     const uint32_t n_steps = n / (P32_RPS * PG_WG);
+    // (a region of at most two steps — a chunk lane's share of a page on a many-lane table — fits the miss queue
+    // whole: one drain at the end instead of three, each of which is a chain of LDS round trips)
+    const bool early = n > 2 * P32_RPS * PG_WG;
     auto load4 = [&](uint32_t step) {  // this lane's four records of a step (they share a block)
       return *reinterpret_cast<const uint4 *>(part_buf + rec_slot64(region, n_regions, (step * PG_WG + threadIdx.x) * 4u));
     };
@@ -3023,7 +3038,12 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
           exists = (uint32_t)q < nv;
           found &= (uint32_t)exists;
         }
-        atomicAdd(&dl[((rr[q] >> fpb) << 2) + idx], found);
+        // (a lane past the end of the region adds its 0 to a slot of its own: left at record 0's bucket, the
+        // up to 2047 of them in a page's last step queue up on ONE LDS address — measured: 15 k cycles per
+        // chunk lane and page, most of a multi-lane pass over short regions)
+        uint32_t at = ((rr[q] >> fpb) << 2) + idx;
+        if (decltype(partial)::value) at = exists ? at : threadIdx.x * 4u + (uint32_t)q;
+        atomicAdd(&dl[at], found);
         missed[q] = exists && !found;
       }
   #pragma unroll
@@ -3035,24 +3055,24 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
       // drain when the next step might not fit (worst case: every record of it misses), and after
       // each of the first few steps: an empty page misses on every first occurrence and on its
       // repeats until it is inserted (measured: 4 early drains 0.232 ms, 0 → 0.240, 16 → 0.257)
-      if (n_miss > MQ32 - 64 * P32_RPS || step < P32_EARLY) drain();
+      if (n_miss > MQ32 - 64 * P32_RPS || (step < P32_EARLY && early)) drain();
     };
     uint4 nxt;
     if (n_steps) nxt = load4(0);
+    // the last, partial step's records are asked for now as well (a short region is two loads: both in flight)
+    const uint32_t tail_j = (n_steps * PG_WG + threadIdx.x) * 4u;
+    const uint32_t tail_nv = tail_j < n ? (n - tail_j < 4u ? n - tail_j : 4u) : 0u;
+    uint4 tailv = make_uint4(0u, 0u, 0u, 0u);
+    if (tail_nv) tailv = load4(n_steps);  // (a quad never straddles a block; its tail past n is ignored)
     for (uint32_t step = 0; step < n_steps; ++step) {
       const uint4 cur = nxt;
       if (step + 1 < n_steps) nxt = load4(step + 1);
       body(step, cur, 4u, std::false_type{});
     }
-    if (n_steps * P32_RPS * PG_WG < n) {  // the page's last, partial step: lanes past the end sit it out
-      const uint32_t j = (n_steps * PG_WG + threadIdx.x) * 4u;
-      const uint32_t nv = j < n ? (n - j < 4u ? n - j : 4u) : 0u;
-      uint4 cur = make_uint4(0u, 0u, 0u, 0u);
-      if (nv) cur = load4(n_steps);  // (a quad never straddles a block; its tail past n is ignored)
-      body(n_steps, cur, nv, std::true_type{});
-    }
+    if (n_steps * P32_RPS * PG_WG < n)  // the page's last, partial step: lanes past the end sit it out
+      body(n_steps, tailv, tail_nv, std::true_type{});
     drain();
-    __syncthreads();
+    lds_barrier();
     // this pass's counts → the page's counts (saturating), four slots per lane and step; all of a
     // thread's loads are issued before the first is used, and the LDS counts go back to zero on the
     // way (the next chunk lane counts from zero)
@@ -3085,7 +3105,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
           reinterpret_cast<uint4 *>(dl)[threadIdx.x + u * PG_WG] = make_uint4(0u, 0u, 0u, 0u);
         }
     }
-    __syncthreads();
+    lds_barrier();  // (the counts on their way to HBM are nobody's business in here: the next lane's are elsewhere)
   }
   __syncthreads();
   if (FRESH) {  // the page's keys, rebuilt from the tags: home bucket = bucket - d, fingerprint = the tag's upper bits

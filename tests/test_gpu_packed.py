@@ -19,6 +19,7 @@ def _device_pack(eng, seq: bytes):
     d_b = torch.from_numpy(np.frombuffer(seq, dtype=np.uint8).copy()).cuda() if n else torch.empty(0, dtype=torch.uint8, device="cuda")
     d_p = torch.zeros((n + 3) // 4 + 8, dtype=torch.uint8, device="cuda")
     d_m = torch.zeros((n + 31) // 32 + 2, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # (torch's copies and fills run on torch's stream, the engine's kernels on its own)
     eng.pack_reads_device(d_b.data_ptr(), n, d_p.data_ptr(), d_m.data_ptr())
     eng.sync()
     return sa.PackedReads(d_p.cpu().numpy()[:(n + 3) // 4], d_m.cpu().numpy().view(np.uint32)[:(n + 31) // 32],
@@ -54,6 +55,7 @@ def test_device_pack_equals_host_pack_and_unpack_inverts_it():
         dev, d_p, d_m = _device_pack(eng, bases.tobytes())
         assert np.array_equal(dev.packed, host.packed) and np.array_equal(dev.nmask, host.nmask)
         d_out = torch.zeros(len(bases) + 16, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # (torch's fill runs on torch's stream, the engine's kernel on its own)
         eng.unpack_reads_device(d_p.data_ptr(), d_m.data_ptr(), len(bases), d_out.data_ptr())
         eng.sync()
         assert np.array_equal(d_out.cpu().numpy()[:len(bases)], bases)
