@@ -2997,9 +2997,9 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     region = (uint64_t)lane * lane_stride + page;
     // this lane's counts of the page: asked for NOW, needed when the lane's records have been counted — the
     // HBM round trip hides behind the record loop instead of standing between two lanes.  (A deeper pipeline —
-    // the next lane's first records and counts in flight over this lane's tail — was measured: ten lanes on a
-    // 30 Mb genome 3.04 → 2.91 ms, one lane 0.238 → 0.246 ms; the pass streams 6.8 GB there and is bound by
-    // that, not by the chain of round trips.  Not kept.)
+    // every lane's fill level asked for up front, the next lane's first records in flight over this lane's drain
+    // and write-out — was measured twice: ten lanes on a 30 Mb genome 3.04 → 2.91 ms before the drains were
+    // made cheap, 1.81 → 1.86 ms after.  Not kept.)
     constexpr int WB = PAGE_SLOTS / 4 / PG_WG;
     uint4 gvv[WB];
     const bool prefetch = !FRESH && lane_hi - lane_lo > 1;  // (one lane: nothing stands between two lanes; the quads that did not change are then not read at all)
@@ -3038,9 +3038,9 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
           exists = (uint32_t)q < nv;
           found &= (uint32_t)exists;
         }
-        // (a lane past the end of the region adds its 0 to a slot of its own: left at record 0's bucket, the
-        // up to 2047 of them in a page's last step queue up on ONE LDS address — measured: 15 k cycles per
-        // chunk lane and page, most of a multi-lane pass over short regions)
+        // (a lane past the end of the region adds its 0 to a slot of its own: left at record 0's bucket, the up
+        // to 2047 of them in a page's last step queue up on ONE LDS address, and same-address atomics go one
+        // by one — it shows on many-lane tables, where every lane of every page has such a step)
         uint32_t at = ((rr[q] >> fpb) << 2) + idx;
         if (decltype(partial)::value) at = exists ? at : threadIdx.x * 4u + (uint32_t)q;
         atomicAdd(&dl[at], found);
