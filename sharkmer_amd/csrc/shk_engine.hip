@@ -282,7 +282,7 @@ int tb_fresh(shk_ctx *c) {
   return fill_state(c, c->tb, false);
 }
 
-int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out) {
+int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out, bool cleared = true) {
   TableRef t{};
   t.log_pages = log_pages;
   t.n_lanes = c->n_lanes;
@@ -298,7 +298,7 @@ int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out) {
                 (unsigned long long)t.cap, t.n_lanes);
   }
   *out = t;
-  return fill_state(c, t, false);
+  return cleared ? fill_state(c, t, false) : SHK_OK;
 }
 
 int read_stats(shk_ctx *c) {
@@ -1463,8 +1463,14 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
     // an owner share starts with enough pages for 4-byte exchange records (2k − level-1 bits ≤ 32, the
     // level-1 fan-out being at most the page bits of the virtual table): k = 21 → 2^10 pages over all owners
     want = std::max<uint64_t>(want, (uint64_t)PAGE_SLOTS << (2 * cfg->k - 32 - c->owner_bits));
-  int rc = alloc_table(c, log_pages_for(want, c->owner_bits), &c->tb);
-  if (rc == SHK_OK) rc = fill_state(c, c->tb, true);
+  // (the table's memory is not cleared here either: see tb_stale)
+  const bool lazy = !env_int("SHK_NO_FRESH", 0);
+  int rc = alloc_table(c, log_pages_for(want, c->owner_bits), &c->tb, !lazy);
+  if (rc == SHK_OK) {
+    TableRef none{};
+    rc = fill_state(c, none, true);
+    c->tb_stale = lazy;
+  }
   if (rc != SHK_OK) return bail(rc);
   HIPB(hipStreamSynchronize(c->stream));
 #undef HIPB
