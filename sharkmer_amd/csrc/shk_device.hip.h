@@ -2699,35 +2699,47 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
     for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
     may_insert = w < room;
   };
-  // general probe of one record into the LDS page: find the key or insert it, add one
-  auto insert = [&](uint64_t key) {
-    if (key == EMPTY) return;  // padding record of an odd (tile, page) run
-    uint32_t sl = slot_of(hash64(key, tb.key_bits), tb.log_pages + tb.owner_bits);
-    for (uint32_t probe = 0; probe < PAGE_SLOTS; ++probe) {
-      uint64_t cur = keys[sl];
-      if (cur == EMPTY) {
-        if (!may_insert) break;  // this wave's share of the page is used up → spill
-        uint64_t prev = atomicCAS((unsigned long long *)&keys[sl], (unsigned long long)EMPTY,
-                                  (unsigned long long)key);
-        if (prev == EMPTY) {
-          n_new++;
-          cur = key;
-        } else {
-          cur = prev;
-        }
-      }
-      if (cur == key) {
-        delta_add(dl, sl);
-        return;
-      }
-      sl = (sl + 1) & (PAGE_SLOTS - 1);
-    }
+  // general probe of one record into the LDS page: find the key or insert it, add one.  Bucket by bucket (two
+  // 16-B LDS reads bring a bucket's four keys; the first of them, in probe order, that is this key or EMPTY ends
+  // the search) instead of one LDS round trip per slot — see k_pages32.
+  auto spill = [&](uint64_t key) {
     unsigned long long i = atomicAdd(&stats->spill_count, 1ull);
     if (i < sp.cap) {
       sp.keys[i] = key;
       sp.lanes[i] = lane;
       sp.counts[i] = 1u;
     }
+  };
+  auto insert = [&](uint64_t key) {
+    if (key == EMPTY) return;  // padding record of an odd (tile, page) run
+    const uint32_t b0 = slot_of(hash64(key, tb.key_bits), tb.log_pages + tb.owner_bits) >> 2;
+    for (uint32_t nb = 0; nb < PAGE_SLOTS / 4;) {
+      const uint32_t s0 = ((b0 + nb) & (PAGE_SLOTS / 4 - 1)) << 2;
+      const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(&keys[s0]);
+      const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&keys[s0 + 2]);
+      const uint32_t e0 = (ka.x == key) | (ka.x == EMPTY), e1 = (ka.y == key) | (ka.y == EMPTY),
+                     e2 = (kb.x == key) | (kb.x == EMPTY), e3 = (kb.y == key) | (kb.y == EMPTY);
+      if (!(e0 | e1 | e2 | e3)) {
+        ++nb;
+        continue;
+      }
+      const uint32_t q = e0 ? 0u : e1 ? 1u : e2 ? 2u : 3u;
+      const uint64_t cur = e0 ? ka.x : e1 ? ka.y : e2 ? kb.x : kb.y;
+      if (cur == key) {
+        delta_add(dl, s0 + q);
+        return;
+      }
+      if (!may_insert) break;  // this wave's share of the page is used up → spill
+      const uint64_t prev = atomicCAS((unsigned long long *)&keys[s0 + q], (unsigned long long)EMPTY,
+                                      (unsigned long long)key);
+      if (prev == EMPTY) {
+        n_new++;
+        delta_add(dl, s0 + q);
+        return;
+      }
+      // somebody else took the slot: look at the bucket again (it may be this very key)
+    }
+    spill(key);
   };
   // Four records per thread per step.  The global loads of the NEXT step, then the four 32-B
   // home buckets (two ds_read_b128 each), are in flight together; a record whose key sits in
