@@ -458,7 +458,9 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   // clear that launch's partition cursors and the spill counter on its way (capacity heuristic
   // when no hint was given: assume ≥ 4× coverage; the spill path keeps the result exact whatever
   // the truth is).
-  const uint64_t tiles_per_sub = MAX_SUB_BASES / TILE_T;
+  // (a batch of at most MAX_SUB_BASES bases is ONE counting launch even when the partial tiles at its 1000-read
+  // block boundaries take the tile count past MAX_SUB_BASES / TILE_T: a second launch would be a second page pass)
+  const uint64_t tiles_per_sub = n_bases <= MAX_SUB_BASES ? std::max<uint64_t>(MAX_SUB_BASES / TILE_T, n_tiles_ub) : MAX_SUB_BASES / TILE_T;
   {
     const uint64_t first_kmers_ub = std::min(tiles_per_sub, n_tiles_ub) * TILE_T;
     int rc = ensure_capacity(c, c->cfg.table_capacity_hint ? 0 : (first_kmers_ub / 4) >> c->owner_bits);
