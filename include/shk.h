@@ -49,6 +49,10 @@ extern "C" {
 #define SHK_FLAG_TIMING 1u        /* bracket every kernel with HIP events */
 #define SHK_FLAG_FORCE_DIRECT 2u  /* count with the global-atomic kernel only */
 #define SHK_FLAG_FORCE_PAGED 4u   /* count with the LDS-page kernels only */
+#define SHK_FLAG_DEFER_ERRORS 8u  /* host-buffer ingests (shk_ingest_reads/_batch/_packed) return once their last
+                                   * slice is queued, like the device-buffer ones: an invalid byte is reported by
+                                   * the NEXT call on the context (ingest, sync, finalize), and that call's first
+                                   * host-to-device copies overlap this one's counting */
 
 typedef struct shk_ctx shk_ctx;
 

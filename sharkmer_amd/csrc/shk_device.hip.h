@@ -722,6 +722,13 @@ __global__ void __launch_bounds__(WG) k_fill(FillSegs f) {
 // from_str has no room for and kmers_from_ascii needs (encoding.rs:346-352): an N mask, bit p % 32 of word
 // p / 32 set where base p is N (its 2-bit code is then 00).  0.28 B/base instead of 1: what a host sends
 // over PCIe when it packs (shk_pack_reads) before it hands a batch over (shk_ingest_packed).
+// An N mask that is nearly all zeros crosses the link as the list of its non-zero words (ingest_host): the staged
+// mask is cleared on the device and the listed words are written into it.
+__global__ void __launch_bounds__(WG) k_nmask_sparse(uint32_t *__restrict__ nm, const uint2 *__restrict__ list, uint32_t n) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i < n) nm[list[i].x] = list[i].y;
+}
+
 // k_unpack restores the ASCII batch in HBM for the counting kernels; k_pack is the device-side packer
 // (validation as in encoding.rs:353-356: the first offender in input order through stats->bad).
 // ==========================================================================================

@@ -10,12 +10,14 @@
 #include "shk_device.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace shk;
@@ -121,12 +123,14 @@ struct shk_ctx {
   const uint64_t *h_hist = nullptr;  // → the mirror's histogram
   // scratch
   hipStream_t copy_stream = nullptr;
-  hipEvent_t copy_done[2] = {nullptr, nullptr};
+  hipEvent_t copy_done[3] = {nullptr, nullptr, nullptr};
+  uint32_t stage_next = 0;        // which of the three staging sets the next slice of a host-buffer ingest takes
   bool zero_count_keys = false;   // some key may have been inserted with count 0 (shk_insert_counts, merges): k_histo reads the keys
   bool lds_attr_scatter = false, lds_attr_rescatter = false, lds_attr_scatter_own = false;  // hipFuncSetAttribute done for this context's device
-  HostBuf h_rebased[2];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
-  DevBuf in_bases, in_offsets, in_bases2, in_offsets2, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
-  DevBuf pk_stage[2], nm_stage[2], pk_ascii;  // packed input: the staged streams of a slice; a whole batch unpacked (device-resident packed ingest)
+  HostBuf h_rebased[3];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
+  DevBuf in_bases, in_offsets, in_bases2, in_offsets2, in_bases3, in_offsets3, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
+  DevBuf pk_stage[3], nm_stage[3], nz_dev[3], pk_ascii;
+  HostBuf nz_host[3];             // … and the non-zero words of a slice's N mask, when they are few (index, word)  // packed input: the staged streams of a slice; a whole batch unpacked (device-resident packed ingest)
   DevBuf xbuf, xspill;            // owner layout: the level-1 records of a launch by [owner][lane][super-page]; the foreign spill list
   uint64_t xspill_cap = 0;
   // host counters
@@ -1496,10 +1500,12 @@ void shk_destroy(shk_ctx *c) {
   c->in_offsets.release();
   c->in_bases2.release();
   c->in_offsets2.release();
-  c->h_rebased[0].release();
-  c->h_rebased[1].release();
-  if (c->copy_done[0]) (void)hipEventDestroy(c->copy_done[0]);
-  if (c->copy_done[1]) (void)hipEventDestroy(c->copy_done[1]);
+  c->in_bases3.release();
+  c->in_offsets3.release();
+  for (int i = 0; i < 3; ++i) {
+    c->h_rebased[i].release();
+    if (c->copy_done[i]) (void)hipEventDestroy(c->copy_done[i]);
+  }
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   c->startbits.release();
   c->tiles.release();
@@ -1514,7 +1520,7 @@ void shk_destroy(shk_ctx *c) {
   c->acc_cur.release();
   c->xbuf.release();
   c->xspill.release();
-  for (int i = 0; i < 2; ++i) c->pk_stage[i].release(), c->nm_stage[i].release();
+  for (int i = 0; i < 3; ++i) c->pk_stage[i].release(), c->nm_stage[i].release(), c->nz_dev[i].release(), c->nz_host[i].release();
   c->pk_ascii.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1569,6 +1575,48 @@ int shk_reset(shk_ctx *c) {
 // overlap").  Striping is unaffected: ingest_core advances the running read index per slice.
 // packed != nullptr: the batch comes as the 2-bit stream + N mask of shk_pack_reads (offsets count BASES of
 // that stream); every slice's share of both crosses PCIe instead of its ASCII bytes and is unpacked in HBM.
+// The non-zero words of an N mask as (index, word) pairs — on a few threads: the caller is between two slices of
+// a host-buffer ingest, with the link busy and nothing else to do.  Returns the number of pairs, or ~0 when
+// there are more than `cap` (the mask then crosses the link as it is).
+static size_t nmask_nonzero(const uint32_t *w, size_t n, uint32_t *pairs, size_t cap) {
+  const unsigned T = (unsigned)std::max(1, std::min(8, (int)(n >> 18)));  // ≥ 1 MiB of mask per thread
+  std::vector<size_t> cnt(T, 0);
+  const size_t seg = cap / T;
+  auto work = [&](unsigned t) {
+    const size_t a = n * t / T, b = n * (t + 1) / T;
+    uint32_t *out = pairs + 2 * seg * t;
+    size_t k = 0;
+    size_t i = a;
+    for (; i < b && (i & 1); ++i)
+      if (w[i]) { if (k < seg) out[2 * k] = (uint32_t)i, out[2 * k + 1] = w[i]; ++k; }
+    for (; i + 8 <= b; i += 8) {  // (64-bit loads: the mask is 4-byte aligned, i is even here — and the host tolerates the rest)
+      uint64_t q[4];
+      memcpy(q, w + i, 32);
+      if ((q[0] | q[1] | q[2] | q[3]) == 0) continue;
+      for (size_t j = i; j < i + 8; ++j)
+        if (w[j]) { if (k < seg) out[2 * k] = (uint32_t)j, out[2 * k + 1] = w[j]; ++k; }
+    }
+    for (; i < b; ++i)
+      if (w[i]) { if (k < seg) out[2 * k] = (uint32_t)i, out[2 * k + 1] = w[i]; ++k; }
+    cnt[t] = k;
+  };
+  if (T == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  size_t total = 0;
+  for (unsigned t = 0; t < T; ++t) {
+    if (cnt[t] > seg) return ~(size_t)0;
+    if (t && cnt[t]) memmove(pairs + 2 * total, pairs + 2 * seg * t, cnt[t] * 8);
+    total += cnt[t];
+  }
+  return total;
+}
+
 static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_seqs,
                        int64_t lane_fixed, const uint8_t *packed = nullptr, const uint32_t *nmask = nullptr) {
   if (!c) return SHK_ERR_BAD_ARG;
@@ -1596,22 +1644,28 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   }
   const size_t n_slices = cut.size() - 1;
   if (!c->copy_stream) HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-  if (!c->copy_done[0]) {
-    HIPC(c, hipEventCreateWithFlags(&c->copy_done[0], hipEventDisableTiming));
-    HIPC(c, hipEventCreateWithFlags(&c->copy_done[1], hipEventDisableTiming));
-  }
+  if (!c->copy_done[0])
+    for (int i = 0; i < 3; ++i) HIPC(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
   bool offsets_pinned = false;
   {
     hipPointerAttribute_t at{};
     if (hipPointerGetAttributes(&at, offsets) == hipSuccess) offsets_pinned = at.type == hipMemoryTypeHost;
     else (void)hipGetLastError();  // (ordinary host memory: not an error)
   }
+  // THREE staging sets, taken in turn across slices and across calls: while slice i is counted, the copies of
+  // slices i+1 and i+2 are queued on the copy stream, so the link never waits for the host to come back from a
+  // counting launch — and the set a call starts with is never the one the previous call's last launch (which
+  // nobody may have waited for: SHK_FLAG_DEFER_ERRORS) is still reading.
+  const uint32_t s0 = c->stage_next;
+  auto set_of = [&](size_t i) { return (int)((s0 + i) % 3); };
+  auto bases_of = [&](int sel) -> DevBuf & { return sel == 0 ? c->in_bases : sel == 1 ? c->in_bases2 : c->in_bases3; };
+  auto offs_of = [&](int sel) -> DevBuf & { return sel == 0 ? c->in_offsets : sel == 1 ? c->in_offsets2 : c->in_offsets3; };
   auto issue_copy = [&](size_t i) -> int {
-    const int bsel = (int)(i & 1);
+    const int bsel = set_of(i);
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
     const uint64_t o0 = offsets[r0], nb = offsets[r1] - o0, ns = r1 - r0;
-    DevBuf &db = bsel ? c->in_bases2 : c->in_bases;
-    DevBuf &dof = bsel ? c->in_offsets2 : c->in_offsets;
+    DevBuf &db = bases_of(bsel);
+    DevBuf &dof = offs_of(bsel);
     HIPC(c, db.ensure(nb + 64));
     HIPC(c, dof.ensure((ns + 1) * 8));
     if (nb && packed) {  // the slice's bytes of the 2-bit stream and words of the N mask (+ pad: k_unpack reads a few bytes on)
@@ -1619,7 +1673,25 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
       HIPC(c, c->pk_stage[bsel].ensure(b1 - b0 + 16));
       HIPC(c, c->nm_stage[bsel].ensure((w1 - w0 + 2) * 4));
       HIPC(c, hipMemcpyAsync(c->pk_stage[bsel].p, packed + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream));
-      HIPC(c, hipMemcpyAsync(c->nm_stage[bsel].p, nmask + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, c->copy_stream));
+      // the N mask: a bit per base, a third of the slice's bytes — and nearly all zeros on most data.  When at
+      // most 1/16 of its words are non-zero they cross the link as a list and the rest is cleared on the device.
+      const size_t nw = (size_t)(w1 - w0), list_cap = nw / 16 + 64;
+      size_t nz = ~(size_t)0;
+      if (nw >= (1u << 16) && env_int("SHK_NMASK_SPARSE", 1)) {
+        HIPC(c, c->nz_host[bsel].ensure(list_cap * 8));
+        nz = nmask_nonzero(nmask + w0, nw, (uint32_t *)c->nz_host[bsel].p, list_cap);
+      }
+      if (nz != ~(size_t)0) {
+        HIPC(c, hipMemsetAsync(c->nm_stage[bsel].p, 0, nw * 4, c->copy_stream));
+        if (nz) {
+          HIPC(c, c->nz_dev[bsel].ensure(nz * 8));
+          HIPC(c, hipMemcpyAsync(c->nz_dev[bsel].p, c->nz_host[bsel].p, nz * 8, hipMemcpyHostToDevice, c->copy_stream));
+          hipLaunchKernelGGL(k_nmask_sparse, dim3((uint32_t)((nz + WG - 1) / WG)), dim3(WG), 0, c->copy_stream,
+                             (uint32_t *)c->nm_stage[bsel].p, (const uint2 *)c->nz_dev[bsel].p, (uint32_t)nz);
+        }
+      } else {
+        HIPC(c, hipMemcpyAsync(c->nm_stage[bsel].p, nmask + w0, nw * 4, hipMemcpyHostToDevice, c->copy_stream));
+      }
     } else if (nb)
       HIPC(c, hipMemcpyAsync(db.p, bases + o0, nb, hipMemcpyHostToDevice, c->copy_stream));
     // the caller's own offsets, as they are (the kernels that read them subtract the slice's first: off_bias) —
@@ -1635,27 +1707,33 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     HIPC(c, hipEventRecord(c->copy_done[bsel], c->copy_stream));
     return SHK_OK;
   };
+  // (sets s0 and s0+1 were last read by launches that a later launch of the previous call has waited for)
   int rc = issue_copy(0);
+  if (rc == SHK_OK && n_slices > 1) rc = issue_copy(1);
   if (rc != SHK_OK) return rc;
+  const bool trace = env_int("SHK_HOST_TRACE", 0) != 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto now_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
   for (size_t i = 0; i < n_slices; ++i) {
-    const int bsel = (int)(i & 1);
-    // the other buffer is free: slice i-1 was counted synchronously.  Its copy now overlaps
-    // the counting of slice i.
+    const int bsel = set_of(i);
+    const double ta = now_us();
     HIPC(c, hipEventSynchronize(c->copy_done[bsel]));  // `rebased[bsel]` consumed; data resident
-    // slice i-1 (launched without a host sync) read the buffer slice i+1 is about to overwrite
+    if (trace) fprintf(stderr, "[slice %zu] copy waited %.0f us (at %.0f)", i, now_us() - ta, now_us());
+    // slice i-1 (launched without a host sync) read the set that slice i+2 is about to overwrite
     rc = settle_light(c);
     if (rc != SHK_OK) {
       (void)hipStreamSynchronize(c->copy_stream);
       return rc;
     }
     HIPC(c, hipStreamSynchronize(c->stream));
-    if (i + 1 < n_slices) {
-      rc = issue_copy(i + 1);
+    if (trace) fprintf(stderr, " count(i-1) done at %.0f\n", now_us());
+    if (i + 2 < n_slices) {
+      rc = issue_copy(i + 2);
       if (rc != SHK_OK) return rc;
     }
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
-    DevBuf &db = bsel ? c->in_bases2 : c->in_bases;
-    DevBuf &dof = bsel ? c->in_offsets2 : c->in_offsets;
+    DevBuf &db = bases_of(bsel);
+    DevBuf &dof = offs_of(bsel);
     if (packed && offsets[r1] > offsets[r0]) {  // 2-bit stream + N mask → the slice's ASCII bytes, in HBM
       const uint64_t o0 = offsets[r0], nb = offsets[r1] - o0;
       // (the staged copies start at byte o0/4 resp. word o0/32 of the streams; what k_unpack reads past their
@@ -1671,6 +1749,11 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
       return rc;
     }
   }
+  c->stage_next = (s0 + (uint32_t)n_slices) % 3;
+  // A host-buffer ingest reports its errors (an invalid byte) before returning — unless the caller asked for
+  // the device-buffer behaviour (SHK_FLAG_DEFER_ERRORS): then the last slice's launch is looked at by the next
+  // call, whose first copies run under it.
+  if (c->cfg.flags & SHK_FLAG_DEFER_ERRORS) return SHK_OK;
   return settle_light(c);  // host-buffer ingest reports its errors (an invalid byte) before returning
 }
 

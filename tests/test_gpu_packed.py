@@ -104,3 +104,20 @@ def test_packed_device_resident_ingest(orc):
         eng.finalize()
         assert np.array_equal(eng.histograms(), ref.histograms())
         assert eng.counters()["n_bases_ingested"] == ref.stats["n_bases_ingested"]
+
+
+@pytest.mark.parametrize("n_per_64k", [0, 6, 30000])
+def test_packed_ingest_sparse_n_mask(orc, n_per_64k):
+    """Slices of ≥ 2 M bases send an N mask that is nearly all zeros as the list of its non-zero words (none at
+    all, a few, or — every other base an N — the mask as it is): the counts must not care."""
+    spec = sa.SynthSpec(genome_len=400_000, sub_per_64k=100, n_per_64k=n_per_64k)
+    bases, offsets = sa.synth_reads(spec, 0, 40_000)  # 6 M bases: one slice of 1.5 M (a mask as it is), one of 4.5 M
+    ref = orc.run_batch(bases, offsets, 21, 2, 300)
+    pk = sa.pack_reads(bases, offsets, pinned=True)
+    with sa.KmerEngine(21, 2, 300) as eng:
+        eng.ingest_packed(pk)
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms())
+        c = eng.counters()
+    for f in ("n_reads_ingested", "n_bases_read", "n_bases_ingested", "n_kmers_ingested", "n_unique_kmers"):
+        assert c[f] == ref.stats[f], f

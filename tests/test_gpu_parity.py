@@ -392,6 +392,27 @@ def test_streamed_slices_match_oracle(orc, monkeypatch, k, chunks):
     check_against_oracle(orc, bases, offsets, k, chunks, 60, check_table=False)
 
 
+def test_deferred_errors_overlap_calls_and_still_report(orc, monkeypatch):
+    """SHK_FLAG_DEFER_ERRORS: a host-buffer ingest returns once its last slice is queued (the next call's copies
+    run under it, on the staging sets taken in turn); the result is the oracle's, and an invalid byte is reported
+    by the NEXT call with the reference's text."""
+    monkeypatch.setenv("SHK_SLICE_KB", "64")
+    rng = np.random.default_rng(5)
+    bases, offsets = ragged_reads(rng, 9_000, max_len=160)
+    ref = orc.run_batch(bases, offsets, 21, 3, 60)
+    with sa.KmerEngine(21, 3, 60, flags=sa.FLAG_DEFER_ERRORS) as eng:
+        for a, b in ((0, 2_500), (2_500, 2_600), (2_600, 7_000), (7_000, 9_000)):  # 1, many and few slices per call
+            eng.ingest_reads(bases, offsets[a:b + 1])
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms())
+        eng.reset()
+        bad = bases[:int(offsets[50])].copy()
+        bad[int(offsets[20]) + 3] = ord("Q")
+        eng.ingest_reads(bad, offsets[:51])  # queued: nobody has looked yet
+        with pytest.raises(sa.ShkError, match="Invalid character 'Q' in sequence. Only ACGTN allowed."):
+            eng.ingest_reads(bases, offsets[:11])
+
+
 def test_config3_shape_k31_properties():
     """k=31 at a size the oracle would take minutes for: size-independent properties only —
     Σ freq·count = k-mer occurrences, Σ freq = distinct, chunk-count invariance of the final
