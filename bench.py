@@ -146,7 +146,7 @@ def extras(sa, torch, dev):
                     best = dt if best is None else min(best, dt)
                 res["pinned_packed"] = {"Gbases_per_s": round(n * L / best / 1e9, 2),
                                         "bound": "2-bit packed stream + N mask (as the list of its non-zero words when they are few) + 8-B offsets over PCIe (shk_pack_reads untimed)",
-                                        "pcie_GB_per_s": round(pk.nbytes / best / 1e9, 2),
+                                        "pcie_GB_per_s": round(pk.wire_bytes() / best / 1e9, 2), "wire_bytes_per_base": round(pk.wire_bytes() / (n * L), 3),
                                         "host_pack_Gbases_per_s": round(n * L / t_p / 1e9, 2)}
         return res
     guarded("host_pinned", host_pinned)

@@ -677,6 +677,14 @@ class PackedReads:
     def nbytes(self):
         return self.packed.nbytes + self.nmask.nbytes + self.offsets.nbytes
 
+    def wire_bytes(self) -> int:
+        """What shk_ingest_packed moves over PCIe for this batch: the 2-bit stream, the offsets, and the N mask —
+        as (index, word) pairs of its non-zero words when those are at most 1/16 of it (per slice in the engine;
+        estimated here over the whole batch)."""
+        nz = int(np.count_nonzero(self.nmask))
+        mask = 8 * nz if nz <= self.nmask.size // 16 else self.nmask.nbytes
+        return self.packed.nbytes + self.offsets.nbytes + mask
+
 
 def pack_reads(bases: np.ndarray, offsets: np.ndarray, threads: int = 0, pinned: bool = False) -> PackedReads:
     """shk_pack_reads over a batch of concatenated ASCII reads (host, multi-threaded).  pinned: the
