@@ -801,12 +801,17 @@ __global__ void __launch_bounds__(WG) k_mark_starts(const uint64_t *__restrict__
                                                     uint64_t n_seqs, uint64_t n_bases,
                                                     uint32_t *__restrict__ startbits, uint64_t sb_words,
                                                     unsigned int *__restrict__ zero_u32, uint32_t n_zero,
-                                                    unsigned long long *__restrict__ zero_u64, uint64_t off_bias) {
+                                                    unsigned long long *__restrict__ zero_u64, uint64_t off_bias,
+                                                    uint4 *__restrict__ zero_a16 = nullptr, uint32_t n_a16 = 0,
+                                                    uint4 *__restrict__ zero_b16 = nullptr, uint32_t n_b16 = 0) {
   // off_bias: what the offsets are ahead of the batch's first byte by (a slice of a host batch is handed on with
   // the caller's own offsets: no re-based copy is made on the host)
   const uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
   for (uint64_t j = i; j < n_zero; j += (uint64_t)gridDim.x * WG) zero_u32[j] = 0;
   if (i == 0 && zero_u64) *zero_u64 = 0;
+  // (the histogram and totals a finalize has read back: cleared here, on the way, instead of by a launch of their own)
+  for (uint64_t j = i; j < n_a16; j += (uint64_t)gridDim.x * WG) zero_a16[j] = make_uint4(0u, 0u, 0u, 0u);
+  for (uint64_t j = i; j < n_b16; j += (uint64_t)gridDim.x * WG) zero_b16[j] = make_uint4(0u, 0u, 0u, 0u);
   if (i >= n_seqs) return;
   const uint64_t o = offsets[i] - off_bias;
   const uint64_t w = o >> 5;

@@ -142,6 +142,9 @@ struct shk_ctx {
   // shk_reset does not clear the table: the first page pass that covers every page and lane writes it whole
   // (k_pages32<true>); anything else that touches the table first clears it then (tb_fresh)
   bool tb_stale = false;
+  // the histogram and totals on the device still hold what the last finalize read back: cleared by the next
+  // reset, by the next ingest's k_mark_starts on its way, or by the next scan itself — not by a launch per finalize
+  bool hist_dirty = false;
   uint32_t own_share_n = 0, own_share_id = 0;  // … or as a share of the pages, resolved when a scan is launched
   bool finalized = false, poisoned = false;
   bool finalize_redone = false;  // the last finalize repeated its histogram scan after repairing spills
@@ -491,7 +494,10 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     ScopedTimer t(c, SHK_K_MARK);
     hipLaunchKernelGGL(k_mark_starts, dim3((uint32_t)((n_seqs + WG - 1) / WG)), dim3(WG), 0,
                        c->stream, d_offsets, n_seqs, n_bases, (uint32_t *)c->startbits.p, (uint64_t)sb_words,
-                       (unsigned int *)c->part_meta.p, n_cursor_words, &c->d_stats->spill_count, off_bias);
+                       (unsigned int *)c->part_meta.p, n_cursor_words, &c->d_stats->spill_count, off_bias,
+                       (uint4 *)c->d_tot, c->hist_dirty ? (uint32_t)(sizeof(HistoTotals) / 16) : 0u, (uint4 *)c->d_hist,
+                       c->hist_dirty ? (uint32_t)((c->ctl_bytes - c->ctl_hist_off) / 16) : 0u);
+    c->hist_dirty = false;
     if (multi)
       hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(TB_WG), 0, c->stream, d_offsets, n_seqs, g0,
                          NL, n_blocks, (TileDesc *)c->tiles.p, c->d_stats, off_bias);
@@ -1547,6 +1553,7 @@ int shk_reset(shk_ctx *c) {
     int rc = fill_state(c, env_int("SHK_NO_FRESH", 0) ? c->tb : none, true);
     if (rc != SHK_OK) return rc;
     c->tb_stale = !env_int("SHK_NO_FRESH", 0);
+    c->hist_dirty = false;
   }
   memset(c->h_stats, 0, sizeof(DevStats));
   c->h_stats->bad = ~0ull;
@@ -2066,7 +2073,16 @@ static int finalize_scan(shk_ctx *c) {
   }
   const uint32_t n_cols = c->cfg.chunks;
   const uint64_t hlen = c->cfg.histo_max + 2;
-  // d_hist and d_tot are zero here: they are zeroed by reset and again right after every read-back
+  if (c->hist_dirty) {  // nothing has come between the last read-back and this scan: histogram + totals back to zero now
+    FillSegs f{};
+    f.ptr[0] = c->d_tot;
+    f.n16[0] = sizeof(HistoTotals) / 16;
+    f.ptr[1] = c->d_hist;
+    f.n16[1] = (c->ctl_bytes - c->ctl_hist_off) / 16;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(f.n16[0] + f.n16[1], WG * 4, 1024)), dim3(WG), 0, c->stream, f);
+    c->hist_dirty = false;
+  }
+  // d_hist and d_tot are zero here
   uint64_t s0 = 0, s1 = c->tb.cap;
   if (c->own_set) {
     own_resolve(c);
@@ -2098,14 +2114,7 @@ static int finalize_scan(shk_ctx *c) {
 static int finalize_fetch(shk_ctx *c) {
   HIPC(c, hipMemcpyAsync(c->h_ctl, c->d_ctl, c->ctl_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipEventRecord(c->done_ev, c->stream));  // the host waits for the copy, not for what follows it
-  {  // histogram + totals back to zero for the next scan; nobody waits for this
-    FillSegs f{};
-    f.ptr[0] = c->d_tot;
-    f.n16[0] = sizeof(HistoTotals) / 16;
-    f.ptr[1] = c->d_hist;
-    f.n16[1] = (c->ctl_bytes - c->ctl_hist_off) / 16;
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(f.n16[0] + f.n16[1], WG * 4, 1024)), dim3(WG), 0, c->stream, f);
-  }
+  c->hist_dirty = true;  // (cleared by whoever comes next: reset, an ingest, or the next scan)
   {
     // poll first: the blocking wait's wake-up alone costs the host tens of µs, a tenth of a whole
     // 1 M-read job; a run that takes longer than the poll window falls through to the blocking wait
