@@ -263,10 +263,36 @@ def extras(sa, torch, dev):
                              "kernels_ms_per_step": _timings_ms(eng, steps)}
         return res
     guarded("shapes", shapes)
+
+    # ---- the multi-GPU finalize's fixed cost: this very bench with SHK_BENCH_FORCE_DIST=1 (the table exchange and
+    # the device-side histogram reduction over RCCL in a world of ONE: what every rank of an N-GPU run adds per
+    # job) and without, as child processes one after the other -------------------------------------------------
+    def dist_fixed_cost():
+        import subprocess
+        res = {}
+        for name, force in (("plain", False), ("merged", True)):
+            env = dict(os.environ)
+            env.pop("SHK_BENCH_FORCE_DIST", None)
+            if force:
+                env["SHK_BENCH_FORCE_DIST"] = "1"
+                env["MASTER_PORT"] = "29543"
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline"], env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            res[name] = json.loads(r.stdout.decode().strip().splitlines()[-1])["ms_per_step"]
+        return {"workload": "config 2's step (bench.py defaults) with SHK_BENCH_FORCE_DIST=1 — fixed-capacity pieces + in-place histogram "
+                            "all_reduce over RCCL, world of one — and without",
+                "ms_per_step_plain": res["plain"], "ms_per_step_merged": res["merged"],
+                "fixed_cost_ms": round(res["merged"] - res["plain"], 4)}
+    guarded("dist_fixed_cost", dist_fixed_cost)
     return out
 
 
 def main():
+    # ONE line on stdout, whatever libraries print on theirs (RCCL announces its version there when a communicator
+    # is created): the process's stdout goes to stderr until the JSON line is written to the real one
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 50 warm-up steps (≈40 ms) because the first ≈20 ms of work after the card has been idle run
@@ -483,7 +509,8 @@ def main():
             del d_bases, d_offsets
             torch.cuda.empty_cache()
             out["extras"] = extras(sa, torch, dev)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
