@@ -45,6 +45,14 @@ for case in range(n_cases):
     try:
         ref = orc.run_batch(bases, offsets, k, chunks, histo_max)
         with sa.KmerEngine(k, chunks, histo_max, capacity_hint=hint, flags=flags) as eng:
+            if rng.random() < 0.5:  # a job before this one: the table's memory holds its leftovers after the reset
+                ob, oo = sa.synth_reads(sa.SynthSpec(genome_len=max(genome // 2, read_len), read_len=read_len, sub_per_64k=500),
+                                        7, max(n_reads // 2, 1))
+                eng.ingest_reads(ob, oo)
+                if rng.random() < 0.5:
+                    eng.finalize()
+                eng.reset()
+                desc += " after-reset"
             for a, b in zip(cuts[:-1], cuts[1:]):
                 eng.ingest_reads(bases[int(offsets[a]):int(offsets[b])], offsets[a:b + 1] - offsets[a])
             eng.finalize()

@@ -575,6 +575,37 @@ def test_two_level_partition_small(orc, monkeypatch, k, chunks, lvl1):
     assert cnt["table_capacity"] >= 8 * 8192
 
 
+@pytest.mark.parametrize("chunks", [2, 10, 16])
+@pytest.mark.parametrize("dirty", [False, True])
+def test_two_level_many_lanes_one_page_launch(orc, monkeypatch, chunks, dirty):
+    """Chunk lanes on the forced two-level geometry: a batch over several lanes takes ONE level-1 pass, ONE
+    level-2 pass and ONE page launch that keeps a page's tags in LDS for all its lanes — and, the table's memory
+    never having been cleared (or holding the leftovers of a job before the reset: `dirty`), that launch is the
+    FRESH one, which writes every lane of every page whole.  A second batch then goes through the ordinary pass."""
+    monkeypatch.setenv("SHK_TWO_LEVEL_MIN_PAGES", "4")
+    monkeypatch.setenv("SHK_LEVEL1_LOG", "2")
+    spec = sa.SynthSpec(genome_len=150_000, sub_per_64k=328, n_per_64k=66)
+    bases, offsets = sa.synth_reads(spec, 0, 50_000)
+    ref = orc.run_batch(bases, offsets, 21, chunks, 200)
+    with sa.KmerEngine(21, chunks, 200, capacity_hint=400_000) as eng:
+        if dirty:
+            ob, oo = sa.synth_reads(sa.SynthSpec(genome_len=90_000, sub_per_64k=900), 3, 20_000)
+            eng.ingest_reads(ob, oo)
+            eng.finalize()
+            eng.reset()
+        eng.ingest_reads(bases, offsets[:30_001])   # → FRESH page launch (at the latest when finalize asks)
+        eng.sync()
+        eng.ingest_reads(bases, offsets[30_000:])   # → ordinary page launch over the same pages
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms())
+        c = eng.counters()
+        keys, cnts = eng.export_table()
+    for f in ("n_reads_ingested", "n_bases_ingested", "n_kmers_ingested", "n_unique_kmers", "n_hashed_kmers"):
+        assert c[f] == ref.stats[f], f
+    rk, rc = ref.merged().export()
+    assert np.array_equal(keys, rk) and np.array_equal(cnts, rc)
+
+
 def test_two_level_partition_large_table():
     """A table past MAX_PARTS pages (64 M distinct-k-mer hint ⇒ 16 Ki pages) takes the two-level
     path by itself; properties at a size the oracle is too slow for."""
