@@ -2672,11 +2672,11 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
                                                  const unsigned int *__restrict__ cursor, uint32_t cap_p,
                                                  const uint64_t *__restrict__ part_buf,
                                                  uint64_t *__restrict__ miss_buf,
-                                                 DevStats *__restrict__ stats, SpillRef sp) {
+                                                 DevStats *__restrict__ stats, SpillRef sp, uint32_t page0 = 0) {
   __shared__ __attribute__((aligned(16))) uint64_t keys[PAGE_SLOTS];
   __shared__ __attribute__((aligned(16))) uint32_t dl[PAGE_SLOTS / 2];
   if (stats->bad != ~0ull) return;
-  const uint32_t page = blockIdx.x;
+  const uint32_t page = blockIdx.x + page0;  // (page0: a launch over a range of pages — grouped flush, see flush_acc)
   const uint32_t filled = cursor[page] < cap_p ? cursor[page] : cap_p;  // beyond cap_p: spilled
   if (filled == 0) return;  // nothing for this page: leave it untouched in HBM
   uint64_t *gk = tb.keys + ((uint64_t)page << PAGE_LOG);
@@ -2891,12 +2891,12 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
                                                    uint32_t lane_stride, uint32_t n_regions_,
                                                    const unsigned int *__restrict__ cursor, uint32_t cap_p,
                                                    const uint32_t *__restrict__ part_buf,
-                                                   DevStats *__restrict__ stats, SpillRef sp) {
+                                                   DevStats *__restrict__ stats, SpillRef sp, uint32_t page0 = 0) {
   __shared__ __attribute__((aligned(16))) uint32_t tags[PAGE_SLOTS];
   __shared__ __attribute__((aligned(16))) uint32_t dl[PAGE_SLOTS];  // this pass's count per slot
   __shared__ __attribute__((aligned(16))) uint32_t mqs[(PG_WG / 64) * MQ32];
   if (stats->bad != ~0ull) return;
-  const uint32_t page = blockIdx.x;
+  const uint32_t page = blockIdx.x + page0;
   if (!FRESH) {
     uint32_t any = 0;
     for (uint32_t l = lane_lo; l < lane_hi; ++l) any |= cursor[l * lane_stride + page];

@@ -30,6 +30,7 @@ static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub, bool multi);
 static int settle(shk_ctx *c);
 static int settle_light(shk_ctx *c);
 static int flush_acc(shk_ctx *c);
+static int replay_held_spills(shk_ctx *c);
 static uint64_t acc_records_est(const shk_ctx *c, uint64_t kmers_ub);
 struct XchgOut;
 static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo);
@@ -145,6 +146,8 @@ struct shk_ctx {
   // the histogram and totals on the device still hold what the last finalize read back: cleared by the next
   // reset, by the next ingest's k_mark_starts on its way, or by the next scan itself — not by a launch per finalize
   bool hist_dirty = false;
+  std::vector<uint64_t> held_keys;   // spilled records taken off the device during a grouped flush (flush_acc)
+  std::vector<uint32_t> held_lanes, held_counts;
   uint32_t own_share_n = 0, own_share_id = 0;  // … or as a share of the pages, resolved when a scan is launched
   bool finalized = false, poisoned = false;
   bool finalize_redone = false;  // the last finalize repeated its histogram scan after repairing spills
@@ -1272,6 +1275,10 @@ static int settle_checked(shk_ctx *c) {
   }
   int rc = drain_spill(c, c->unsettled_spill_cap);
   if (rc != SHK_OK) return rc;
+  if (!c->held_keys.empty() && !c->acc_active) {  // what a grouped flush took off the device goes back in now
+    rc = replay_held_spills(c);
+    if (rc != SHK_OK) return rc;
+  }
   // keep the load factor ≤ 1/2 for the next launch
   if (c->h_stats->n_distinct * 2 > c->tb.cap) {
     rc = grow_to(c, log_pages_for(c->h_stats->n_distinct * 4, c->owner_bits));
@@ -1280,9 +1287,64 @@ static int settle_checked(shk_ctx *c) {
   return SHK_OK;
 }
 
+// Spilled records that were taken off the device in the middle of a grouped flush (below): they go back in, through
+// the ordinary repair path (which may grow the table), once no records wait for the old geometry any more.
+static int hold_spills(shk_ctx *c, uint64_t spill_cap) {
+  const uint64_t n = c->h_stats->spill_count;
+  if (n == 0) return SHK_OK;
+  if (n > spill_cap)
+    return fail(c, SHK_ERR_INVARIANT, "spill list overflow (%llu > %llu)", (unsigned long long)n, (unsigned long long)spill_cap);
+  SpillRef sp = spill_ref(c->spillA, spill_cap);
+  const size_t at = c->held_keys.size();
+  c->held_keys.resize(at + n);
+  c->held_lanes.resize(at + n);
+  c->held_counts.resize(at + n);
+  HIPC(c, hipMemcpyAsync(c->held_keys.data() + at, sp.keys, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipMemcpyAsync(c->held_lanes.data() + at, sp.lanes, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipMemcpyAsync(c->held_counts.data() + at, sp.counts, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  c->h_stats->spill_count = 0;
+  return SHK_OK;
+}
+static int replay_held_spills(shk_ctx *c) {
+  // (a flush that spilled a quarter of a table's worth of records: whatever the caller's capacity hint promised is
+  // not what the data hold — from here on windows end when the evidence says so)
+  if (c->held_keys.size() > c->tb.cap / 4) c->cfg.table_capacity_hint = 0;
+  while (!c->held_keys.empty()) {
+    const uint64_t cap = std::max<uint64_t>(std::min<uint64_t>(c->held_keys.size(), 1ull << 26), 1);
+    const uint64_t n = std::min<uint64_t>(c->held_keys.size(), cap);
+    HIPC(c, c->spillA.ensure(cap * 16));
+    SpillRef sp = spill_ref(c->spillA, cap);
+    const size_t at = c->held_keys.size() - n;  // (from the back: the vectors shrink as they are replayed)
+    HIPC(c, hipMemcpyAsync(sp.keys, c->held_keys.data() + at, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(sp.lanes, c->held_lanes.data() + at, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(sp.counts, c->held_counts.data() + at, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->held_keys.resize(at);
+    c->held_lanes.resize(at);
+    c->held_counts.resize(at);
+    c->h_stats->spill_count = n;
+    int rc = drain_spill(c, cap);
+    if (rc != SHK_OK) return rc;
+  }
+  std::vector<uint64_t>().swap(c->held_keys);
+  std::vector<uint32_t>().swap(c->held_lanes);
+  std::vector<uint32_t>().swap(c->held_counts);
+  return SHK_OK;
+}
+
 // Count the records that are waiting in the accumulation regions: one k_pages32 launch over every
 // lane's regions, then the cursors go back to zero.  The launch's outcome is looked at by the
 // settle that follows.
+//
+// EXACTNESS WHATEVER THE TABLE'S SIZE: a page pass spills at most the records it reads, and a region holds at
+// most acc_cap of them, so a launch over G pages can put at most G · lanes · acc_cap entries on the spill list.
+// When that bound for ALL pages exceeds the list (a window far larger than the list — or a capacity hint that was
+// far too low: every new key of every page spills), the flush goes over the pages in GROUPS whose bound fits;
+// after each group the host takes what was spilled off the device (hold_spills: pinned-size independent, it is
+// ordinary host memory) — the table cannot be grown while records still wait for its geometry — and puts it back
+// through the ordinary repair path once the last group is done (replay_held_spills, from settle_checked).
 static int flush_acc(shk_ctx *c) {
   if (!c->acc_active) return SHK_OK;
   const uint32_t n_pages = 1u << c->acc_lp;
@@ -1298,27 +1360,55 @@ static int flush_acc(shk_ctx *c) {
     int rcf = tb_fresh(c);
     if (rcf != SHK_OK) return rcf;
   }
-  if (c->acc_rec32) {
-    ScopedTimer t(c, SHK_K_PAGES);
-    if (fresh)
-      hipLaunchKernelGGL(k_pages32<true>, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
-                         NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
-                         c->d_stats, sp);
-    else
-      hipLaunchKernelGGL(k_pages32<false>, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
-                         NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
-                         c->d_stats, sp);
-    c->tb_stale = false;
-  } else {  // 8-byte records: one page pass per lane over that lane's regions
+  // pages per launch so that even if every record of every one of them spilled the list would hold them
+  const uint64_t per_page_ub = (uint64_t)(c->acc_rec32 ? NL : 1u) * c->acc_cap;
+  uint64_t ppg = std::max<uint64_t>(spill_cap / std::max<uint64_t>(per_page_ub, 1), 1);
+  if (env_int("SHK_FLUSH_GROUP_PAGES", 0) > 0) ppg = (uint64_t)env_int("SHK_FLUSH_GROUP_PAGES", 0);  // test hook
+  // (a window whose records all fit the list — the usual case — is one launch whatever the regions could hold)
+  const bool grouped = ppg < n_pages && (c->acc_records_ub > spill_cap || env_int("SHK_FLUSH_GROUP_PAGES", 0) > 0);
+  if (!grouped) ppg = n_pages;
+  if (grouped) {  // the partition launches' own spills first: the groups need the whole list
+    int rc = read_stats(c);
+    if (rc != SHK_OK) return rc;
+    if (c->h_stats->bad != ~0ull) return SHK_OK;  // (the settle that follows reports it; nothing is counted)
+    rc = hold_spills(c, spill_cap);
+    if (rc != SHK_OK) return rc;
+  }
+  if (!c->acc_rec32)
     HIPC(c, c->part2.ensure((uint64_t)n_pages * std::min<uint64_t>((uint64_t)c->acc_cap + MISS_SLACK, MISS_PAGE_MAX) * 8));  // (planned with the regions)
-    for (uint32_t lane = 0; lane < NL; ++lane) {
+  for (uint64_t p0 = 0; p0 < n_pages; p0 += ppg) {
+    const uint32_t gp = (uint32_t)std::min<uint64_t>(ppg, n_pages - p0);
+    if (c->acc_rec32) {
       ScopedTimer t(c, SHK_K_PAGES);
-      hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
-                         (const unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
-                         (const uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap,
-                         (uint64_t *)c->part2.p, c->d_stats, sp);
+      if (fresh)
+        hipLaunchKernelGGL(k_pages32<true>, dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+                           NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
+                           c->d_stats, sp, (uint32_t)p0);
+      else
+        hipLaunchKernelGGL(k_pages32<false>, dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+                           NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
+                           c->d_stats, sp, (uint32_t)p0);
+    } else {  // 8-byte records: one page pass per lane over that lane's regions
+      for (uint32_t lane = 0; lane < NL; ++lane) {
+        ScopedTimer t(c, SHK_K_PAGES);
+        hipLaunchKernelGGL(k_pages, dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, lane,
+                           (const unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
+                           (const uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap,
+                           (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
+        if (grouped) {  // (a lane's launch over the group is bounded by gp · acc_cap on its own)
+          int rc = read_stats(c);
+          if (rc == SHK_OK) rc = hold_spills(c, spill_cap);
+          if (rc != SHK_OK) return rc;
+        }
+      }
+    }
+    if (grouped && c->acc_rec32) {
+      int rc = read_stats(c);
+      if (rc == SHK_OK) rc = hold_spills(c, spill_cap);
+      if (rc != SHK_OK) return rc;
     }
   }
+  if (c->acc_rec32) c->tb_stale = false;
   HIPC(c, hipMemsetAsync(c->acc_cur.p, 0, (size_t)NL * n_pages * 4, c->stream));
   c->acc_active = false;
   c->acc_records_ub = 0;
@@ -1564,6 +1654,9 @@ int shk_reset(shk_ctx *c) {
   c->n_inserted = 0;
   c->own_set = false;
   c->own_share_n = 0;
+  c->held_keys.clear();
+  c->held_lanes.clear();
+  c->held_counts.clear();
   c->zero_count_keys = false;
   c->finalized = c->poisoned = c->hist_ready = false;
   c->unsettled = false;  // the memsets above are ordered behind any launch still in flight

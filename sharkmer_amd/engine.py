@@ -250,6 +250,7 @@ class KmerEngine:
         self._L = load_library()
         self.k, self.chunks, self.histo_max = k, chunks, histo_max
         self.n_owners, self.owner_id = max(n_owners, 1), owner_id
+        self._tdev = f"cuda:{device}"  # torch tensors over this context's memory live on ITS device, whatever torch's current one is
         cfg = _Config(k=k, chunks=chunks, histo_max=histo_max, device=device, flags=flags,
                       table_capacity_hint=capacity_hint, n_owners=n_owners, owner_id=owner_id)
         if device_ids is not None:
@@ -358,7 +359,7 @@ class KmerEngine:
         a reduction over the ranks may sum in place — on the engine's stream."""
         p, n = C.c_void_p(), C.c_uint64()
         self._check(self._L.shk_finalize_begin(self._h, user_word, C.byref(p), C.byref(n)))
-        return self._raw_tensor(p.value, int(n.value), "<i8")
+        return self._raw_tensor(p.value, int(n.value), "<i8", self._tdev)
 
     def finalize_end(self):
         """shk_finalize_end → (again, Σ user_word)."""
@@ -522,8 +523,8 @@ class KmerEngine:
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr,
                                                  "data": (ptr, False), "version": 2}
 
-        keys = torch.as_tensor(_Raw(dk, (cap,), "<i8"), device="cuda")
-        vals = torch.as_tensor(_Raw(dv, (n_lanes, cap), "<i4"), device="cuda")
+        keys = torch.as_tensor(_Raw(dk, (cap,), "<i8"), device=self._tdev)
+        vals = torch.as_tensor(_Raw(dv, (n_lanes, cap), "<i4"), device=self._tdev)
         return keys, vals
 
     def merge_page_tensors(self, p0: int, p1: int, keys_t, vals_t):
@@ -553,8 +554,8 @@ class KmerEngine:
         counts = np.asarray(counts, dtype=np.uint64)
         n = int(counts.sum())
         _, _, n_lanes = self.table_geometry()
-        keys = torch.empty(max(n, 1), dtype=torch.int64, device="cuda")
-        vals = torch.empty((n_lanes, max(n, 1)), dtype=torch.int32, device="cuda")
+        keys = torch.empty(max(n, 1), dtype=torch.int64, device=self._tdev)
+        vals = torch.empty((n_lanes, max(n, 1)), dtype=torch.int32, device=self._tdev)
         off = np.zeros(len(counts), dtype=np.uint64)
         off[1:] = np.cumsum(counts)[:-1]
         self._check(self._L.shk_compact_owners(self._h, len(counts), off.ctypes.data, keys.data_ptr(),
@@ -569,7 +570,7 @@ class KmerEngine:
         counts = np.ascontiguousarray(counts, dtype=np.uint64)
         _, _, n_lanes = self.table_geometry()
         n = int(counts.sum())
-        buf = torch.empty(max(n * (2 + n_lanes), 1), dtype=torch.int32, device="cuda")
+        buf = torch.empty(max(n * (2 + n_lanes), 1), dtype=torch.int32, device=self._tdev)
         self._check(self._L.shk_compact_owners_packed(self._h, len(counts), counts.ctypes.data, buf.data_ptr(), skip_owner))
         return buf[:n * (2 + n_lanes)], n_lanes
 
@@ -578,7 +579,7 @@ class KmerEngine:
         piece o = [header 2 ints][k-mers 2·capacity][lane counts capacity each], unused places EMPTY."""
         import torch
         n_lanes = max(1, self.chunks)  # (not table_geometry(): that waits for the counting launches)
-        buf = torch.empty(n_owners * (2 + capacity * (2 + n_lanes)), dtype=torch.int32, device="cuda")
+        buf = torch.empty(n_owners * (2 + capacity * (2 + n_lanes)), dtype=torch.int32, device=self._tdev)
         self._check(self._L.shk_compact_owners_fixed(self._h, n_owners, capacity, buf.data_ptr(), skip_owner))
         return buf, n_lanes
 
@@ -611,7 +612,7 @@ class KmerEngine:
 
     # -- exchange rounds as torch tensors (sharkmer_amd/dist.py: OwnerCounter) -----------------------
     @staticmethod
-    def _raw_tensor(ptr: int, n: int, typestr: str):
+    def _raw_tensor(ptr: int, n: int, typestr: str, device: str = "cuda"):
         import torch
 
         class _Raw:  # minimal __cuda_array_interface__ carrier
@@ -619,15 +620,15 @@ class KmerEngine:
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr,
                                                  "data": (ptr, False), "version": 2}
         if n == 0 or not ptr:
-            return torch.empty(0, dtype={"<i4": torch.int32, "<i8": torch.int64, "|u1": torch.uint8}[typestr], device="cuda")
-        return torch.as_tensor(_Raw(ptr, (n,), typestr), device="cuda")
+            return torch.empty(0, dtype={"<i4": torch.int32, "<i8": torch.int64, "|u1": torch.uint8}[typestr], device=device)
+        return torch.as_tensor(_Raw(ptr, (n,), typestr), device=device)
 
     def xchg_scatter_tensors(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int, layout_bases: int = 0):
         """One round's level-1 scatter → (records int32[W·segment_records], cursors int32[W·regions],
         layout, n_foreign_spilled) as zero-copy views of the context's exchange buffer."""
         rec, cur, lay, nf = self.xchg_scatter_device(d_bases, d_offsets, n_seqs, n_bases, layout_bases)
         W = lay.n_owners
-        return (self._raw_tensor(rec, W * lay.segment_records, "<i4"), self._raw_tensor(cur, W * lay.regions, "<i4"),
+        return (self._raw_tensor(rec, W * lay.segment_records, "<i4", self._tdev), self._raw_tensor(cur, W * lay.regions, "<i4", self._tdev),
                 lay, nf)
 
     def xchg_absorb_tensors(self, rec_t, cur_t, lay):
@@ -638,7 +639,7 @@ class KmerEngine:
     def xchg_spill_tensors(self):
         """(kmers int64[n], lanes int32[n], counts int32[n]) views of the foreign spill list."""
         k, l, c, n = self.xchg_spill()
-        return self._raw_tensor(k, n, "<i8"), self._raw_tensor(l, n, "<i4"), self._raw_tensor(c, n, "<i4")
+        return self._raw_tensor(k, n, "<i8", self._tdev), self._raw_tensor(l, n, "<i4", self._tdev), self._raw_tensor(c, n, "<i4", self._tdev)
 
     def insert_tensors(self, kmers_t, lanes_t, counts_t):
         n = kmers_t.numel()

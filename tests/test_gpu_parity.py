@@ -850,6 +850,33 @@ def test_deferred_page_passes_two_level(orc, monkeypatch, k, chunks, hint, budge
     _deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget)
 
 
+@pytest.mark.parametrize("k,chunks", [(21, 1), (21, 3), (31, 2)])
+def test_grouped_flush_with_a_hint_far_too_low(orc, monkeypatch, k, chunks):
+    """A capacity hint is a promise the engine must survive: with one the deferred window never ends for the
+    table's sake, so a hint far too low lets a page pass meet several times more new k-mers than its pages hold —
+    every one of them a spilled record.  A flush whose records could outnumber the spill list goes over the pages
+    in groups and parks what each group spills in host memory until no record waits for the old geometry any more
+    (here: forced groups of 7 pages); the table then grows through the ordinary repair path.  Exact all the same."""
+    monkeypatch.setenv("SHK_FLUSH_GROUP_PAGES", "7")
+    spec = sa.SynthSpec(genome_len=6_000_000, sub_per_64k=100, n_per_64k=30)   # ≈ 5 M distinct k-mers …
+    bases, offsets = sa.synth_reads(spec, 0, 45_000)
+    ref = orc.run_batch(bases, offsets, k, chunks, 100)
+    with sa.KmerEngine(k, chunks, 100, capacity_hint=1_100_000) as eng:          # … promised: 1.1 M
+        for a in range(0, 45_000, 1_500):
+            eng.ingest_reads(bases, offsets[a:a + 1_501])
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms())
+        c = eng.counters()
+        keys, cnts = eng.export_table()
+    assert c["n_grows"] >= 1
+    if chunks == 1:  # (several lanes take the owner-layout route, whose windows end before the pages overflow)
+        assert c["n_spilled"] > 10_000
+    for f in ("n_kmers_ingested", "n_unique_kmers", "n_hashed_kmers", "n_bases_ingested"):
+        assert c[f] == ref.stats[f], f
+    rk, rc = ref.merged().export()
+    assert np.array_equal(keys, rk) and np.array_equal(cnts, rc)
+
+
 def _deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget):
     if budget:
         monkeypatch.setenv("SHK_DEFER_BUDGET", str(budget))
