@@ -626,7 +626,12 @@ int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint6
       const uint64_t local = c.first_rec + r->cur_seq;
       while (r->cur_flaw < c.flaws.size() && c.flaws[r->cur_flaw].rec < local) ++r->cur_flaw;
       if (cadence && r->cur_flaw < c.flaws.size() && c.flaws[r->cur_flaw].rec == local) return r->raise(c.flaws[r->cur_flaw]);
-      if (len > bases_cap) return r->fail(SHK_ERR_BAD_ARG, "sequence longer than the batch buffer");
+      // (a sequence that no batch of this size can hold: reported when it is the FIRST of a batch, with nothing
+      // consumed — the caller may come back with a larger buffer; shk_run_files does)
+      if (len > bases_cap && n == n_begin && used == 0) {
+        r->err = "sequence longer than the batch buffer";  // (not sticky: the same call with a larger buffer goes on)
+        return SHK_ERR_BAD_ARG;
+      }
       if (used + len > bases_cap) {  // does not fit: it is delivered first thing next call
         stop = true;
         break;
@@ -919,7 +924,9 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
   // super-batches through pinned buffers; the engine stripes by its own running read index,
   // which is exactly drain_batch's cadence (io.rs:340-343,355-361) whatever the batch size
   const uint64_t max_seqs = rc->batch_reads ? rc->batch_reads : 1000000;
-  const uint64_t cap_bases = rc->batch_bases ? rc->batch_bases : (256ull << 20);
+  // (pinning host memory costs ≈ 45 µs per MB each way: two 256 MB buffers were 40 ms of a 1.2 Gbase job; 64 MB
+  // batches keep every launch large enough, and a read that is longer gets larger buffers when it shows up)
+  uint64_t cap_bases = rc->batch_bases ? rc->batch_bases : (64ull << 20);
   // two batch buffers: while the engine takes batch i (copy + count), the front-end fills batch i+1
   uint8_t *bases2[2] = {(uint8_t *)shk_alloc_pinned(cap_bases), nullptr};
   uint64_t *offs2[2] = {(uint64_t *)shk_alloc_pinned((max_seqs + 1) * 8), nullptr};
@@ -955,6 +962,22 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     }
     uint64_t n = 0;
     v = shk_fastq_next_batch(rd, bases2[cur], cap_bases, offs2[cur], max_seqs, &n);
+    while (v == SHK_ERR_BAD_ARG && !rc->batch_bases && cap_bases < (16ull << 30) &&
+           strstr(shk_fastq_error(rd), "longer than the batch buffer")) {  // a very long read: larger buffers, same call again
+      if (join_ingest() != SHK_OK) break;  // (the other buffer was still being read by the engine; its outcome comes first, below)
+      cap_bases *= 4;
+      for (int i = 0; i < 2; ++i) {
+        if (!bases2[i]) continue;  // (not in use yet: allocated at the new size when it is)
+        shk_free_pinned(bases2[i]);
+        bases2[i] = (uint8_t *)shk_alloc_pinned(cap_bases);
+        if (!bases2[i]) {
+          cleanup();
+          g_run_error = "pinned buffer allocation failed";
+          return SHK_ERR_NOMEM;
+        }
+      }
+      v = shk_fastq_next_batch(rd, bases2[cur], cap_bases, offs2[cur], max_seqs, &n);
+    }
     // the batch before this one: its outcome comes first, as in the reference, which ingests what it has read
     // before it reads on (io.rs:340-343)
     const int prev = join_ingest();
