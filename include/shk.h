@@ -49,6 +49,9 @@ extern "C" {
 #define SHK_FLAG_TIMING 1u        /* bracket every kernel with HIP events */
 #define SHK_FLAG_FORCE_DIRECT 2u  /* count with the global-atomic kernel only */
 #define SHK_FLAG_FORCE_PAGED 4u   /* count with the LDS-page kernels only */
+#define SHK_FLAG_TIMING_SAMPLED 16u /* with SHK_FLAG_TIMING: only the launches of every 4th job are bracketed (a job =
+                                    * what lies between two shk_reset calls; the first after shk_reset_timings is) — the
+                                    * event records themselves cost ≈3 % of a 0.6 ms job */
 #define SHK_FLAG_DEFER_ERRORS 8u  /* host-buffer ingests (shk_ingest_reads/_batch/_packed) return once their last
                                    * slice is queued, like the device-buffer ones: an invalid byte is reported by
                                    * the NEXT call on the context (ingest, sync, finalize), and that call's first

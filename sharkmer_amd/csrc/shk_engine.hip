@@ -146,6 +146,8 @@ struct shk_ctx {
   // the histogram and totals on the device still hold what the last finalize read back: cleared by the next
   // reset, by the next ingest's k_mark_starts on its way, or by the next scan itself — not by a launch per finalize
   bool hist_dirty = false;
+  uint64_t job_idx = 0;      // shk_reset calls since shk_reset_timings (SHK_FLAG_TIMING_SAMPLED)
+  bool timing_now = true;
   std::vector<uint64_t> held_keys;   // spilled records taken off the device during a grouped flush (flush_acc)
   std::vector<uint32_t> held_lanes, held_counts;
   uint32_t own_share_n = 0, own_share_id = 0;  // … or as a share of the pages, resolved when a scan is launched
@@ -213,7 +215,7 @@ struct ScopedTimer {
   hipEvent_t a = nullptr, b = nullptr;
   bool shared = false;
   ScopedTimer(shk_ctx *c_, int kid_, bool chain = false) : c(c_), kid(kid_) {
-    if (!(c->cfg.flags & SHK_FLAG_TIMING)) return;
+    if (!(c->cfg.flags & SHK_FLAG_TIMING) || !c->timing_now) return;
     auto get = [&]() {
       hipEvent_t e;
       if (!c->event_pool.empty()) {
@@ -1645,6 +1647,8 @@ int shk_reset(shk_ctx *c) {
     c->tb_stale = !env_int("SHK_NO_FRESH", 0);
     c->hist_dirty = false;
   }
+  c->job_idx++;
+  c->timing_now = !(c->cfg.flags & SHK_FLAG_TIMING_SAMPLED) || ((c->job_idx - 1) % 4 == 0);
   memset(c->h_stats, 0, sizeof(DevStats));
   c->h_stats->bad = ~0ull;
   // no host sync: everything later is ordered behind these on the engine stream; h_stats is
@@ -2384,6 +2388,8 @@ int shk_reset_timings(shk_ctx *c) {
   (void)hipSetDevice(c->cfg.device);
   resolve_timings(c);
   memset(&c->timings, 0, sizeof c->timings);
+  c->job_idx = 0;
+  c->timing_now = true;
   return SHK_OK;
 }
 

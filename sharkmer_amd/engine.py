@@ -22,6 +22,7 @@ N_READS_PER_BATCH = 1000  # io.rs:15
 FLAG_TIMING = 1
 FLAG_FORCE_DIRECT = 2
 FLAG_FORCE_PAGED = 4
+FLAG_TIMING_SAMPLED = 16  # with FLAG_TIMING: only every 4th job's launches are bracketed (include/shk.h)
 FLAG_DEFER_ERRORS = 8  # host-buffer ingests return once queued; errors surface at the next call (include/shk.h)
 
 KERNEL_NAMES = ["mark", "scan", "direct", "scatter", "pages", "histo", "grow", "insert",
