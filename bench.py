@@ -371,8 +371,9 @@ def main():
         if dist is not None:
             return dc.finalize_histograms()
         eng.finalize()
-        return eng.histograms()
+        return eng.histograms(h_out)
 
+    h_out = np.empty((args.chunks, args.histo_max + 2), dtype=np.uint64)  # the caller's histogram array, filled every step
     ramp_steps = 0
     if dist is not None:
         # every step ends in collectives: all ranks must run the SAME number of ramp steps

@@ -368,9 +368,13 @@ class KmerEngine:
         self._check(self._L.shk_finalize_end(self._h, C.byref(again), C.byref(usum)))
         return bool(again.value), int(usum.value)
 
-    def histograms(self) -> np.ndarray:
-        """histo_vecs (io.rs:1020-1028): (chunks, histo_max+2) u64."""
-        out = np.zeros((self.chunks, self.histo_max + 2), dtype=np.uint64)
+    def histograms(self, out: np.ndarray | None = None) -> np.ndarray:
+        """histo_vecs (io.rs:1020-1028): (chunks, histo_max+2) u64.  out: a caller-owned array of that shape to
+        fill (a job of a few hundred µs notices the allocation of a fresh one)."""
+        if out is None:
+            out = np.empty((self.chunks, self.histo_max + 2), dtype=np.uint64)
+        else:
+            assert out.shape == (self.chunks, self.histo_max + 2) and out.dtype == np.uint64 and out.flags.c_contiguous
         self._check(self._L.shk_histograms(self._h, out.ctypes.data))
         return out
 
