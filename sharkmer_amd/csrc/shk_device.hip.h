@@ -2386,7 +2386,10 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
   __shared__ uint32_t wsum[RS_NT / 64];
   if (stats->bad != ~0ull) return;
   const uint32_t S = 1u << log_sub;  // pages per super-page
-  const uint32_t region = blockIdx.x / tiles_per_region, tile = blockIdx.x % tiles_per_region;
+  // (the tiles of one source region go to ONE XCD: see k_part_rescatter32)
+  uint32_t bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t region = bid / tiles_per_region, tile = bid % tiles_per_region;
   const uint32_t filled = src_cursor[region] < src_cap ? src_cursor[region] : src_cap;
   const uint32_t r0 = tile * RS_TILE;
   if (r0 >= filled) return;
@@ -2516,7 +2519,13 @@ __global__ void __launch_bounds__(RS32_NT) k_part_rescatter32(
   // Source regions: one per super-page, or — the owner layout of k_scatter32 — [lane][super-page] with
   // 2^log_src_lane super-pages per lane (log_src_lane = 31: a single lane, lane_).  `region` below is the
   // super-page inside this table's share; region_hi carries the owner bits above it for a key rebuild.
-  const uint32_t src_region = blockIdx.x / tiles_per_region, tile = blockIdx.x % tiles_per_region;
+  // Workgroups are dealt to the 8 XCDs round robin; every XCD has its own L2.  All tiles of a source region
+  // append to the same 2^log_sub destination regions — runs that lie next to each other in HBM, and cursors
+  // that are bumped once per tile — so the tiles of one region are given to ONE XCD (logical block = the XCD's
+  // share of the grid, taken in order): its L2 merges the neighbouring partial-line writes and keeps the cursors.
+  uint32_t bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t src_region = bid / tiles_per_region, tile = bid % tiles_per_region;
   const uint32_t lane = lane_ + (src_region >> log_src_lane);
   const uint32_t region = src_region & ((1u << log_src_lane) - 1u);
   const uint64_t dst_region_base = dst_region_base_ + (uint64_t)(src_region >> log_src_lane) * dst_lane_stride;
