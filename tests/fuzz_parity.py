@@ -34,7 +34,11 @@ for case in range(n_cases):
     if rng.random() < 0.3:
         env["SHK_TWO_LEVEL_MIN_PAGES"] = "4"
         env["SHK_LEVEL1_LOG"] = str(int(rng.integers(0, 4)))
-    for key in ("SHK_REC32", "SHK_SCATTER32_LDS", "SHK_TWO_LEVEL_MIN_PAGES", "SHK_LEVEL1_LOG"):
+    if rng.random() < 0.2:
+        env["SHK_FLUSH_GROUP_PAGES"] = str(int(rng.integers(1, 9)))  # deferred flushes in groups of a few pages
+    if rng.random() < 0.2:
+        env["SHK_DEFER_BUDGET"] = str(int(rng.choice([20_000, 300_000])))
+    for key in ("SHK_REC32", "SHK_SCATTER32_LDS", "SHK_TWO_LEVEL_MIN_PAGES", "SHK_LEVEL1_LOG", "SHK_FLUSH_GROUP_PAGES", "SHK_DEFER_BUDGET"):
         os.environ.pop(key, None)
     os.environ.update(env)
     histo_max = int(rng.choice([1, 10, 255, 10_000]))
