@@ -930,3 +930,28 @@ def test_deferred_invalid_byte_poisons_before_anything_is_counted(orc):
             eng.finalize()
         with pytest.raises(sa.ShkError):
             eng.finalize()
+
+
+def test_sampled_kernel_timing():
+    """SHK_FLAG_TIMING_SAMPLED: only the launches of jobs 1, 5, 9, … after shk_reset_timings are bracketed with
+    events (bench.py divides by those); the counts do not care."""
+    spec = sa.SynthSpec(genome_len=50_000)
+    bases, offsets = sa.synth_reads(spec, 0, 4_000)
+    with sa.KmerEngine(21, 1, 100, flags=sa.FLAG_TIMING | sa.FLAG_TIMING_SAMPLED) as eng:
+        eng.reset_timings()
+        hists = []
+        for _ in range(9):
+            eng.reset()
+            eng.ingest_reads(bases, offsets)
+            eng.finalize()
+            hists.append(eng.histograms())
+        tim = eng.timings()
+    assert all(np.array_equal(h, hists[0]) for h in hists)
+    assert tim["histo"][1] == 3 and tim["mark"][1] == 3   # jobs 1, 5 and 9
+    with sa.KmerEngine(21, 1, 100, flags=sa.FLAG_TIMING) as eng:
+        eng.reset_timings()
+        for _ in range(3):
+            eng.reset()
+            eng.ingest_reads(bases, offsets)
+            eng.finalize()
+        assert eng.timings()["histo"][1] == 3
