@@ -2323,6 +2323,11 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
             // 2^LOGP regions of one lane: byte offset = at·4 + (at >> 10)·(regions - 1)·4096 + region·4096
             const uint32_t off = __umul24(at4 >> (RB_LOG + 2), (uint32_t)(((1u << LOGP) - 1u) << (RB_LOG + 2))) + at4 + (pcb << RB_LOG);
             __builtin_memcpy(base + off, &rec2, 8);
+          } else if (!OWN && !WIDE && ALL) {
+            // the same with the regions of all lanes block-interleaved together (their number is a wave-uniform
+            // run-time value; a lane's buffer stays below 4 GiB or the launch is a WIDE one)
+            const uint32_t off = (at4 >> (RB_LOG + 2)) * ((n_regions - 1u) << (RB_LOG + 2)) + at4 + ((rbase << (RB_LOG + 2)) + (pcb << RB_LOG));
+            __builtin_memcpy(base + off, &rec2, 8);
           } else {
             __builtin_memcpy(slot_ptr(pcb >> 2, at4 >> 2), &rec2, 8);
           }
@@ -2864,13 +2869,13 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
 // k_pages32: the page workgroup for 4-byte records (k_part_scatter_sorted<.., true>).  A record
 // is rec = mix_key(key) mod 2^R, R = 2k - log_pages ≤ 32: home bucket = its top 11 bits,
 // fingerprint fp = the R-11 bits below.  The page sits in LDS as 32-bit TAGS instead of keys:
-//     tag(slot) = fp(key) << 3 | d ,  d = (bucket(slot) - home bucket(key)) mod 2048, d ≤ 6
+//     tag(slot) = fp(key) << 4 | d ,  d = (bucket(slot) - home bucket(key)) mod 2048, d ≤ 14
 // which — mix_key being a bijection and the page known — identifies the key.  A record hits when
-// one of the four tags of its home bucket (ONE ds_read_b128) equals fp << 3; no hash is computed
+// one of the four tags of its home bucket (ONE ds_read_b128) equals fp << 4; no hash is computed
 // here at all.  Everything else (first occurrences, displaced keys) goes through a per-wave miss
 // queue IN LDS (the tags leave room for it) and the general probe, which compares (fp, d) slot
 // by slot, inserts with a CAS on the tag and then writes the rebuilt key (unmix_key) to the
-// page in HBM.  What a tag cannot express — a key ≥ 7 buckets from home (d = 7, only ever created
+// page in HBM.  What a tag cannot express — a key ≥ 15 buckets from home (d = 15, only ever created
 // by the direct path) met on a probe, or a probe that would have to insert that far out —
 // sends the record to the spill list, i.e. through the exact global-memory path.
 // Counts: 16-bit deltas as in k_pages.  Keys are written when inserted, so the page's keys are
@@ -2880,6 +2885,11 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr uint32_t TAG_EMPTY = 0xFFFFFFFFu;
+// A tag's low TAG_DB bits: how many buckets past its home bucket the key sits (0 … TAG_FAR - 1; TAG_FAR = all ones:
+// farther than a tag can say — only ever created by the direct path — or, with all other bits set too, EMPTY).
+// Four bits since round 2 (the fingerprint has at most 21): with three, ONE k-mer of a 3 M-k-mer input that came to
+// lie 7 buckets from home sent its ≈1000 records through the spill path in every job.
+constexpr uint32_t TAG_DB = 4, TAG_FAR = (1u << TAG_DB) - 1u;
 constexpr uint32_t MQ32 = 512;              // miss-queue entries per wave (LDS)
 constexpr uint32_t P32_RPS = 4;             // records per thread per step (one 16-B load)
 constexpr uint32_t P32_EARLY = 4;           // steps after which the miss queue is drained regardless of its fill
@@ -2939,7 +2949,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
       if (kv[q] != EMPTY) {
         const uint32_t rec = (uint32_t)mix_key(kv[q], bits) & (uint32_t)(0xFFFFFFFFull >> (32 - R));
         const uint32_t d = (((2 * i + q) >> 2) - (rec >> fpb)) & (PAGE_SLOTS / 4 - 1);
-        tg[q] = ((rec & fpmask) << 3) | (d < 7 ? d : 7u);
+        tg[q] = ((rec & fpmask) << TAG_DB) | (d < TAG_FAR ? d : TAG_FAR);
         my_occ++;
       }
     }
@@ -2978,14 +2988,14 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
   // answer is the slot's tag if somebody else was faster).  Slot by slot this was a chain of LDS round trips per
   // record: most of a many-lane page pass (10 lanes, 30 Mb genome: 10 k cycles per lane and page in the drains).
   auto insert = [&](uint32_t rec) {
-    const uint32_t home = rec >> fpb, fp3 = (rec & fpmask) << 3;
-    for (uint32_t d = 0; d < 7;) {
+    const uint32_t home = rec >> fpb, fp3 = (rec & fpmask) << TAG_DB;
+    for (uint32_t d = 0; d < TAG_FAR;) {
       const uint32_t sl0 = ((home + d) & (PAGE_SLOTS / 4 - 1)) << 2, want = fp3 | d;
       const uint4 t4 = *reinterpret_cast<const uint4 *>(&tags[sl0]);
       // the first slot of the bucket, in probe order, that ends the search: this key's tag, an EMPTY slot, or a far
       // entry (low bits 7 — EMPTY has them too); one decision per bucket, the same code for every lane
-      const uint32_t s0 = (t4.x == want) | ((t4.x & 7u) == 7u), s1 = (t4.y == want) | ((t4.y & 7u) == 7u),
-                     s2 = (t4.z == want) | ((t4.z & 7u) == 7u), s3 = (t4.w == want) | ((t4.w & 7u) == 7u);
+      const uint32_t s0 = (t4.x == want) | ((t4.x & TAG_FAR) == TAG_FAR), s1 = (t4.y == want) | ((t4.y & TAG_FAR) == TAG_FAR),
+                     s2 = (t4.z == want) | ((t4.z & TAG_FAR) == TAG_FAR), s3 = (t4.w == want) | ((t4.w & TAG_FAR) == TAG_FAR);
       if (!(s0 | s1 | s2 | s3)) {
         ++d;
         continue;
@@ -3062,7 +3072,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
       bool missed[4];
   #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint32_t want = (rr[q] & fpmask) << 3;
+        const uint32_t want = (rr[q] & fpmask) << TAG_DB;
         const uint32_t e0 = bk[q].x == want, e1 = bk[q].y == want, e2 = bk[q].z == want, e3 = bk[q].w == want;
         const uint32_t idx = e1 + 2u * e2 + 3u * e3;
         uint32_t found = e0 | e1 | e2 | e3;
@@ -3153,8 +3163,8 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
       for (int q = 0; q < 2; ++q) {
         ko[q] = EMPTY;
         if (t2[q] != TAG_EMPTY) {
-          const uint32_t home = (((2 * i + q) >> 2) - (t2[q] & 7u)) & (PAGE_SLOTS / 4 - 1);
-          const uint32_t rec = (home << fpb) | (t2[q] >> 3);
+          const uint32_t home = (((2 * i + q) >> 2) - (t2[q] & TAG_FAR)) & (PAGE_SLOTS / 4 - 1);
+          const uint32_t rec = (home << fpb) | (t2[q] >> TAG_DB);
           ko[q] = unmix_key((gpage << R) | rec, bits);
         }
       }
