@@ -215,7 +215,9 @@ int shk_sync(shk_ctx *ctx);
  * (io.rs:1042-1047, 1120-1132).  SHK_ERR_NO_READS mirrors io.rs:578-580.
  * Idempotent; ingest after finalize re-opens the context. */
 int shk_finalize(shk_ctx *ctx);
-/* shk_finalize in two halves, for a caller that sums histograms over several contexts ON THE DEVICE (one process
+/* shk_finalize in two halves — histo_vecs (io.rs:1020-1028) of the UNION of several contexts' reads, bins being
+ * additive over disjoint key sets (KmerCounts::extend, counting.rs:157-166) — for a caller that sums histograms
+ * over several contexts ON THE DEVICE (one process
  * per GPU: an in-place all-reduce of *d_sum over the ranks, queued on shk_stream(), instead of a host round trip
  * through shk_histograms).  _begin queues the scan and hands out the block a reduction may SUM — n_words u64:
  * the totals, the per-lane base counts, four bookkeeping words (reads ingested, bases read, "my scan ran over a
@@ -311,13 +313,15 @@ int shk_merge_entries(shk_ctx *ctx, const void *d_keys, const void *d_vals, uint
  * in one all-to-all.  A received piece goes to shk_merge_entries(piece, piece + 8·c, c, c).  Asynchronous on
  * the context's stream (shk_stream). */
 int shk_compact_owners_packed(shk_ctx *ctx, uint32_t n_owners, const uint64_t *counts, void *d_buf, int32_t skip_owner);
-/* The same with pieces of a FIXED capacity (entries) at fixed places, so that nobody has to know anybody's counts
+/* The same (the sender's half of KmerCounts::extend across devices, counting.rs:157-166) with pieces of a FIXED
+ * capacity (entries) at fixed places, so that nobody has to know anybody's counts
  * before the all-to-all (no host read-back in front of it).  Piece o lies at byte offset o·(8 + capacity·(8 +
  * 4·n_lanes)): an 8-byte header, then [k-mers][lane 0]…[lane L-1] with unused places holding EMPTY k-mers (all
  * ones).  Entries beyond the capacity are NOT written; the header of every piece holds how many entries the
  * fullest owner range of this sender had.  Asynchronous on the context's stream. */
 int shk_compact_owners_fixed(shk_ctx *ctx, uint32_t n_owners, uint64_t capacity, void *d_buf, int32_t skip_owner);
-/* KmerCounts::extend of the n_pieces received fixed-capacity pieces lying back to back (what the equal-split
+/* KmerCounts::extend (counting.rs:157-166, saturating per lane as counting.rs:144-149) of the n_pieces received
+ * fixed-capacity pieces lying back to back (what the equal-split
  * all-to-all of shk_compact_owners_fixed buffers delivers, this rank's own piece included at skip_piece) in ONE
  * launch.  All or nothing: if ANY header says a range had more entries than the capacity, nothing is merged —
  * every rank receives a piece from every sender, so every rank decides alike — and the caller repeats the exchange
@@ -326,7 +330,8 @@ int shk_compact_owners_fixed(shk_ctx *ctx, uint32_t n_owners, uint64_t capacity,
  * > capacity ⇒ nothing was merged. */
 int shk_merge_pieces(shk_ctx *ctx, const void *d_buf, uint32_t n_pieces, uint64_t capacity, int32_t skip_piece);
 int shk_merge_pieces_max(shk_ctx *ctx, uint64_t *max_count);
-/* The owned range of shk_set_owned_pages as share `owner` of `n_owners` (a power of two) equal parts of the pages,
+/* The owned range of shk_set_owned_pages — the part of the merged table (io.rs:1023-1028) whose histogram this
+ * context contributes — as share `owner` of `n_owners` (a power of two) equal parts of the pages,
  * worked out when the histogram scan is launched — so it needs no look at the table geometry (which would have to
  * wait for the counting launches) and follows the table when a merge grows it. */
 int shk_set_owner_share(shk_ctx *ctx, uint32_t n_owners, uint32_t owner);
