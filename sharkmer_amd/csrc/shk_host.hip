@@ -470,14 +470,15 @@ struct shk_fastq {
       // The parsing pool is the pipeline's critical path (the producer never waits for the consumer: a 128 MB window
       // is split in ≈5 ms, its sequences are copied out in less), so it gets every CPU this process may really use
       // — a container's CFS quota counts, not the host's core count — and the copying pool a quarter of that
-      // (measured on a 16-CPU quota, Gbases/s of an 8 M-read plain file, three runs each: 8/8 threads 8.6,
-      // 12/4 9.0, 16/4 9.4, 14/2 7.1).
+      // (measured on a 16-CPU quota, Gbases/s of an 8 M-read plain file, three runs each, parse/copy threads: 8/8
+      // 8.6, 12/4 9.0, 16/4 9.4 and 8.8, 14/2 7.1, 24/4 9.6, 24/8 10.0, 32/4 8.7 — a quota is an AVERAGE over 100 ms:
+      // bursts wider than it are not throttled, and the pools idle half of the time).
       const uint32_t usable = usable_cpus();
       const char *ev = getenv("SHK_FASTQ_THREADS");
       const char *evc = getenv("SHK_FASTQ_COPY_THREADS");
-      T = ev && atoi(ev) > 0 ? (uint32_t)atoi(ev) : std::max(2u, std::min(16u, usable));
+      T = ev && atoi(ev) > 0 ? (uint32_t)atoi(ev) : std::max(2u, std::min(24u, usable + usable / 2));
       pool.reset(new Pool(T));
-      cpool.reset(new Pool(evc && atoi(evc) > 0 ? (uint32_t)atoi(evc) : std::max(2u, std::min(8u, usable / 4))));
+      cpool.reset(new Pool(evc && atoi(evc) > 0 ? (uint32_t)atoi(evc) : std::max(2u, std::min(8u, usable / 2))));
     }
     // plain files go through the shared pool one after the other (each is parsed at memory speed); streams
     // get a thread each and run ahead

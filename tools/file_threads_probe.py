@@ -44,7 +44,7 @@ for i in range(8):
     parts.append(pth)
 del rec, bases
 for rep in range(3):
-    for thr in ("", "8/8", "12/4", "14/2", "16/4", "12/8"):
+    for thr in ("16/4", "24/4", "32/4", "24/8"):
         env = dict(os.environ)
         if thr:
             env["SHK_FASTQ_THREADS"], env["SHK_FASTQ_COPY_THREADS"] = thr.split("/")
