@@ -412,7 +412,7 @@ class Run:
 
     def _check(self, rc):
         if rc != ORC_OK:
-            raise OracleError(rc, (lib().orc_run_error(self._p) or b"").decode("latin-1"))
+            raise OracleError(rc, (lib().orc_run_error(self._p) or b"").decode("utf-8", "replace"))
 
     def push_seq(self, seq):
         s = _b(seq)

@@ -9,6 +9,7 @@
 #define _GNU_SOURCE
 #include "shk_oracle.h"
 
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -659,8 +660,13 @@ static int chunk_ingest_seq(orc_run *r, orc_chunk *c, const uint8_t *seq, size_t
   int rc = orc_counts_ingest_seq(c->kmer_counts, seq, len, &r->bad_char);
   if (rc != ORC_OK) {
     if (rc == ORC_ERR_INVALID_CHAR)
+    { /* `b as char`: the byte is the scalar U+00b — two UTF-8 bytes from 0x80 on */
+      char ch[3] = {0, 0, 0};
+      if (r->bad_char < 0x80) ch[0] = (char)r->bad_char;
+      else { ch[0] = (char)(0xC0 | (r->bad_char >> 6)); ch[1] = (char)(0x80 | (r->bad_char & 0x3F)); }
       snprintf(r->err, sizeof r->err,
-               "Invalid character '%c' in sequence. Only ACGTN allowed.", r->bad_char);
+               "Invalid character '%s' in sequence. Only ACGTN allowed.", ch);
+    }
     return rc;
   }
   c->n_reads += 1;
@@ -806,44 +812,279 @@ const char *orc_run_error(const orc_run *r) { return r->err; }
 uint8_t orc_run_bad_char(const orc_run *r) { return r->bad_char; }
 
 /* ===================================================================== */
-/* FASTQ reading: io.rs:161-198, 271-352, 598-625                        */
+/* FASTQ reading: io.rs:161-198, 213-265, 271-352, 598-625               */
 /* ===================================================================== */
 
-/* BufRead::lines(): split on '\n', strip one trailing '\r' (std semantics).
- * gzread on a non-gzip file passes bytes through unchanged, which matches the
- * "gzip by extension or 1f 8b magic, else plain" rule of io.rs:611-616. */
+/* An io::Error as BufRead::lines hands it to read_fastq: its ErrorKind (printed with {:?} by
+ * stream_io_error, io.rs:213-265) and its Display text. */
+enum { IOK_NONE = 0, IOK_UNEXPECTED_EOF, IOK_INVALID_INPUT, IOK_INVALID_DATA, IOK_OTHER };
 typedef struct {
-  gzFile f;
+  int kind;
+  char text[96];
+} io_err;
+static const char *iok_name(int k) {
+  switch (k) {
+    case IOK_UNEXPECTED_EOF: return "UnexpectedEof";
+    case IOK_INVALID_INPUT: return "InvalidInput";
+    case IOK_INVALID_DATA: return "InvalidData";
+    default: return "Other";
+  }
+}
+static void io_set(io_err *e, int kind, const char *text) {
+  e->kind = kind;
+  snprintf(e->text, sizeof e->text, "%s", text);
+}
+
+/* The Box<dyn BufRead> of open_fastq_reader (io.rs:598-625): the file itself, or
+ * flate2::read::GzDecoder over it.  flate2 1.1.9 / miniz_oxide 0.8.9 (Cargo.lock:569-576,
+ * 940-947) are not under /root/reference; what is restated here is their published behaviour
+ * (flate2 src/gz/bufread.rs GzDecoder::{new,read} with multi = false, src/gz/mod.rs
+ * GzHeaderParser::parse, src/zio.rs read):
+ *   - the header is parsed when the decoder is made; an error is KEPT and returned by the first
+ *     read: 1f 8b / CM 8 / reserved flag bits → InvalidInput "invalid gzip header", a NUL-ended
+ *     field past 65535 bytes → InvalidInput "gzip header field too long", FHCRC mismatch →
+ *     InvalidInput "corrupt gzip stream does not have a matching checksum", input ending inside
+ *     it → UnexpectedEof;
+ *   - the body is raw DEFLATE; a decoder error → InvalidInput "corrupt deflate stream"; input
+ *     that ends inside the stream makes the decoder report no progress, zio::read returns Ok(0),
+ *     and the decoder goes on to the trailer;
+ *   - the trailer's 8 bytes: any missing → UnexpectedEof; CRC-32 or ISIZE not what was written →
+ *     the "matching checksum" error;
+ *   - then end of stream for ever: ONE member, whatever follows it.
+ * The inflate engine is zlib's raw inflate (windowBits −15): member framing, checks and errors are
+ * all done here, none of them by zlib's gz* layer. */
+typedef struct {
+  FILE *f;
+  int use_gzip;
+  int gz_state; /* 0 error pending (gz_err), 1 body, 2 trailer, 3 end */
+  io_err gz_err;
+  z_stream zs;
+  int zs_init;
+  unsigned char inbuf[1 << 15];
+  uint32_t crc;
+  uint64_t amount;
+} byte_source;
+
+/* the compressed input, with what inflate has not consumed yet served first */
+static int src_getc(byte_source *s) {
+  if (s->zs.avail_in == 0) {
+    size_t n = fread(s->inbuf, 1, sizeof s->inbuf, s->f);
+    if (n == 0) return -1;
+    s->zs.next_in = s->inbuf;
+    s->zs.avail_in = (uInt)n;
+  }
+  s->zs.avail_in--;
+  return *s->zs.next_in++;
+}
+
+static void gz_parse_header(byte_source *s) {
+  unsigned char h[10];
+  uint32_t hcrc = 0;
+  s->gz_state = 0;
+  for (int i = 0; i < 10; i++) {
+    int c = src_getc(s);
+    if (c < 0) { io_set(&s->gz_err, IOK_UNEXPECTED_EOF, "unexpected end of file"); return; }
+    h[i] = (unsigned char)c;
+  }
+  hcrc = (uint32_t)crc32(0L, h, 10);
+  if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xE0)) {
+    io_set(&s->gz_err, IOK_INVALID_INPUT, "invalid gzip header");
+    return;
+  }
+  int flg = h[3];
+  if (flg & 4) { /* FEXTRA */
+    unsigned char x[2];
+    for (int i = 0; i < 2; i++) {
+      int c = src_getc(s);
+      if (c < 0) { io_set(&s->gz_err, IOK_UNEXPECTED_EOF, "unexpected end of file"); return; }
+      x[i] = (unsigned char)c;
+    }
+    hcrc = (uint32_t)crc32(hcrc, x, 2);
+    unsigned xlen = x[0] | (x[1] << 8);
+    for (unsigned i = 0; i < xlen; i++) {
+      int c = src_getc(s);
+      if (c < 0) { io_set(&s->gz_err, IOK_UNEXPECTED_EOF, "unexpected end of file"); return; }
+      unsigned char b = (unsigned char)c;
+      hcrc = (uint32_t)crc32(hcrc, &b, 1);
+    }
+  }
+  for (int field = 0; field < 2; field++) { /* FNAME, FCOMMENT: read_to_nul */
+    if (!(flg & (field == 0 ? 8 : 16))) continue;
+    size_t held = 0;
+    for (;;) {
+      int c = src_getc(s);
+      if (c < 0) { io_set(&s->gz_err, IOK_UNEXPECTED_EOF, "unexpected end of file"); return; }
+      unsigned char b = (unsigned char)c;
+      hcrc = (uint32_t)crc32(hcrc, &b, 1);
+      if (b == 0) break;
+      if (held == 65535) { io_set(&s->gz_err, IOK_INVALID_INPUT, "gzip header field too long"); return; }
+      held++;
+    }
+  }
+  if (flg & 2) { /* FHCRC */
+    unsigned char x[2];
+    for (int i = 0; i < 2; i++) {
+      int c = src_getc(s);
+      if (c < 0) { io_set(&s->gz_err, IOK_UNEXPECTED_EOF, "unexpected end of file"); return; }
+      x[i] = (unsigned char)c;
+    }
+    if ((unsigned)(x[0] | (x[1] << 8)) != (hcrc & 0xFFFF)) {
+      io_set(&s->gz_err, IOK_INVALID_INPUT, "corrupt gzip stream does not have a matching checksum");
+      return;
+    }
+  }
+  s->gz_state = 1;
+}
+
+/* Read::read: >0 bytes, 0 end of stream, -1 error (*err) */
+static long source_read(byte_source *s, unsigned char *dst, size_t cap, io_err *err) {
+  if (!s->use_gzip) {
+    if (s->zs.avail_in) { /* what the peek had read */
+      size_t n = s->zs.avail_in < cap ? s->zs.avail_in : cap;
+      memcpy(dst, s->zs.next_in, n);
+      s->zs.next_in += n;
+      s->zs.avail_in -= (uInt)n;
+      return (long)n;
+    }
+    size_t n = fread(dst, 1, cap, s->f);
+    if (n == 0 && ferror(s->f)) { io_set(err, IOK_OTHER, strerror(errno)); return -1; }
+    return (long)n;
+  }
+  for (;;) {
+    if (s->gz_state == 0) { /* GzState::Err: handed out once, then End */
+      *err = s->gz_err;
+      s->gz_state = 3;
+      return -1;
+    }
+    if (s->gz_state == 3) return 0;
+    if (s->gz_state == 1) {
+      if (s->zs.avail_in == 0) {
+        size_t n = fread(s->inbuf, 1, sizeof s->inbuf, s->f);
+        s->zs.next_in = s->inbuf;
+        s->zs.avail_in = (uInt)n;
+        if (n == 0) { /* the input ends inside the stream: Ok(0) from zio::read, on to the trailer */
+          s->gz_state = 2;
+          continue;
+        }
+      }
+      s->zs.next_out = dst;
+      s->zs.avail_out = (uInt)cap;
+      int rc = inflate(&s->zs, Z_NO_FLUSH);
+      size_t got = cap - s->zs.avail_out;
+      if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
+        /* (what this call had written is NOT handed out by flate2 either: the read fails) — but
+         * everything a decoder can say before the damage is kept here, as in the product; see
+         * DESIGN.md on which record a corrupt stream is blamed on */
+        if (got) {
+          s->crc = (uint32_t)crc32(s->crc, dst, (uInt)got);
+          s->amount += got;
+          s->gz_state = 0;
+          io_set(&s->gz_err, IOK_INVALID_INPUT, "corrupt deflate stream");
+          return (long)got;
+        }
+        io_set(err, IOK_INVALID_INPUT, "corrupt deflate stream");
+        s->gz_state = 3;
+        return -1;
+      }
+      s->crc = (uint32_t)crc32(s->crc, dst, (uInt)got);
+      s->amount += got;
+      if (rc == Z_STREAM_END) s->gz_state = 2;
+      if (got) return (long)got;
+      continue;
+    }
+    /* trailer: CRC-32, ISIZE, little endian, from what inflate left unread and then the file */
+    unsigned char t[8];
+    for (int i = 0; i < 8; i++) {
+      int c = src_getc(s);
+      if (c < 0) {
+        io_set(err, IOK_UNEXPECTED_EOF, "unexpected end of file");
+        s->gz_state = 3;
+        return -1;
+      }
+      t[i] = (unsigned char)c;
+    }
+    uint32_t want_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    uint32_t want_len = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    s->gz_state = 3;
+    if (want_crc != s->crc || want_len != (uint32_t)s->amount) {
+      io_set(err, IOK_INVALID_INPUT, "corrupt gzip stream does not have a matching checksum");
+      return -1;
+    }
+    return 0;
+  }
+}
+
+/* str::from_utf8 on one line: decode scalar values, refuse overlong forms, surrogates and
+ * anything above U+10FFFF */
+static int line_is_utf8(const unsigned char *s, size_t n) {
+  size_t i = 0;
+  while (i < n) {
+    unsigned c = s[i];
+    unsigned len, cp, min;
+    if (c < 0x80) { i++; continue; }
+    if ((c & 0xE0) == 0xC0) { len = 2; cp = c & 0x1F; min = 0x80; }
+    else if ((c & 0xF0) == 0xE0) { len = 3; cp = c & 0x0F; min = 0x800; }
+    else if ((c & 0xF8) == 0xF0) { len = 4; cp = c & 0x07; min = 0x10000; }
+    else return 0;
+    if (i + len > n) return 0;
+    for (unsigned j = 1; j < len; j++) {
+      if ((s[i + j] & 0xC0) != 0x80) return 0;
+      cp = (cp << 6) | (s[i + j] & 0x3F);
+    }
+    if (cp < min || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return 0;
+    i += len;
+  }
+  return 1;
+}
+
+/* BufReader + BufRead::lines(): read_until '\n' (a failed read returns the error and what had been
+ * gathered of the line is gone), the line must be UTF-8 (else InvalidData "stream did not contain
+ * valid UTF-8"), then one trailing '\n' and — only then — one trailing '\r' are stripped. */
+typedef struct {
+  byte_source src;
+  unsigned char rbuf[8192];
+  size_t rpos, rlen;
   char *buf;
   size_t cap;
 } line_reader;
 
-/* returns 1 line read, 0 EOF, -1 I/O error */
-static int next_line(line_reader *lr, char **line, size_t *len) {
+/* returns 1 line read, 0 EOF, -1 error (*err) */
+static int next_line(line_reader *lr, char **line, size_t *len, io_err *err) {
   size_t n = 0;
+  int saw_nl = 0;
   for (;;) {
-    if (lr->cap - n < 2) {
+    if (lr->rpos == lr->rlen) {
+      long got = source_read(&lr->src, lr->rbuf, sizeof lr->rbuf, err);
+      if (got < 0) return -1;
+      if (got == 0) break;
+      lr->rpos = 0;
+      lr->rlen = (size_t)got;
+    }
+    unsigned char *p = lr->rbuf + lr->rpos;
+    size_t avail = lr->rlen - lr->rpos;
+    unsigned char *nl = (unsigned char *)memchr(p, '\n', avail);
+    size_t take = nl ? (size_t)(nl - p) + 1 : avail;
+    if (lr->cap < n + take + 1) {
       size_t nc = lr->cap ? lr->cap * 2 : 1 << 16;
-      char *p = (char *)realloc(lr->buf, nc);
-      if (!p) return -1;
-      lr->buf = p;
+      while (nc < n + take + 1) nc *= 2;
+      char *q = (char *)realloc(lr->buf, nc);
+      if (!q) { io_set(err, IOK_OTHER, "out of memory"); return -1; }
+      lr->buf = q;
       lr->cap = nc;
     }
-    if (!gzgets(lr->f, lr->buf + n, (int)(lr->cap - n))) {
-      int errnum = 0;
-      gzerror(lr->f, &errnum);
-      if (errnum != Z_OK && errnum != Z_STREAM_END) return -1;
-      if (n == 0) return 0;
-      break; /* last line without newline */
-    }
-    size_t got = strlen(lr->buf + n);
-    n += got;
-    if (n > 0 && lr->buf[n - 1] == '\n') {
-      n--;
-      if (n > 0 && lr->buf[n - 1] == '\r') n--;
-      break;
-    }
-    if (gzeof(lr->f)) break;
+    memcpy(lr->buf + n, p, take);
+    n += take;
+    lr->rpos += take;
+    if (nl) { saw_nl = 1; break; }
+  }
+  if (n == 0) return 0;
+  if (!line_is_utf8((const unsigned char *)lr->buf, n)) {
+    io_set(err, IOK_INVALID_DATA, "stream did not contain valid UTF-8");
+    return -1;
+  }
+  if (saw_nl) {
+    n--;
+    if (n > 0 && lr->buf[n - 1] == '\r') n--;
   }
   lr->buf[n] = 0;
   *line = lr->buf;
@@ -861,61 +1102,122 @@ static int fastq_fail(orc_run *r, const char *fmt, ...) {
   return ORC_ERR_FASTQ;
 }
 
+/* stream_io_error, io.rs:213-265, for a local source (the names this reader sees are never URLs) */
+static int stream_io_error(orc_run *r, const char *line_role, const io_err *e, const char *source_name) {
+  unsigned long long recno = (unsigned long long)r->st.n_reads_read + 1;
+  if (e->kind == IOK_UNEXPECTED_EOF)
+    snprintf(r->err, sizeof r->err,
+             "Local read stream ended unexpectedly while reading %s line of record %llu in %s "
+             "(I/O error: %s \xE2\x80\x94 kind %s). The file may be truncated or corrupted.",
+             line_role, recno, source_name, e->text, iok_name(e->kind));
+  else
+    snprintf(r->err, sizeof r->err, "Failed to read %s line of record %llu in %s: %s (kind %s)",
+             line_role, recno, source_name, e->text, iok_name(e->kind));
+  return ORC_ERR_IO;
+}
+
+/* header.chars().next().unwrap_or(' ') */
+static void first_char(const char *s, size_t len, char out[5]) {
+  if (len == 0) { out[0] = ' '; out[1] = 0; return; }
+  unsigned char c = (unsigned char)s[0];
+  size_t n = c < 0x80 ? 1 : c < 0xE0 ? 2 : c < 0xF0 ? 3 : 4;
+  if (n > len) n = len;
+  memcpy(out, s, n);
+  out[n] = 0;
+}
+
+static char *keep_line(char **copy, size_t *cap, const char *line, size_t len) {
+  if (*cap < len + 1) {
+    *cap = len + 64;
+    *copy = (char *)realloc(*copy, *cap);
+  }
+  memcpy(*copy, line, len + 1);
+  return *copy;
+}
+
 int orc_run_read_fastq(orc_run *r, const char *path, uint64_t max_reads,
                        uint64_t validate_every, int *reached_max) {
   if (reached_max) *reached_max = 0;
-  line_reader lr = {0};
-  lr.f = gzopen(path, "rb");
-  if (!lr.f) {
+  line_reader *lr = (line_reader *)calloc(1, sizeof *lr);
+  if (!lr) return ORC_ERR_NOMEM;
+  /* open_fastq_reader, io.rs:598-625 */
+  size_t plen = strlen(path);
+  int has_gz_ext = (plen >= 3 && !strcmp(path + plen - 3, ".gz")) || (plen >= 5 && !strcmp(path + plen - 5, ".gzip"));
+  lr->src.f = fopen(path, "rb");
+  if (!lr->src.f) {
     snprintf(r->err, sizeof r->err, "Failed to open file: %s", path);
+    free(lr);
     return ORC_ERR_IO;
   }
-  gzbuffer(lr.f, 1 << 20);
+  int use_gzip = has_gz_ext;
+  if (!use_gzip) { /* fill_buf() peek: the first two bytes are looked at, not consumed (they are
+                    * served again below — the source may be a pipe, which cannot be rewound) */
+    int c0 = fgetc(lr->src.f), c1 = c0 == EOF ? EOF : fgetc(lr->src.f);
+    use_gzip = c0 == 0x1f && c1 == 0x8b;
+    size_t n = 0;
+    if (c0 != EOF) lr->src.inbuf[n++] = (unsigned char)c0;
+    if (c1 != EOF) lr->src.inbuf[n++] = (unsigned char)c1;
+    lr->src.zs.next_in = lr->src.inbuf;
+    lr->src.zs.avail_in = (uInt)n;
+  }
+  lr->src.use_gzip = use_gzip;
+  if (use_gzip) {
+    unsigned char *keep_in = lr->src.zs.next_in;
+    uInt keep_n = lr->src.zs.avail_in;
+    lr->src.zs.zalloc = Z_NULL;
+    lr->src.zs.zfree = Z_NULL;
+    lr->src.zs.opaque = Z_NULL;
+    int zrc = inflateInit2(&lr->src.zs, -15);
+    lr->src.zs.next_in = keep_in;
+    lr->src.zs.avail_in = keep_n;
+    if (zrc != Z_OK) {
+      fclose(lr->src.f);
+      free(lr);
+      return ORC_ERR_NOMEM;
+    }
+    lr->src.zs_init = 1;
+    gz_parse_header(&lr->src);
+  }
   int rc = ORC_OK;
-  char *hdr_copy = NULL;
-  size_t hdr_cap = 0;
-  char *seq_copy = NULL;
-  size_t seq_cap = 0;
-  char *sep_copy = NULL;
-  size_t sep_cap = 0;
-  for (;;) {
+  char *hdr_copy = NULL, *seq_copy = NULL, *sep_copy = NULL;
+  size_t hdr_cap = 0, seq_cap = 0, sep_cap = 0;
+  io_err e;
+  for (;;) { /* read_fastq, io.rs:282-349 */
     char *line;
     size_t len;
-    int got = next_line(&lr, &line, &len);
+    int got = next_line(lr, &line, &len, &e);
     if (got == 0) break;
-    if (got < 0) { rc = ORC_ERR_IO; snprintf(r->err, sizeof r->err, "Failed to read header line of record %llu in %s", (unsigned long long)r->st.n_reads_read + 1, path); break; }
-    if (hdr_cap < len + 1) { hdr_cap = len + 64; hdr_copy = (char *)realloc(hdr_copy, hdr_cap); }
-    memcpy(hdr_copy, line, len + 1);
+    if (got < 0) { rc = stream_io_error(r, "header", &e, path); break; }
+    keep_line(&hdr_copy, &hdr_cap, line, len);
     size_t hdr_len = len;
 
-    got = next_line(&lr, &line, &len);
+    got = next_line(lr, &line, &len, &e);
     if (got == 0) { /* io.rs:291-295 */
       rc = fastq_fail(r, "Truncated FASTQ record at record %llu in %s: missing sequence line",
                       (unsigned long long)r->st.n_reads_read + 1, path);
       break;
     }
-    if (got < 0) { rc = ORC_ERR_IO; break; }
-    if (seq_cap < len + 1) { seq_cap = len + 64; seq_copy = (char *)realloc(seq_copy, seq_cap); }
-    memcpy(seq_copy, line, len + 1);
+    if (got < 0) { rc = stream_io_error(r, "sequence", &e, path); break; }
+    keep_line(&seq_copy, &seq_cap, line, len);
     size_t seq_len = len;
 
-    got = next_line(&lr, &line, &len);
+    got = next_line(lr, &line, &len, &e);
     if (got == 0) { /* io.rs:302-306 */
       rc = fastq_fail(r, "Truncated FASTQ record at record %llu in %s: missing separator line",
                       (unsigned long long)r->st.n_reads_read + 1, path);
       break;
     }
-    if (got < 0) { rc = ORC_ERR_IO; break; }
-    if (sep_cap < len + 1) { sep_cap = len + 64; sep_copy = (char *)realloc(sep_copy, sep_cap); }
-    memcpy(sep_copy, line, len + 1);
+    if (got < 0) { rc = stream_io_error(r, "separator", &e, path); break; }
+    keep_line(&sep_copy, &sep_cap, line, len);
+    size_t sep_len = len;
 
-    got = next_line(&lr, &line, &len);
+    got = next_line(lr, &line, &len, &e);
     if (got == 0) { /* io.rs:313-317 */
       rc = fastq_fail(r, "Truncated FASTQ record at record %llu in %s: missing quality line",
                       (unsigned long long)r->st.n_reads_read + 1, path);
       break;
     }
-    if (got < 0) { rc = ORC_ERR_IO; break; }
+    if (got < 0) { rc = stream_io_error(r, "quality", &e, path); break; }
     size_t qual_len = len;
 
     /* io.rs:321-332 */
@@ -923,6 +1225,7 @@ int orc_run_read_fastq(orc_run *r, const char *path, uint64_t max_reads,
                           (validate_every > 0 && r->st.n_reads_read % validate_every == 0);
     if (should_validate) { /* io.rs:161-198 */
       unsigned long long recno = (unsigned long long)r->st.n_reads_read + 1;
+      char fc[5];
       if (hdr_len > 0 && hdr_copy[0] == '>') {
         rc = fastq_fail(r,
                         "Input appears to be FASTA format, not FASTQ (record %llu starts with '>'). "
@@ -931,13 +1234,15 @@ int orc_run_read_fastq(orc_run *r, const char *path, uint64_t max_reads,
         break;
       }
       if (!(hdr_len > 0 && hdr_copy[0] == '@')) {
-        rc = fastq_fail(r, "FASTQ record %llu has invalid header (expected '@', got '%c'): %s",
-                        recno, hdr_len ? hdr_copy[0] : ' ', hdr_copy);
+        first_char(hdr_copy, hdr_len, fc);
+        rc = fastq_fail(r, "FASTQ record %llu has invalid header (expected '@', got '%s'): %s",
+                        recno, fc, hdr_copy);
         break;
       }
-      if (!(sep_copy[0] == '+')) {
-        rc = fastq_fail(r, "FASTQ record %llu has invalid separator line (expected '+', got '%c'): %s",
-                        recno, sep_copy[0] ? sep_copy[0] : ' ', sep_copy);
+      if (!(sep_len > 0 && sep_copy[0] == '+')) {
+        first_char(sep_copy, sep_len, fc);
+        rc = fastq_fail(r, "FASTQ record %llu has invalid separator line (expected '+', got '%s'): %s",
+                        recno, fc, sep_copy);
         break;
       }
       if (qual_len != seq_len) {
@@ -953,8 +1258,10 @@ int orc_run_read_fastq(orc_run *r, const char *path, uint64_t max_reads,
       break;
     }
   }
-  gzclose(lr.f);
-  free(lr.buf);
+  if (lr->src.zs_init) inflateEnd(&lr->src.zs);
+  fclose(lr->src.f);
+  free(lr->buf);
+  free(lr);
   free(hdr_copy);
   free(seq_copy);
   free(sep_copy);

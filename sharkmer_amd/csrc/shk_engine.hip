@@ -8,6 +8,7 @@
 // There is no CPU fallback anywhere in this file.
 #include "../../include/shk.h"
 #include "shk_device.hip.h"
+#include "shk_front.h"
 
 #include <algorithm>
 #include <chrono>
@@ -1014,7 +1015,7 @@ static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub,
   if (c->h_stats->bad != ~0ull) {
     c->poisoned = true;
     c->poison_code = SHK_ERR_INVALID_CHAR;
-    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%c' in sequence. Only ACGTN allowed.", (char)(c->h_stats->bad & 0xFF));
+    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%s' in sequence. Only ACGTN allowed.", shk::byte_as_char((uint8_t)(c->h_stats->bad & 0xFF)).c_str());
   }
   if (c->h_stats->scratch[0] > c->xspill_cap) return fail(c, SHK_ERR_INVARIANT, "foreign spill list overflow");
   xo->d_records = c->xbuf.p;
@@ -1272,8 +1273,8 @@ static int settle_checked(shk_ctx *c) {
     // identical text to encoding.rs:353-356
     c->poisoned = true;
     c->poison_code = SHK_ERR_INVALID_CHAR;
-    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%c' in sequence. Only ACGTN allowed.",
-                (char)(c->h_stats->bad & 0xFF));
+    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%s' in sequence. Only ACGTN allowed.",
+                shk::byte_as_char((uint8_t)(c->h_stats->bad & 0xFF)).c_str());
   }
   int rc = drain_spill(c, c->unsettled_spill_cap);
   if (rc != SHK_OK) return rc;
@@ -1897,11 +1898,11 @@ int shk_pack_reads_device(shk_ctx *c, const void *d_bases, uint64_t n_bases, voi
   int rc = read_stats(c);
   if (rc != SHK_OK) return rc;
   if (c->h_stats->bad != ~0ull) {  // encoding.rs:353-356; the context's table was not touched: no poisoning
-    const char bad = (char)(c->h_stats->bad & 0xFF);
+    const std::string bad = shk::byte_as_char((uint8_t)(c->h_stats->bad & 0xFF));
     HIPC(c, hipMemsetAsync(&c->d_stats->bad, 0xFF, 8, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     c->h_stats->bad = ~0ull;
-    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%c' in sequence. Only ACGTN allowed.", bad);
+    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%s' in sequence. Only ACGTN allowed.", bad.c_str());
   }
   return SHK_OK;
 }

@@ -1,0 +1,71 @@
+// shk_inflate.h — DEFLATE (RFC 1951) decoder + gzip member framing (RFC 1952) of the FASTQ front-end.
+//
+// Why hand-written: the reference opens a .gz with flate2::read::GzDecoder (src/io.rs:618-621;
+// flate2 1.1.9 over miniz_oxide 0.8.9, Cargo.lock:569-576, 940-947 — neither vendored under /root/reference).
+// That decoder (a) reads ONE gzip member and then reports end of stream whatever follows, (b) defers a header
+// error to the first read, (c) verifies CRC32 and ISIZE of the trailer, (d) turns a stream that ends early into
+// an io::Error the FASTQ loop reports through stream_io_error (src/io.rs:213-265).  zlib's gzread — what this
+// file replaces — does none of that the same way (it concatenates members, passes non-gzip bytes through and
+// treats a truncated stream as a clean end).  The oracle restates the same semantics separately over zlib's
+// raw inflate (under oracle/), so the two share no decoding code.
+//
+// Plain C++17, no HIP: built into libshk.so and into the sanitizer builds of the host code.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace shk {
+
+// io::ErrorKind of the error a flate2 reader would hand to BufRead::lines (what stream_io_error prints with {:?})
+enum IoKind : int { IO_NONE = 0, IO_UNEXPECTED_EOF = 1, IO_INVALID_INPUT = 2, IO_INVALID_DATA = 3, IO_OTHER = 4 };
+struct IoError {
+  IoKind kind = IO_NONE;
+  const char *text = "";  // Display of the io::Error
+};
+const char *io_kind_name(IoKind k);  // "UnexpectedEof", "InvalidInput", "InvalidData"
+
+enum InflateStatus {
+  INF_OUTPUT_FULL = 0,  // fewer than Inflater::OUT_SLACK bytes of room are left; call again with a fresh buffer
+  INF_STREAM_END = 1,   // the final block's end-of-block symbol has been decoded
+  INF_TRUNCATED = 2,    // the input ends inside the stream: everything decodable has been written
+  INF_CORRUPT = 3       // not a valid DEFLATE stream from here on: everything before has been written
+};
+
+// Resumable over OUTPUT buffers, one contiguous INPUT (a mapped or slurped file).  History: the caller keeps the last
+// 32 KiB of output (or all of it, if less) directly in front of out_pos when it switches buffers.
+struct Inflater {
+  static constexpr size_t OUT_SLACK = 320;  // a symbol is only decoded with this much room (258 + wide-copy overshoot)
+  const uint8_t *in = nullptr, *in_end = nullptr;
+  uint64_t bitbuf = 0;
+  uint32_t bitcnt = 0;
+  int state = 0;  // 0 block header, 1 stored, 2 Huffman, 3 done
+  bool last_block = false;
+  uint32_t stored_left = 0;
+  uint64_t total_out = 0;
+  uint32_t litlen[2048 + 1024];  // 11-bit primary + subtables
+  uint32_t dist[256 + 512];      // 8-bit primary + subtables
+  void reset(const uint8_t *p, const uint8_t *e);
+  // Decodes into out_base[out_pos, out_cap); bytes [out_pos - min(out_pos, 32768), out_pos) are the history.
+  InflateStatus run(uint8_t *out_base, size_t *out_pos, size_t out_cap);
+  // After INF_STREAM_END: the first input byte behind the stream (whole unread bytes are given back).
+  const uint8_t *input_after_stream() const { return in - (bitcnt >> 3); }
+};
+
+// CRC-32 (IEEE, reflected) — slicing-by-8, and the combination of two CRCs so that a buffer can be summed in pieces.
+uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n);
+uint32_t crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+
+// One gzip member, the way flate2's GzDecoder (multi = false) reads it.
+struct GzMember {
+  Inflater inf;
+  IoError header_error;  // GzState::Err: reported by the first read
+  bool body_done = false;
+  const uint8_t *file_end = nullptr;
+  // Parses the header over [p, e).  Never fails here: a bad or short header is kept for the first read.
+  void open(const uint8_t *p, const uint8_t *e);
+  // What reading on after the last data byte reports: the trailer check (needs the CRC-32 and length of everything
+  // written) after INF_STREAM_END, or the error a short or corrupt body turns into.  IO_NONE = clean end of stream.
+  IoError finish(InflateStatus last, uint32_t crc, uint64_t total_out) const;
+};
+
+}  // namespace shk

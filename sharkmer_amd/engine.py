@@ -141,6 +141,56 @@ def _share_hip_runtime_with_torch():
             pass
 
 
+FRONT_SYMBOLS = [
+    "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_stats",
+    "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args", "shk_run_error",
+    "shk_packed_sizes", "shk_pack_reads",
+]
+
+
+def _type_front(L):
+    """The entry points of the plain-C++ host side (csrc/shk_front.cpp): FASTQ front-end, packer, writers."""
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.shk_packed_sizes.argtypes = [u64, C.POINTER(u64), C.POINTER(u64)]
+    L.shk_packed_sizes.restype = None
+    L.shk_pack_reads.argtypes = [vp, u64, vp, vp, u32]
+    L.shk_fastq_open.argtypes = [C.POINTER(C.c_char_p), u32, u64, u64, C.POINTER(vp)]
+    L.shk_fastq_close.argtypes = [vp]
+    L.shk_fastq_close.restype = None
+    L.shk_fastq_error.argtypes = [vp]
+    L.shk_fastq_error.restype = C.c_char_p
+    L.shk_fastq_next_batch.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.shk_fastq_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.shk_write_histo.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, vp]
+    L.shk_write_final_histo.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, vp]
+    L.shk_write_stats_yaml.argtypes = [C.c_char_p, C.POINTER(_RunStats)]
+    L.shk_validate_args.argtypes = [u32, u64, C.c_char_p]
+    L.shk_run_error.argtypes = []
+    L.shk_run_error.restype = C.c_char_p
+
+
+_front = None
+
+
+def load_front_library():
+    """The library the host-side entry points are called in: libshk.so — or, with SHK_FRONT_LIB set, a build of
+    csrc/shk_front.cpp + shk_inflate.cpp alone (the sanitizer builds of `make -C sharkmer_amd/csrc san`, which
+    tests/test_host_san.py runs the CPU tests against)."""
+    global _front
+    if _front is not None:
+        return _front
+    alt = os.environ.get("SHK_FRONT_LIB")
+    if not alt:
+        _front = load_library()
+        return _front
+    L = C.CDLL(alt)
+    _type_front(L)
+    for name in FRONT_SYMBOLS:
+        getattr(L, name)
+    _front = L
+    return L
+
+
 def load_library():
     """dlopen libshk.so and type its entry points.  Raises if the HIP build is missing."""
     global _lib
@@ -199,9 +249,6 @@ def load_library():
     L.shk_insert_device.argtypes = [vp, vp, vp, vp, u64]
     L.shk_stream.argtypes = [vp]
     L.shk_stream.restype = vp
-    L.shk_packed_sizes.argtypes = [u64, C.POINTER(u64), C.POINTER(u64)]
-    L.shk_packed_sizes.restype = None
-    L.shk_pack_reads.argtypes = [vp, u64, vp, vp, u32]
     L.shk_ingest_packed.argtypes = [vp, vp, vp, vp, u64]
     L.shk_ingest_packed_device.argtypes = [vp, vp, vp, vp, u64, u64]
     L.shk_pack_reads_device.argtypes = [vp, vp, u64, vp, vp]
@@ -216,19 +263,7 @@ def load_library():
     L.shk_free_device.argtypes = [vp, vp]
     L.shk_free_device.restype = None
     L.shk_synth_reads_device.argtypes = [vp, C.POINTER(_Synth), u64, u64, vp, vp]
-    L.shk_fastq_open.argtypes = [C.POINTER(C.c_char_p), u32, u64, u64, C.POINTER(vp)]
-    L.shk_fastq_close.argtypes = [vp]
-    L.shk_fastq_close.restype = None
-    L.shk_fastq_error.argtypes = [vp]
-    L.shk_fastq_error.restype = C.c_char_p
-    L.shk_fastq_next_batch.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
-    L.shk_fastq_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.shk_write_histo.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, vp]
-    L.shk_write_final_histo.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, vp]
-    L.shk_write_stats_yaml.argtypes = [C.c_char_p, C.POINTER(_RunStats)]
-    L.shk_validate_args.argtypes = [u32, u64, C.c_char_p]
-    L.shk_run_error.argtypes = []
-    L.shk_run_error.restype = C.c_char_p
+    _type_front(L)
     L.shk_run_files.argtypes = [C.POINTER(_RunConfig), C.POINTER(_RunStats)]
     for name in ABI_SYMBOLS:
         getattr(L, name)  # AttributeError here = the .so is stale
@@ -676,8 +711,24 @@ class PackedReads:
     """A batch as shk_pack_reads leaves it: packed u8[(n+3)//4] (4 bases per byte, first base on top),
     nmask u32[(n+31)//32] (bit p%32 of word p//32 ⇔ base p is N), offsets u64[n_seqs+1] in bases."""
 
-    def __init__(self, packed, nmask, offsets, n_bases):
+    def __init__(self, packed, nmask, offsets, n_bases, _pinned=None):
         self.packed, self.nmask, self.offsets, self.n_bases = packed, nmask, offsets, n_bases
+        self._pinned = _pinned  # (library, [pointers]) when the arrays are views over shk_alloc_pinned memory
+
+    def close(self):
+        """Give pinned arrays back (shk_free_pinned); the numpy views must not be used afterwards."""
+        if self._pinned:
+            L, ptrs = self._pinned
+            self._pinned = None
+            self.packed = self.nmask = self.offsets = None
+            for q in ptrs:
+                L.shk_free_pinned(q)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def nbytes(self):
@@ -694,8 +745,9 @@ class PackedReads:
 
 def pack_reads(bases: np.ndarray, offsets: np.ndarray, threads: int = 0, pinned: bool = False) -> PackedReads:
     """shk_pack_reads over a batch of concatenated ASCII reads (host, multi-threaded).  pinned: the
-    output arrays live in pinned host memory (shk_alloc_pinned; freed with the process)."""
-    L = load_library()
+    output arrays live in pinned host memory (shk_alloc_pinned), owned by the PackedReads: close() — or dropping the
+    object — gives them back."""
+    L = load_library() if pinned else load_front_library()
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = int(offsets[-1]) if len(offsets) else 0
@@ -714,7 +766,7 @@ def pack_reads(bases: np.ndarray, offsets: np.ndarray, threads: int = 0, pinned:
     rc = L.shk_pack_reads(bases.ctypes.data, n, packed.ctypes.data, nmask.ctypes.data, threads)
     if rc != 0:
         raise ShkError(rc, (L.shk_run_error() or b"").decode("utf-8", "replace"))
-    return PackedReads(packed, nmask, offs, n)
+    return PackedReads(packed, nmask, offs, n, _pinned=(L, [pp, pm, po]) if pinned else None)
 
 
 # ---- host side either side of the path: FASTQ front-end, writers, whole-run driver -----------------
@@ -724,7 +776,7 @@ class FastqReader:
     Parses only (no GPU needed)."""
 
     def __init__(self, paths, max_reads: int = 0, validate_every: int = 0):
-        self._L = load_library()
+        self._L = load_front_library()
         arr = (C.c_char_p * max(len(paths), 1))(*[os.fsencode(p) for p in paths])
         h = C.c_void_p()
         rc = self._L.shk_fastq_open(arr, len(paths), max_reads, validate_every, C.byref(h))
@@ -759,7 +811,7 @@ class FastqReader:
 
 def write_histo(path: str, histo: np.ndarray, k: int, histo_max: int, version: str = "3.1.0"):
     h = np.ascontiguousarray(histo, dtype=np.uint64)
-    rc = load_library().shk_write_histo(os.fsencode(path), version.encode(), k, h.shape[0], histo_max,
+    rc = load_front_library().shk_write_histo(os.fsencode(path), version.encode(), k, h.shape[0], histo_max,
                                         h.ctypes.data)
     if rc != 0:
         raise ShkError(rc, "shk_write_histo failed")
@@ -767,7 +819,7 @@ def write_histo(path: str, histo: np.ndarray, k: int, histo_max: int, version: s
 
 def write_final_histo(path: str, histo: np.ndarray, k: int, histo_max: int, version: str = "3.1.0"):
     h = np.ascontiguousarray(histo, dtype=np.uint64)
-    rc = load_library().shk_write_final_histo(os.fsencode(path), version.encode(), k, h.shape[0],
+    rc = load_front_library().shk_write_final_histo(os.fsencode(path), version.encode(), k, h.shape[0],
                                               histo_max, h.ctypes.data)
     if rc != 0:
         raise ShkError(rc, "shk_write_final_histo failed")
@@ -782,14 +834,14 @@ def write_stats_yaml(path: str, **f):
                    n_multi_kmers=f.get("n_multi_kmers", 0), n_singleton_kmers=f.get("n_singleton_kmers", 0),
                    peak_memory_bytes=f.get("peak_memory_bytes", 0),
                    has_histogram=1 if f.get("has_histogram", f["chunks"] > 0) else 0)
-    rc = load_library().shk_write_stats_yaml(os.fsencode(path), C.byref(st))
+    rc = load_front_library().shk_write_stats_yaml(os.fsencode(path), C.byref(st))
     if rc != 0:
         raise ShkError(rc, "shk_write_stats_yaml failed")
 
 
 def validate_args(k: int, histo_max: int, sample):
     """cli.rs:659-673 + 645-652; raises ShkError with the reference's message."""
-    L = load_library()
+    L = load_front_library()
     rc = L.shk_validate_args(k, histo_max, None if sample is None else sample.encode())
     if rc != 0:
         raise ShkError(rc, (L.shk_run_error() or b"").decode("utf-8", "replace"))
