@@ -1529,7 +1529,11 @@ __global__ void __launch_bounds__(WG) k_merge(TableRef tb, uint64_t n_slots, uin
 // shk_finalize_begin: the words a reduction over the ranks sums besides the totals and the histogram.
 __global__ void k_fin_extras(unsigned long long *__restrict__ extra, unsigned long long n_reads,
                              unsigned long long n_bases_read, unsigned long long user_word,
-                             const DevStats *__restrict__ stats, uint32_t was_unsettled) {
+                             const DevStats *__restrict__ stats, uint32_t was_unsettled,
+                             const unsigned long long *__restrict__ lane_bases, unsigned long long *__restrict__ lane_sum,
+                             uint32_t n_lanes) {
+  // the live per-lane base counters go into the summed block afresh on every finalize (they are never reduced in place)
+  for (uint32_t l = threadIdx.x; l < n_lanes; l += blockDim.x) lane_sum[l] = lane_bases[l];
   if (threadIdx.x == 0) {
     extra[0] = n_reads;
     extra[1] = n_bases_read;

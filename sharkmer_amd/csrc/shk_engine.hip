@@ -108,9 +108,13 @@ struct shk_ctx {
   // device state
   // Control block: every small piece of device state in ONE allocation, mirrored in pinned host
   // memory with the same layout, so that a reset is one fill launch and the end of a run one copy:
-  //   [DevStats][HistoTotals][lane_bases × n_lanes][pad to 16 B][hist × chunks·(histo_max+2)]
+  //   [DevStats][lane_bases × n_lanes][pad to 16 B] | [HistoTotals][lane sums × n_lanes][4 words][pad to 16 B][hist × chunks·(histo_max+2)]
+  // Everything from HistoTotals on is a SUM over contexts (what shk_finalize_begin hands out for an in-place
+  // reduction); the LIVE per-lane base counters the counting kernels add to lie in front of it, so that a repeated
+  // _begin / reduce / _end never sums a sum — k_fin_extras copies them into the summed part every time.
   uint8_t *d_ctl = nullptr, *h_ctl = nullptr;
-  size_t ctl_bytes = 0, ctl_hist_off = 0;
+  size_t ctl_bytes = 0, ctl_hist_off = 0, ctl_tot_off = 0;
+  unsigned long long *d_lane_sum = nullptr, *h_lane_sum = nullptr;
   DevStats *d_stats = nullptr;
   DevStats *h_stats = nullptr;
   unsigned long long *d_lane_bases = nullptr, *h_lane_bases = nullptr;
@@ -1545,7 +1549,8 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   HIPB(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
   const size_t hist_n = (size_t)std::max<uint32_t>(cfg->chunks, 1) * (cfg->histo_max + 2);
   {
-    size_t off = sizeof(DevStats) + sizeof(HistoTotals) + sizeof(unsigned long long) * (c->n_lanes + 4);  // (+ d_extra)
+    c->ctl_tot_off = (sizeof(DevStats) + sizeof(unsigned long long) * c->n_lanes + 15) & ~(size_t)15;  // (behind the live lane counters)
+    size_t off = c->ctl_tot_off + sizeof(HistoTotals) + sizeof(unsigned long long) * (c->n_lanes + 4);  // (+ lane sums, d_extra)
     c->ctl_hist_off = (off + 15) & ~(size_t)15;
     c->ctl_bytes = (c->ctl_hist_off + hist_n * sizeof(unsigned long long) + 15) & ~(size_t)15;
   }
@@ -1554,12 +1559,14 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   memset(c->h_ctl, 0, c->ctl_bytes);
   c->d_stats = (DevStats *)c->d_ctl;
   c->h_stats = (DevStats *)c->h_ctl;
-  c->d_tot = (HistoTotals *)(c->d_ctl + sizeof(DevStats));
-  c->h_totp = (HistoTotals *)(c->h_ctl + sizeof(DevStats));
-  c->d_lane_bases = (unsigned long long *)(c->d_ctl + sizeof(DevStats) + sizeof(HistoTotals));
-  c->h_lane_bases = (unsigned long long *)(c->h_ctl + sizeof(DevStats) + sizeof(HistoTotals));
-  c->d_extra = c->d_lane_bases + c->n_lanes;
-  c->h_extra = c->h_lane_bases + c->n_lanes;
+  c->d_lane_bases = (unsigned long long *)(c->d_ctl + sizeof(DevStats));
+  c->h_lane_bases = (unsigned long long *)(c->h_ctl + sizeof(DevStats));
+  c->d_tot = (HistoTotals *)(c->d_ctl + c->ctl_tot_off);
+  c->h_totp = (HistoTotals *)(c->h_ctl + c->ctl_tot_off);
+  c->d_lane_sum = (unsigned long long *)(c->d_ctl + c->ctl_tot_off + sizeof(HistoTotals));
+  c->h_lane_sum = (unsigned long long *)(c->h_ctl + c->ctl_tot_off + sizeof(HistoTotals));
+  c->d_extra = c->d_lane_sum + c->n_lanes;
+  c->h_extra = c->h_lane_sum + c->n_lanes;
   c->d_hist = (unsigned long long *)(c->d_ctl + c->ctl_hist_off);
   c->h_hist = (const uint64_t *)(c->h_ctl + c->ctl_hist_off);
   c->h_stats->bad = ~0ull;
@@ -2280,10 +2287,10 @@ int shk_finalize_begin(shk_ctx *c, uint64_t user_word, void **d_sum, uint64_t *n
   for (auto v : c->lane_reads) n_reads += v;
   hipLaunchKernelGGL(k_fin_extras, dim3(1), dim3(64), 0, c->stream, c->d_extra, (unsigned long long)n_reads,
                      (unsigned long long)c->n_bases_read, (unsigned long long)user_word, (const DevStats *)c->d_stats,
-                     c->fin_was_unsettled ? 1u : 0u);
+                     c->fin_was_unsettled ? 1u : 0u, (const unsigned long long *)c->d_lane_bases, c->d_lane_sum, c->n_lanes);
   HIPC(c, hipGetLastError());
   *d_sum = c->d_tot;
-  *n_words = (c->ctl_bytes - sizeof(DevStats)) / 8;
+  *n_words = (c->ctl_bytes - c->ctl_tot_off) / 8;
   return SHK_OK;
 }
 
@@ -2347,7 +2354,10 @@ int shk_get_counters(shk_ctx *c, shk_counters *o) {
                            hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
   }
-  for (uint32_t l = 0; l < c->n_lanes; ++l) o->n_bases_ingested += c->h_lane_bases[l];
+  {  // (after shk_finalize_end: the job-wide sums the reduction left; else this context's own counters)
+    const unsigned long long *lb = c->fin_summed && c->finalized ? c->h_lane_sum : c->h_lane_bases;
+    for (uint32_t l = 0; l < c->n_lanes; ++l) o->n_bases_ingested += lb[l];
+  }
   if (c->finalized || c->hist_ready) {
     o->n_kmers_ingested = c->h_tot.n_lane_sum;
     o->n_unique_kmers = c->h_tot.n_unique;
@@ -2909,7 +2919,12 @@ static int merge_launch(shk_ctx *c, const void *d_keys, const void *d_vals, uint
   // Fixed-capacity pieces behind a counting launch nobody has looked at yet: nothing is waited for.  If that
   // launch spilled, the senders' headers are poisoned and k_merge touches nothing; if not, what the merge spills
   // goes on the same list (same capacity, the counter runs on) and the finalize that follows repairs it.
-  const bool ride_on = piece_cap && c->unsettled && !c->acc_active && c->unsettled_spill_cap > 0 &&
+  // (Only when that list could take the merge's own worst case — every entry spilling on every lane, which is what
+  // W pieces' worth of new keys do to pages sized for the local shard alone: k_merge drops what does not fit the list,
+  // and the settle that follows would fail the job with "spill list overflow" where the exact-count protocol would
+  // have finished.  A counting launch's list has a place per k-mer of the launch, so this holds whenever the pieces
+  // are no larger than the batch.)
+  const bool ride_on = piece_cap && c->unsettled && !c->acc_active && c->unsettled_spill_cap >= n * c->n_lanes &&
                        c->spillA.cap >= c->unsettled_spill_cap * 16;
   if (!ride_on) {
     int rcs = settle(c);

@@ -59,16 +59,23 @@ struct shk_group {
   std::vector<uint64_t> hist;
   shk_counters tot{};
 
-  void barrier() {
+  // Returns whether any worker had failed WHEN THE LAST ONE ARRIVED — one answer for all of them, taken inside the
+  // barrier, so that either every worker leaves the round early or none does (a worker that looked at status[] on its
+  // own after waking could see a peer's failure from the NEXT phase, skip the next barrier and leave that peer waiting
+  // in it for ever).  A worker writes only its own status[] entry, before it takes the barrier's lock.
+  bool b_failed = false;
+  bool barrier() {
     std::unique_lock<std::mutex> lk(bm);
     const uint64_t g = b_gen;
     if (++b_count == D) {
       b_count = 0;
+      b_failed = any_failed();
       ++b_gen;
       bcv.notify_all();
     } else {
       bcv.wait(lk, [&] { return b_gen != g; });
     }
+    return b_failed;
   }
   bool any_failed() const {
     for (int s : status)
@@ -253,8 +260,7 @@ int group_round(shk_ctx *top, const uint8_t *bases, const uint64_t *offsets, con
                                              &g->cur_ptr[d], &g->lay[d], &g->n_foreign[d]);
       c->xchg_lane_fixed = -1;
     }
-    g->barrier();
-    if (g->any_failed()) return g->status[d];
+    if (g->barrier()) return g->status[d];
     bool foreign = false;
     for (uint32_t s = 0; s < D; ++s) foreign |= g->n_foreign[s] > 0;
     // ---- phase 2: pull my segment out of every peer's buffer and absorb it
@@ -284,8 +290,7 @@ int group_round(shk_ctx *top, const uint8_t *bases, const uint64_t *offsets, con
       g->status[d] = shk_xchg_spill(c, &g->sp_k[d], &g->sp_l[d], &g->sp_c[d], &n);
       g->sp_n[d] = n;
     }
-    g->barrier();
-    if (g->any_failed()) return g->status[d];
+    if (g->barrier()) return g->status[d];
     // ---- phase 3 (skewed input only): every device inserts what it owns of every spill list
     if (foreign) {
       for (uint32_t i = 0; i < D && g->status[d] == SHK_OK; ++i) {
@@ -303,7 +308,7 @@ int group_round(shk_ctx *top, const uint8_t *bases, const uint64_t *offsets, con
         hipc(hipMemcpyPeerAsync(p + n * 12, g->dev_ids[d], g->sp_c[s], g->dev_ids[s], n * 4, c->stream));
         if (g->status[d] == SHK_OK) g->status[d] = shk_insert_device(c, p, p + n * 8, p + n * 12, n);  // (synchronous)
       }
-      g->barrier();  // everybody has read my list
+      (void)g->barrier();  // everybody has read my list
       if (g->status[d] == SHK_OK) g->status[d] = shk_xchg_spill_clear(c);
     }
     return g->status[d];

@@ -177,6 +177,11 @@ def test_fixed_capacity_pieces_from_the_second_job_on(orc, monkeypatch, cap):
             assert np.array_equal(hist, ref.histograms())
             assert tot["n_unique_kmers"] == ref.stats["n_unique_kmers"]
             assert tot["n_kmers_ingested"] == ref.stats["n_kmers_ingested"]
+            # the per-lane base counters live OUTSIDE the block the ranks reduce in place: a repeated exchange
+            # (cap=1024: every job; cap=2^20: after the poisoned one) must not sum a sum
+            assert tot["n_bases_ingested"] == ref.stats["n_bases_ingested"]
+            assert tot["n_reads_ingested"] == ref.stats["n_reads_ingested"] == n_reads
+            assert tot["n_bases_read"] == ref.stats["n_bases_read"]
         n_fixed, n_rem, n_grows = res[3]
         if cap == 1 << 20:
             assert n_fixed >= 4 and n_rem >= 1 and n_grows >= 1  # (a poisoned exchange is repeated with fixed pieces)
