@@ -1,12 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — Gbases/s of k-mer counting (k=21, 150 bp reads), histograms bit-exact vs CPU.
 
-One "step" = the whole BASELINE.json config-2 job on one GPU: an empty table, one batch of
-synthetic reads already resident in HBM → validate/scan → count → histogram emit.
-With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank counts its own
-shard of reads (weak scaling: per-GPU work fixed); the per-rank tables are exchanged by owner
-page range over RCCL (all_to_all), merged, scanned, and the histograms all-reduced, so the
-emitted histogram is that of the union of all reads.
+--config 2 (default; BASELINE.json configs[1], the configuration the metric is quoted on): one "step" = the whole
+job on one GPU: an empty table, one batch of synthetic reads already resident in HBM → validate/scan → count →
+histogram emit.  The timed loop ROTATES over `--batches` (4) distinct resident batches — consecutive reads of the same
+genome — so no input byte is re-read within 600 MB of input traffic and nothing of it can sit in the 256 MiB Infinity
+Cache between steps.  With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank counts its own
+shard of reads (weak scaling: per-GPU work fixed); the per-rank tables are exchanged by owner page range over RCCL
+(all_to_all), merged, scanned, and the histograms all-reduced, so the emitted histogram is that of the union of all
+reads.
+
+--config 4 / --config 5 (BASELINE.json configs[3] / configs[4]: 1 B reads over a 3 Gb genome on 8×MI355X, one chunk
+lane resp. 10 cumulative subsets): KEY-SPACE-PARTITIONED ingest (sharkmer_amd.dist.OwnerCounter) — every rank holds
+1/N of the key space, scatters its reads' k-mer records by owner, the records cross the links in one all_to_all per
+round, every rank absorbs what it owns; histograms are summed at the end.  A rank's input is ITS SHARE OF THE CONFIG
+AS STATED: 10^9 / 8 = 125 M reads, resident in HBM (18.75 GB), whatever N is — at N = 8 the run IS the config; at
+smaller N it is the same per-rank load on a proportionally smaller job (weak scaling).  At N = 1: config 4 runs the
+exchange path over a one-rank RCCL communicator into the whole 2^33-slot table; config 5's whole key space (48 B ×
+2^33 slots) does not fit one card, so the one rank plays owner 0 of 8 and drops what the seven others would have
+received (the same kernels; no exchange) — `config.workload` says which.
 
 Before the W warm-up steps an untimed RAMP of steps (≈0.25 s of device work) lets the card reach its
 steady clocks — the first ≈20 ms after idling run ≈4 % slower; `ramp_steps` is reported.  The timed region
@@ -15,10 +27,13 @@ points of SURVEY.md §8d on record: pinned host buffers → histogram (ii), FAST
 BASELINE configs[2] (k = 31, 100 M reads) from HBM and streamed from pinned host memory, and the
 chunk-lane / large-table shapes.  --no-extras skips them.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events
-on the engine's own stream inside libshk (SHK_FLAG_TIMING); `cpu_baseline` times the CPU
-oracle (a single-threaded C restatement of the reference algorithm — "port") on the same
-reads and checks the GPU histogram against it.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events on the engine's own
+stream inside libshk (SHK_FLAG_TIMING): `achieved` = ALGORITHMIC bytes per launch ÷ its duration; every
+kernel also carries `physical_GBps` = the HBM bytes per launch the committed PMC passes of this round measured
+(profiles/rNN_traffic.json) ÷ the same duration.  `roofline_path` is the whole job against SURVEY.md §8d's B_alg, over
+summed kernel time (`frac`) and over the driver's own clock (`frac_driver_clock` = B_alg ÷ ms_per_step).
+`cpu_baseline` times the CPU oracle (a single-threaded C restatement of the reference algorithm — "port") on the
+reads of the last timed step and checks the GPU histogram against it.
 """
 from __future__ import annotations
 
@@ -287,6 +302,173 @@ def extras(sa, torch, dev):
     return out
 
 
+def owner_config(args, real_stdout):
+    """--config 4 / 5: one rank's share of BASELINE.json configs[3] / configs[4] per GPU, key-space-partitioned ingest
+    (reference semantics: io.rs:340-361 striping by global read index, io.rs:1023-1028 per-chunk histograms)."""
+    import torch
+    import sharkmer_amd as sa
+    from sharkmer_amd.dist import OwnerCounter
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    L, k, histo_max = 150, 21, args.histo_max
+    lanes = 1 if args.config == 4 else 10
+    genome = 3_000_000_000
+    JOB_GPUS = 8                                  # BASELINE.json: "8×MI355X"
+    rpr = args.reads or 10**9 // JOB_GPUS         # reads per rank: its share of the job as stated
+    steps, warmup = args.steps if args.steps != 100 else 3, args.warmup if args.warmup != 50 else 1
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+    # how the rank takes part: exchange rounds over RCCL among `world` owners — or, where the whole key space does not
+    # fit the ranks there are (config 5 on one card: 48 B × 2^33 slots), as owner 0 of 8, dropping the others' records
+    drop_mode = args.config == 5 and world < 4
+    if drop_mode and world > 1:
+        raise SystemExit("--config 5 needs 1 GPU (one owner's share, no exchange) or >= 4 GPUs (the key space must fit)")
+    import torch.distributed as dist
+    if not drop_mode:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29532")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    n_owners = JOB_GPUS if drop_mode else world
+    flags = sa.FLAG_TIMING
+    eng = sa.KmerEngine(k, lanes, histo_max, device=dev, capacity_hint=genome // n_owners, flags=flags,
+                        n_owners=n_owners, owner_id=0 if drop_mode else rank)
+    spec = sa.SynthSpec(genome_len=genome, read_len=L)
+    # the rank's reads, resident in HBM: rounds of ≤ 2^28 bases
+    round_reads = 1_700_000
+    n_rounds = -(-rpr // round_reads)
+    d_all = torch.empty(rpr * L, dtype=torch.uint8, device=f"cuda:{dev}")
+    d_off = torch.empty(round_reads + 1, dtype=torch.int64, device=f"cuda:{dev}")
+    first_read = rank * rpr
+    for r in range(n_rounds):
+        n = min(round_reads, rpr - r * round_reads)
+        eng.synth_reads_device(spec, first_read + r * round_reads, n, d_all.data_ptr() + r * round_reads * L, d_off.data_ptr())
+    # (d_off: offsets 0, L, 2L, … — a shorter last round writes the same values over a prefix of them)
+    eng.sync()
+    oc = None if drop_mode else OwnerCounter(eng, dist, device=dev, round_bases=round_reads * L)
+    lay_box = [None]
+
+    def step():
+        eng.reset()
+        if oc is not None:
+            oc.n_rounds = oc.n_foreign_rounds = oc.wire_bytes = 0
+        for r in range(n_rounds):
+            n = min(round_reads, rpr - r * round_reads)
+            ptr = d_all.data_ptr() + r * round_reads * L
+            if oc is None:
+                eng.set_read_index(first_read + r * round_reads)
+                eng.ingest_reads_device(ptr, d_off.data_ptr(), n, n * L)
+            else:
+                lay_box[0] = oc.round((ptr, d_off.data_ptr(), n, n * L, first_read + r * round_reads))
+        if oc is None:
+            eng.finalize()
+            return eng.histograms(), eng.counters()
+        h = oc.finalize_histograms()
+        return h, oc.totals
+
+    def barrier():
+        if not drop_mode and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    eng.reset_timings()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        hist, tot = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tim = eng.timings()
+    cnt = eng.counters()
+    if rank == 0:
+        n_bases = rpr * L
+        n_kmers_rank = rpr * (L - k + 1)
+        total_bases = n_bases * world * steps
+        value = total_bases / dt / 1e9
+        cap = cnt["table_capacity"]
+        own_frac = 1.0 / n_owners if drop_mode else 1.0   # the part of a rank's records that ends up in its own page passes
+        # algorithmic bytes of a step on ONE rank: its bases read, a 4-byte record per k-mer written by the level-1 pass,
+        # read and written by the level-2 pass and read by the page pass (what this rank absorbs: 1/N of N ranks' records —
+        # or 1/8 of its own in drop mode), every page in and out once, one table scan
+        rec = 4
+        stage_bytes = {"scatter": n_bases + n_kmers_rank * rec,
+                       "pscan": 2 * n_kmers_rank * rec * own_frac,
+                       "pages": n_kmers_rank * rec * own_frac + 2 * cap * (8 + 4 * lanes),
+                       "histo": cap * (8 + 4 * lanes)}
+        per_kernel = {}
+        for name, (ms, launches) in tim.items():
+            if launches and name in stage_bytes:
+                per_step_ms = ms / steps
+                per_kernel[name] = {"ms_per_step": round(per_step_ms, 3), "launches_per_step": launches / steps,
+                                    "alg_bytes_per_step": int(stage_bytes[name]),
+                                    "achieved_GBps": round(stage_bytes[name] / (per_step_ms * 1e-3) / 1e9, 1)}
+        dom = max(per_kernel, key=lambda n_: per_kernel[n_]["ms_per_step"]) if per_kernel else None
+        roof = None
+        if dom:
+            d = per_kernel[dom]
+            lps = d["launches_per_step"]
+            roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(d["achieved_GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
+                    "alg_bytes_per_launch": int(d["alg_bytes_per_step"] / lps), "avg_launch_ms": round(d["ms_per_step"] / lps, 4)}
+        b_alg = n_bases + n_kmers_rank * 16 * own_frac + cnt["n_unique_kmers"] / (1 if drop_mode else world) * 8 + cap * (8 + 4 * lanes)
+        path_roof = {"alg_bytes_per_step_per_rank": int(b_alg), "achieved_GBps": round(b_alg / (dt / steps) / 1e9, 1),
+                     "frac_driver_clock": round(b_alg / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5)}
+        kmers_expected = (L - k + 1) * rpr * world
+        exchange = None
+        if oc is not None and lay_box[0] is not None:
+            lay = lay_box[0]
+            exchange = {"rounds": oc.n_rounds, "n_foreign_rounds": oc.n_foreign_rounds,
+                        "segment_bytes": int((lay.segment_records + lay.regions) * 4),
+                        "link_bytes_per_round": int((lay.segment_records + lay.regions) * 4) if world > 1 else 0,
+                        "wire_bytes_per_rank_per_step": int(oc.wire_bytes), "region_cap": int(lay.region_cap), "regions": int(lay.regions)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            ns = args.cpu_sample_reads or 200_000
+            hb, ho = sa.synth_reads(spec, 0, ns)
+            t1 = time.perf_counter()
+            orc.run_batch(hb, ho, k, lanes, histo_max)
+            cdt = time.perf_counter() - t1
+            cpu = {"value": round(ns * L / cdt / 1e9, 5), "unit": "Gbases/s", "cores": 1, "kind": "port",
+                   "sample": f"the first {ns} reads of the job ({lanes} chunk lane(s)), single-threaded C restatement of sharkmer's counting path",
+                   "cpu_model": cpu_model()}
+        which = "configs[3]" if args.config == 4 else "configs[4]"
+        how = (f"owner 0 of {n_owners}: every read of the share offered, the other owners' records dropped in the level-1 pass (no exchange)"
+               if drop_mode else f"exchange rounds among {world} owner share(s) over RCCL (OwnerCounter)")
+        out = {
+            "metric": "Gbases/sec k-mer counted (k=21, 150bp reads); histogram bit-exact vs CPU",
+            "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json {which}: one rank's share per GPU — {rpr} synthetic {L}bp reads of a {genome} bp genome, k={k}, "
+                                   f"{lanes} chunk lane(s), {world}xMI355X; {how}; step = reset + all rounds + histogram emit, input resident in HBM",
+                       "reads_per_gpu": rpr, "k": k, "chunks": lanes, "genome": genome, "n_owners": n_owners,
+                       "mode": "drop" if drop_mode else "exchange", "round_reads": round_reads},
+            "roofline": roof, "cpu_baseline": cpu, "roofline_path": path_roof, "kernels": per_kernel,
+            "kernels_ms_per_step": {k_: round(v[0] / steps, 3) for k_, v in tim.items() if v[0] > 0},
+            "exchange": exchange,
+            "totals": {f: int(tot[f]) for f in ("n_reads_ingested", "n_kmers_ingested", "n_unique_kmers") if f in tot},
+            "kmers_as_expected": (int(tot["n_kmers_ingested"]) == kmers_expected) if not drop_mode else None,
+            "histogram_rows_sum_to_distinct": bool(int(hist[-1, 1:].sum()) == int(tot["n_unique_kmers"])),
+            "table": {"capacity": cap, "n_grows": cnt["n_grows"], "n_spilled": cnt["n_spilled"]},
+        }
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    eng.close()
+    if not drop_mode:
+        dist.destroy_process_group()
+
+
 def main():
     # ONE line on stdout, whatever libraries print on theirs (RCCL announces its version there when a communicator
     # is created): the process's stdout goes to stderr until the JSON line is written to the real one
@@ -299,7 +481,10 @@ def main():
     # ≈4 % slower (measured: scatter 0.48 ms with 3 warm-up steps, 0.46 ms with 50 or 300), then 100 timed steps
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--config", type=int, choices=[2, 4, 5], default=2,
+                    help="2: BASELINE configs[1] (the metric's configuration); 4 / 5: configs[3] / configs[4], a rank's share per GPU")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: 1 M for --config 2, 125 M for 4 / 5)")
+    ap.add_argument("--batches", type=int, default=4, help="--config 2: distinct resident batches the steps rotate over")
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--genome", type=int, default=3_000_000)
     ap.add_argument("--chunks", type=int, default=1)
@@ -311,6 +496,9 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=0,
                     help="reads for the CPU baseline (0 = the whole step batch of rank 0)")
     args = ap.parse_args()
+    if args.config != 2:
+        return owner_config(args, real_stdout)
+    args.reads = args.reads or 1_000_000
 
     import torch
     import sharkmer_amd as sa
@@ -355,19 +543,26 @@ def main():
     eng = sa.KmerEngine(args.k, args.chunks, args.histo_max, device=dev,
                         capacity_hint=genome, flags=flags)
 
-    d_bases = torch.empty(n_reads * L, dtype=torch.uint8, device=f"cuda:{dev}")
+    # NB distinct batches resident in HBM: batch b of rank r is reads [(r·NB + b)·n, (r·NB + b + 1)·n) of the generator
+    NB = max(1, args.batches)
+    d_bases = [torch.empty(n_reads * L, dtype=torch.uint8, device=f"cuda:{dev}") for _ in range(NB)]
     d_offsets = torch.empty(n_reads + 1, dtype=torch.int64, device=f"cuda:{dev}")
-    eng.synth_reads_device(spec, rank * n_reads, n_reads, d_bases.data_ptr(), d_offsets.data_ptr())
+    batch_first = [(rank * NB + b) * n_reads for b in range(NB)]
+    for b in range(NB):
+        eng.synth_reads_device(spec, batch_first[b], n_reads, d_bases[b].data_ptr(), d_offsets.data_ptr())
     n_bases = n_reads * L
+    step_no = [0]
 
     if dist is not None:
         from sharkmer_amd.dist import DistCounter
         dc = DistCounter(eng, dist, device=dev)
 
     def step():
+        b = step_no[0] % NB
+        step_no[0] += 1
         eng.reset()
-        eng.set_read_index(rank * n_reads)
-        eng.ingest_reads_device(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases)
+        eng.set_read_index(batch_first[b])
+        eng.ingest_reads_device(d_bases[b].data_ptr(), d_offsets.data_ptr(), n_reads, n_bases)
         if dist is not None:
             return dc.finalize_histograms()
         eng.finalize()
@@ -421,44 +616,52 @@ def main():
         # 8 B per k-mer record written and read, 12 B per table slot in and out); a step has several
         # launches of a kernel when the batch spans chunk lanes or exceeds 2^28 bases, and then each
         # launch moves its share of the batch (but every page of the table)
+        # the record a k-mer is between the partition and the page pass: 4 bytes when the mixed key's bits below the
+        # level-1 fan-out (1024) fit a word — 2k − 10 ≤ 32, k ≤ 21 — else 8.  The page pass of a job that counts one
+        # batch into an empty table is the FRESH one: it reads no page, it writes every page once
+        rec_bytes = 4 if 2 * args.k - 10 <= 32 else 8
         def alg_bytes(name, lps):
             return {
-                "scatter": (n_bases * 1 + n_kmers * 8) / lps,      # bases read + one record per k-mer written
-                "pages": n_kmers * 8 / lps + cap * 12 * 2,         # records read + every page in and out
+                "scatter": (n_bases * 1 + n_kmers * 8) / lps,      # bases read + one record per k-mer written (8 B; the kernel moves rec_bytes)
+                "pages": n_kmers * rec_bytes / lps + cap * (8 + 4 * lanes),   # records read at the width in use + every page written out once
                 "histo": cap * (8 + 4 * lanes),                    # one table scan per histogram emit
                 "direct": (n_bases * 1 + n_kmers * 16 + nd * 8) / lps,
                 "scan": n_bases * 1 / lps,
             }.get(name)
+        # HBM bytes per launch from the PMC passes of THIS round's build (tools/profile_round.sh →
+        # tools/collect_profile.py → profiles/<round>_traffic.json, FETCH_SIZE doubled per the gfx950 note of
+        # MI355X_MICROARCH.md): a committed measurement of the same command, named in the line; only the newest
+        # round's file counts (an older one would be a stale constant), and only for the workload it was taken on
+        import glob
+        traffic_kernels, traffic_src = {}, None
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True):
+            tj = json.load(open(tpath))
+            if tj.get("reads") == n_reads and tj.get("k") == args.k and tj.get("batches", 1) == NB:
+                traffic_kernels = tj.get("kernels", {})
+                traffic_src = os.path.relpath(tpath, ROOT)
+            break
         per_kernel = {}
         for name, (ms, launches) in tim.items():
             lps = launches / timed_steps
             if launches and alg_bytes(name, lps) is not None:
                 avg = ms / launches
                 ab = alg_bytes(name, lps)
+                phys = traffic_kernels.get(name, {}).get("hbm_bytes_per_launch")
                 per_kernel[name] = {"avg_launch_ms": round(avg, 4), "launches_per_step": lps,
                                     "alg_bytes_per_launch": int(ab),
-                                    "achieved_GBps": round(ab / (avg * 1e-3) / 1e9, 1)}
+                                    "achieved_GBps": round(ab / (avg * 1e-3) / 1e9, 1),           # algorithmic bytes ÷ time
+                                    "hbm_bytes_per_launch": phys,
+                                    "physical_GBps": round(phys / (avg * 1e-3) / 1e9, 1) if phys else None}  # PMC bytes ÷ time
         hot = [k_ for k_ in ("direct", "scatter", "pages") if k_ in per_kernel]
         dom = max(hot, key=lambda k_: per_kernel[k_]["avg_launch_ms"] * per_kernel[k_]["launches_per_step"]) if hot else None
         roof = None
         if dom:
             d = per_kernel[dom]
-            # HBM bytes per launch from the PMC passes of THIS round's build (tools/profile_round.sh →
-            # tools/collect_profile.py → profiles/<round>_traffic.json, FETCH_SIZE doubled per the gfx950 note of
-            # MI355X_MICROARCH.md): a committed measurement of the same command, named here; null when the
-            # newest file on record is for another workload
-            traffic, traffic_src = None, None
-            import glob
-            for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True):
-                tj = json.load(open(tpath))
-                if tj.get("reads") == n_reads and tj.get("k") == args.k and dom in tj.get("kernels", {}):
-                    traffic = tj["kernels"][dom].get("hbm_bytes_per_launch")
-                    traffic_src = os.path.relpath(tpath, ROOT)
-                break  # (only the newest round's file counts: an older one would be a stale constant)
+            traffic = d["hbm_bytes_per_launch"]
             roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(d["achieved_GBps"] / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": d["alg_bytes_per_launch"],
-                    "avg_launch_ms": d["avg_launch_ms"]}
+                    "traffic": traffic, "traffic_source": traffic_src if traffic else None, "alg_bytes_per_launch": d["alg_bytes_per_launch"],
+                    "avg_launch_ms": d["avg_launch_ms"], "physical_GBps": d["physical_GBps"]}
         # the whole counting path against SURVEY.md §8d's B_alg (1 B/base + 16 B/k-mer + 8 B/distinct
         # + one table scan per emit), over the summed device time of its kernels
         path_ms = sum(ms for name, (ms, _) in tim.items()
@@ -466,18 +669,21 @@ def main():
         b_alg = n_bases * 1 + n_kmers * 16 + nd * 8 + cap * (8 + 4 * lanes)
         path_roof = {"alg_bytes_per_step": int(b_alg), "device_ms_per_step": round(path_ms, 4),
                      "achieved_GBps": round(b_alg / (path_ms * 1e-3) / 1e9, 1) if path_ms else None,
-                     "frac": round(b_alg / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if path_ms else None}
+                     "frac": round(b_alg / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if path_ms else None,
+                     # the same bytes over the DRIVER-style clock (launch gaps and the host round trip included)
+                     "frac_driver_clock": round(b_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
         cpu = cpu_all = None
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             ns = args.cpu_sample_reads or n_reads
-            hb, ho = sa.synth_reads(spec, 0, ns)
+            last_first = batch_first[(step_no[0] - 1) % NB]   # the batch the last timed step counted (rank 0)
+            hb, ho = sa.synth_reads(spec, last_first, ns)
             t1 = time.perf_counter()
             ref = orc.run_batch(hb, ho, args.k, args.chunks, args.histo_max)
             cdt = time.perf_counter() - t1
             cpu = {"value": round(ns * L / cdt / 1e9, 5), "unit": "Gbases/s", "cores": 1,
                    "kind": "port",
-                   "sample": f"{ns} reads x {L} bp of the step batch (rank 0 shard), "
+                   "sample": f"{ns} reads x {L} bp: the batch of the last timed step (rank 0 shard, reads {last_first}..), "
                              f"single-threaded C restatement of sharkmer's counting path"}
             cpu["cpu_model"] = cpu_model()
             # context only: the same restatement on all host cores — reads sharded over
@@ -498,8 +704,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: {n_reads} synthetic {L}bp reads per GPU, "
                                    f"k={args.k}, {n_gpus}xMI355X, single hash-table shard per GPU; "
-                                   f"step = reset + count + histogram emit, input resident in HBM",
-                       "reads_per_gpu": n_reads, "k": args.k, "chunks": args.chunks,
+                                   f"step = reset + count + histogram emit, input resident in HBM, "
+                                   f"steps rotate over {NB} distinct batches",
+                       "reads_per_gpu": n_reads, "batches": NB, "k": args.k, "chunks": args.chunks,
                        "genome": genome, "path": args.path},
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "roofline_path": path_roof, "kernels": per_kernel,
@@ -511,7 +718,8 @@ def main():
         }
         if world == 1 and dist is None and not args.no_extras:
             eng.close()
-            del d_bases, d_offsets
+            d_bases.clear()
+            del d_offsets
             torch.cuda.empty_cache()
             out["extras"] = extras(sa, torch, dev)
         sys.stdout.flush()

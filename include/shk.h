@@ -75,7 +75,9 @@ typedef struct shk_config {
    * partition a batch's records by owner for an exchange between the W contexts instead.  Read/base
    * counters count every read handed over; k-mer counters and histograms cover the owned share
    * (histogram bins are additive across shares: KmerCounts::extend over disjoint key sets,
-   * counting.rs:157-166, io.rs:1023-1028).  0 or 1: the whole key space. */
+   * counting.rs:157-166, io.rs:1023-1028).  0: the whole key space.  1: the whole key space AS A SHARE — the
+   * context takes the shk_xchg_* rounds like any owner share (one segment), so that the exchange path of a
+   * W-process job runs unchanged in a world of one. */
   uint32_t n_owners;
   uint32_t owner_id;
   /* MULTI-DEVICE CONTEXT (SURVEY.md §8b `n_devices, device_ids`): n_devices > 1 makes ONE context that

@@ -36,6 +36,14 @@ static uint64_t acc_records_est(const shk_ctx *c, uint64_t kmers_ub);
 struct XchgOut;
 static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo);
 static int xchg_prepare_cursors(shk_ctx *c, uint32_t *n_words);
+static bool trace_on() {
+  static const bool on = getenv("SHK_TRACE") != nullptr;
+  return on;
+}
+#define SHK_TRACEF(...)                                  \
+  do {                                                   \
+    if (trace_on()) fprintf(stderr, "[shk] " __VA_ARGS__); \
+  } while (0)
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -100,6 +108,11 @@ struct shk_ctx {
   uint32_t n_lanes = 1;
   // owner share (cfg.n_owners > 1): this context holds the k-mers of owner `owner_id` only
   uint32_t n_owners = 1, owner_bits = 0, owner_id = 0;
+  // cfg.n_owners == 1 said explicitly: a "share" that is the whole key space — the context takes the owner-layout
+  // route and the shk_xchg_* rounds like any owner share (one segment), so that the exchange path of a W-rank job runs
+  // unchanged in a world of one (OwnerCounter over a one-rank communicator; configs[3] on a single card)
+  bool share_w1 = false;
+  bool is_share() const { return owner_bits != 0 || share_w1; }
   int64_t xchg_lane_fixed = -1;  // the next shk_xchg_scatter_device sends every read to this chunk lane (multi-device shk_ingest_batch)
   uint32_t n_cus = 256;  // compute units of the device (multiProcessorCount)
   hipStream_t stream = nullptr;
@@ -588,7 +601,7 @@ static PartGeom part_geom(const shk_ctx *c) {
   g.n_pages = 1u << g.lp;
   const uint32_t lvl1_log = (uint32_t)env_int("SHK_LEVEL1_LOG", 10);                      // test hooks: force
   const uint32_t two_level_min = (uint32_t)env_int("SHK_TWO_LEVEL_MIN_PAGES", MAX_PARTS);  // the two-level path
-  g.two_level = g.lw > 0 || g.n_pages > std::min<uint32_t>(two_level_min, (uint32_t)MAX_PARTS);
+  g.two_level = c->is_share() || g.n_pages > std::min<uint32_t>(two_level_min, (uint32_t)MAX_PARTS);
   g.log_p1 = g.two_level ? std::max(std::min(lvl1_log, g.lpg), g.lw) : g.lpg;
   g.log_sub = g.lpg - g.log_p1;
   g.P1 = 1u << g.log_p1;
@@ -603,7 +616,15 @@ static bool use_rec32(const shk_ctx *c, const PartGeom &g) {
   const uint32_t r1_bits = 2 * c->cfg.k >= g.log_p1 ? 2 * c->cfg.k - g.log_p1 : 0;
   return rbits >= 11 && rbits <= 32 && r1_bits <= 32 && env_int("SHK_REC32", 1) != 0;
 }
-constexpr int SC32_NT = 1024, SC32_TT = 16384;  // k_scatter32: 64 KiB of records + 64 KiB of entries in LDS,
+// (SHK_SC32_NT / SHK_SC32_WGS: build-time shape of k_scatter32 — threads per workgroup (a tile is 16 bases per
+// thread) and workgroups per CU)
+#ifndef SHK_SC32_NT
+#define SHK_SC32_NT 1024
+#endif
+#ifndef SHK_SC32_WGS
+#define SHK_SC32_WGS 1
+#endif
+constexpr int SC32_NT = SHK_SC32_NT, SC32_TT = 16 * SHK_SC32_NT;  // k_scatter32: 64 KiB of records + 64 KiB of entries in LDS,
 constexpr size_t SC32_LDS_MAX = 160 * 1024 - 1024;  // one workgroup per CU (its static LDS is < 1 KiB)
 static size_t scatter32_lds(uint32_t P1) {
   return (size_t)SC32_TT * 8 + (size_t)P1 * 12 + 32;  // entries (+ P1/2 holes at most) + records + three words per partition (+ the walk's 8 spare counters when P1 < 8)
@@ -628,7 +649,7 @@ static bool xl_feasible(const shk_ctx *c, const PartGeom &g) {
 }
 static bool xl_route(const shk_ctx *c, const PartGeom &g, bool multi, bool defer) {
   if (!xl_feasible(c, g)) return false;
-  if (g.lw > 0) return true;
+  if (c->is_share()) return true;
   return defer && multi && env_int("SHK_XL", 1) != 0;
 }
 
@@ -652,11 +673,11 @@ static CountPath count_path(const shk_ctx *c, uint64_t sub_kmers_ub, bool multi 
   // level-2 pass, ONE page launch that keeps a page's tags in LDS for all its lanes) instead of a scatter,
   // a re-scatter and a page pass per lane, each re-reading the keys — also when the batch is large enough
   // to be counted at once (the records just wait for the page pass that finalize, or the budget, asks for)
-  if (multi && c->n_lanes > 1 && !c->owner_bits && env_int("SHK_XL", 1) != 0 && env_int("SHK_DEFER", 1) != 0) {
+  if (multi && c->n_lanes > 1 && !c->is_share() && env_int("SHK_XL", 1) != 0 && env_int("SHK_DEFER", 1) != 0) {
     const PartGeom g2 = part_geom(c);
     if (g2.two_level && xl_feasible(c, g2)) return PATH_DEFER;
   }
-  if (c->owner_bits)  // an owner share: the owner layout + deferred page passes, or global atomics (both drop foreign k-mers)
+  if (c->is_share())  // an owner share: the owner layout + deferred page passes, or global atomics (both drop foreign k-mers)
     return xl_feasible(c, part_geom(c)) && env_int("SHK_DEFER", 1) != 0 ? PATH_DEFER : PATH_DIRECT;
   if ((c->cfg.flags & SHK_FLAG_FORCE_PAGED) || paged_pays(c, sub_kmers_ub)) return PATH_PAGED;
   const PartGeom g = part_geom(c);
@@ -694,6 +715,9 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
     for (uint32_t l = 0; l < c->n_lanes && !full && l < c->acc_lane_ub.size(); ++l)
       if ((lane_one < 0 || (uint32_t)lane_one == l) && c->acc_lane_ub[l] + add > c->acc_lane_budget) full = true;
     if (full) {
+      SHK_TRACEF("acc_prepare: window full (%llu booked + %llu > %llu, or a lane's %llu + %llu > %llu) -> flush\n", (unsigned long long)c->acc_records_ub,
+                 (unsigned long long)kmers_ub, (unsigned long long)c->acc_budget, (unsigned long long)(c->acc_lane_ub.empty() ? 0 : c->acc_lane_ub[0]),
+                 (unsigned long long)add, (unsigned long long)c->acc_lane_budget);
       int rc = settle(c);  // flush + settle (may grow the table)
       if (rc != SHK_OK) return rc;
     }
@@ -755,6 +779,9 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
       HIPC(c, c->part2.ensure((uint64_t)n_pages * std::min<uint64_t>(cap + MISS_SLACK, MISS_PAGE_MAX) * 8));
   }
   budget = std::min(budget, c->acc_budget_max);
+  SHK_TRACEF("acc_prepare: window of %llu records (max %llu), lane budget %llu, region cap %u x %llu pages x %u lanes, rec32 %d, first add %llu\n",
+             (unsigned long long)budget, (unsigned long long)c->acc_budget_max, (unsigned long long)c->acc_lane_budget, c->acc_cap,
+             (unsigned long long)n_pages, NL, (int)c->acc_rec32, (unsigned long long)kmers_ub);
   HIPC(c, c->acc_cur.ensure((size_t)NL * n_pages * 4 + 64));
   HIPC(c, hipMemsetAsync(c->acc_cur.p, 0, (size_t)NL * n_pages * 4, c->stream));
   c->acc_lp = c->tb.log_pages;
@@ -885,7 +912,7 @@ static int xl_scatter(shk_ctx *c, const BatchRef &b, const PartGeom &g, const Xl
   own.log_w = g.lw;
   own.keep = keep_all ? 0xFFFFFFFFu : c->owner_id;
   own.seg_recs = keep_all ? (uint32_t)x.seg_recs : 0u;
-  const uint32_t G = std::min<uint32_t>(grid_for(b.tile_count, 1, (uint32_t)env_int("SHK_PART_G", 512)), c->n_cus);
+  const uint32_t G = std::min<uint32_t>(grid_for(b.tile_count * (TILE_T / SC32_TT), 1, (uint32_t)env_int("SHK_PART_G", 512)), c->n_cus * SHK_SC32_WGS);
   const size_t lds = scatter32_lds(g.P1);
   {
     ScopedTimer t(c, SHK_K_SCATTER, /*chain=*/prezeroed && c->chain_from_mark);
@@ -961,7 +988,7 @@ static XlPlan xchg_plan(const shk_ctx *c, const PartGeom &g, uint64_t layout_bas
   return x;
 }
 static int xchg_check(shk_ctx *c, const PartGeom &g) {
-  if (!c->owner_bits) return fail(c, SHK_ERR_STATE, "not an owner share (shk_config.n_owners ≤ 1)");
+  if (!c->is_share()) return fail(c, SHK_ERR_STATE, "not an owner share (shk_config.n_owners = 0: say 1 for a share that is the whole key space)");
   if (!xl_feasible(c, g) || count_path(c, 0) != PATH_DEFER)
     return fail(c, SHK_ERR_STATE,
                 "the owner exchange needs 4-byte records (2k - %u ≤ 32) and ≤ 16 chunk lanes at this table geometry; "
@@ -1113,10 +1140,10 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       if (rec32 && lds32) {
         int rcl;
         if (defer && !two_level)  // straight into the accumulation regions, (lane, page) layout
-          rcl = launch_scatter32(c, acc_wide != 0, std::min<uint32_t>(G, c->n_cus), lds_s32, b, log_p1, 0xFFFFFFFFu,
+          rcl = launch_scatter32(c, acc_wide != 0, std::min<uint32_t>(G, c->n_cus * SHK_SC32_WGS), lds_s32, b, log_p1, 0xFFFFFFFFu,
                                  (unsigned int *)c->acc_cur.p, c->acc_cap, (uint32_t *)c->acc_buf.p, sp, dbg, NL);
         else
-          rcl = launch_scatter32(c, false, std::min<uint32_t>(G, c->n_cus), lds_s32, b, log_p1,
+          rcl = launch_scatter32(c, false, std::min<uint32_t>(G, c->n_cus * SHK_SC32_WGS), lds_s32, b, log_p1,
                                  all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1, (uint32_t *)c->part.p, sp, dbg, NL);
         if (rcl != SHK_OK) return rcl;
       } else if (rec32)
@@ -1460,7 +1487,11 @@ static int settle_light(shk_ctx *c) {
   if (!c->acc_active) return settle(c);
   int rc = read_stats(c);
   if (rc != SHK_OK) return rc;
-  if (c->h_stats->bad != ~0ull || c->h_stats->spill_count > 0) return settle(c);  // (re-reads the stats; rare)
+  if (c->h_stats->bad != ~0ull || c->h_stats->spill_count > 0) {
+    SHK_TRACEF("settle_light: last launch spilled %llu records (window %llu booked) -> settle\n", (unsigned long long)c->h_stats->spill_count,
+               (unsigned long long)c->acc_records_ub);
+    return settle(c);  // (re-reads the stats; rare)
+  }
   c->unsettled = false;  // a clean partition launch: nothing to repair, the table was not touched
   return SHK_OK;
 }
@@ -1521,6 +1552,7 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   c->cfg.device_ids = nullptr;
   c->cfg.n_devices = 0;
   c->n_lanes = cfg->chunks == 0 ? 1 : cfg->chunks;  // io.rs:378
+  c->share_w1 = cfg->n_owners == 1;
   if (cfg->n_owners > 1) {
     c->n_owners = cfg->n_owners;
     c->owner_id = cfg->owner_id;
@@ -1571,7 +1603,7 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
   c->h_hist = (const uint64_t *)(c->h_ctl + c->ctl_hist_off);
   c->h_stats->bad = ~0ull;
   uint64_t want = cfg->table_capacity_hint ? cfg->table_capacity_hint * 2 : (1ull << 20);
-  if (c->owner_bits && 2 * cfg->k > 32 + c->owner_bits && 2 * cfg->k - 32 <= (uint32_t)env_int("SHK_LEVEL1_LOG", 10))
+  if (c->is_share() && 2 * cfg->k > 32 + c->owner_bits && 2 * cfg->k - 32 <= (uint32_t)env_int("SHK_LEVEL1_LOG", 10))
     // an owner share starts with enough pages for 4-byte exchange records (2k − level-1 bits ≤ 32, the
     // level-1 fan-out being at most the page bits of the virtual table): k = 21 → 2^10 pages over all owners
     want = std::max<uint64_t>(want, (uint64_t)PAGE_SLOTS << (2 * cfg->k - 32 - c->owner_bits));
@@ -2069,6 +2101,26 @@ int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, co
   SpillRef sp = spill_ref(c->spillA, spill_cap);
   rc = xl_absorb(c, g, (const uint32_t *)d_records, (const unsigned int *)d_cursors, lay->region_cap, lay->regions, sp);
   if (rc != SHK_OK) return rc;
+  if (trace_on()) {  // (debugging aid: where did the segment's records go?)
+    const size_t nreg = (size_t)c->n_lanes << c->tb.log_pages;
+    std::vector<unsigned int> cur(nreg), src(lay->regions);
+    unsigned long long spilled = 0;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(cur.data(), c->acc_cur.p, nreg * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(src.data(), d_cursors, (size_t)lay->regions * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&spilled, &c->d_stats->spill_count, 8, hipMemcpyDeviceToHost);
+    unsigned long long sum = 0, ssum = 0;
+    unsigned int mx = 0, mn = ~0u, over = 0, smx = 0;
+    for (unsigned int v : cur) sum += v, mx = std::max(mx, v), mn = std::min(mn, v), over += v > c->acc_cap;
+    for (size_t i = 0, shown = 0; i < cur.size() && shown < 6; ++i)
+      if (cur[i] > c->acc_cap) {
+        SHK_TRACEF("  page %zu (sub %zu of super-page %zu): %u records\n", i, i & ((1u << g.log_sub) - 1u), i >> g.log_sub, cur[i]);
+        ++shown;
+      }
+    for (unsigned int v : src) ssum += v, smx = std::max(smx, v);
+    SHK_TRACEF("absorb: segment holds %llu records (fullest region %u of cap %u); page cursors: sum %llu min %u max %u, %u over cap %u; spill_count %llu (list cap %llu)\n",
+               ssum, smx, lay->region_cap, sum, mn, mx, over, c->acc_cap, spilled, (unsigned long long)spill_cap);
+  }
   c->acc_active = true;
   acc_book(c, est, -1, lane_bound);
   c->unsettled = true;
@@ -2155,7 +2207,7 @@ static int finalize_scan(shk_ctx *c) {
   HIPC(c, hipSetDevice(c->cfg.device));
   uint64_t n_reads = 0;
   for (auto v : c->lane_reads) n_reads += v;
-  if (n_reads == 0 && c->n_inserted == 0 && !c->own_set && !c->owner_bits)  // io.rs:578-580 (owner shares: the caller looks at the sum over the shares)
+  if (n_reads == 0 && c->n_inserted == 0 && !c->own_set && !c->is_share())  // io.rs:578-580 (owner shares: the caller looks at the sum over the shares)
     return fail(c, SHK_ERR_NO_READS,
                 "No reads were ingested. Check that input files contain valid FASTQ records.");
   if (c->acc_active) {  // records still waiting for their page pass

@@ -31,6 +31,49 @@ import numpy as np
 import torch
 
 
+# No single message above this many bytes.  Measured on MI355X (RCCL 2.26.6 as shipped with torch 2.10 / ROCm 7.0,
+# tools/rccl_a2a_probe.py): a send/recv pair of more than 2^30 bytes delivers only the first half of the buffer and
+# reports success — all_to_all_single, all_to_all and batch_isend_irecv alike (a 1044 MiB message: the second 522 MiB
+# never arrive; 1024 MiB and below are whole).  Everything here that can grow with the job goes in pieces well below.
+MAX_MESSAGE_BYTES = int(os.environ.get("SHK_DIST_MAX_MESSAGE", 1 << 28))   # (the variable: a test hook)
+
+
+def exchange_parts(dist, out: torch.Tensor, inp: torch.Tensor, world: int, rank: int, in_splits=None, out_splits=None,
+                   skip_self: bool = False):
+    """all_to_all_single — part s of `inp` (in_splits[s] elements; equal parts when None) goes to rank s, part s of
+    `out` comes from rank s — that never hands the communicator a message above MAX_MESSAGE_BYTES: when every part is
+    below it, ONE all_to_all_single; otherwise grouped send/recv pairs over slices of the parts (the fully connected
+    mesh still carries a rank's W−1 transfers at once), the rank's own part by a device copy (skip_self: not at all —
+    the caller uses it where it lies)."""
+    if in_splits is None:
+        per = inp.numel() // world
+        assert inp.numel() == per * world and out.numel() == inp.numel()
+        in_splits = out_splits = [per] * world
+    esz = inp.element_size()
+    if max(max(in_splits), max(out_splits)) * esz <= MAX_MESSAGE_BYTES or not hasattr(dist, "batch_isend_irecv"):
+        if in_splits[0] * world == inp.numel() and len(set(in_splits)) == 1 and list(in_splits) == list(out_splits):
+            dist.all_to_all_single(out, inp)   # (in-process test transports have nothing else)
+        else:
+            dist.all_to_all_single(out, inp, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits))
+        return
+    step = MAX_MESSAGE_BYTES // esz
+    in_at = [sum(in_splits[:i]) for i in range(world)]
+    out_at = [sum(out_splits[:i]) for i in range(world)]
+    assert in_splits[rank] == out_splits[rank]
+    if not skip_self and in_splits[rank]:
+        out[out_at[rank]:out_at[rank] + out_splits[rank]].copy_(inp[in_at[rank]:in_at[rank] + in_splits[rank]])
+    ops = []
+    for d in range(1, world):
+        to, frm = (rank + d) % world, (rank - d) % world
+        for c0 in range(0, in_splits[to], step):   # (both ends cut a part the same way: at multiples of `step`)
+            ops.append(dist.P2POp(dist.isend, inp[in_at[to] + c0:in_at[to] + min(in_splits[to], c0 + step)], to))
+        for c0 in range(0, out_splits[frm], step):
+            ops.append(dist.P2POp(dist.irecv, out[out_at[frm] + c0:out_at[frm] + min(out_splits[frm], c0 + step)], frm))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
 def shard_batches(n_reads: int, rank: int, world: int, batch: int = 1000):
     """Round-robin assignment of whole 1000-read batches to ranks: returns
     [(first_read, n_reads_in_batch), ...] for `rank`.  Chunk membership is a function of the
@@ -116,11 +159,15 @@ class OwnerCounter:
             if self._recv is None or self._recv[0].numel() != rec.numel() or self._recv[1].numel() != cur.numel():
                 self._recv = (torch.empty_like(rec), torch.empty_like(cur))
             rrec, rcur = self._recv
-            dist.all_to_all_single(rrec, rec)
-            dist.all_to_all_single(rcur, cur)
             S, G = lay.segment_records, lay.regions
+            # a segment above the message limit travels in pieces, and the rank's own segment then does not travel at
+            # all: it is absorbed where the scatter left it (shk.h: "rank r's own segment needs no copy")
+            big = S * rec.element_size() > MAX_MESSAGE_BYTES and hasattr(dist, "batch_isend_irecv")
+            exchange_parts(dist, rrec, rec, W, self.rank, skip_self=True)
+            dist.all_to_all_single(rcur, cur)
             for s in range(W):
-                self.eng.xchg_absorb_tensors(rrec[s * S:(s + 1) * S], rcur[s * G:(s + 1) * G], lay)
+                src = rec if (big and s == self.rank) else rrec
+                self.eng.xchg_absorb_tensors(src[s * S:(s + 1) * S], rcur[s * G:(s + 1) * G], lay)
             if any_foreign:
                 self.n_foreign_rounds += 1
                 self._exchange_spills()
@@ -265,7 +312,7 @@ class DistCounter:
             with torch.cuda.stream(ext):
                 buf, L = self.eng.compact_owner_fixed(W, self._cap, self.rank)
                 rbuf = torch.empty_like(buf)
-                dist.all_to_all_single(rbuf, buf)
+                exchange_parts(dist, rbuf, buf, W, self.rank)
                 self.eng.merge_fixed_pieces(rbuf, W, self._cap, self.rank)
                 self._keep = (buf, rbuf)
             self._fixed_used = self._cap
@@ -304,7 +351,7 @@ class DistCounter:
                 buf, L = self.eng.compact_owner_packed(counts, self.rank)
                 w = 2 + L
                 rbuf = torch.empty(max(sum(recv) * w, 1), dtype=torch.int32, device=buf.device)[:sum(recv) * w]
-                dist.all_to_all_single(rbuf, buf, output_split_sizes=[r * w for r in recv], input_split_sizes=[x * w for x in send])
+                exchange_parts(dist, rbuf, buf, W, self.rank, in_splits=[x * w for x in send], out_splits=[r * w for r in recv])
                 at = 0
                 for src in range(W):
                     self.eng.merge_packed_piece(rbuf[at:at + recv[src] * w], recv[src], L)
@@ -315,9 +362,9 @@ class DistCounter:
         n_recv = sum(recv)
         rk = keys.new_empty(n_recv)
         rv = vals.new_empty((n_lanes, n_recv))
-        dist.all_to_all_single(rk, keys, output_split_sizes=recv, input_split_sizes=send)
+        exchange_parts(dist, rk, keys, W, self.rank, in_splits=send, out_splits=recv)
         for l in range(n_lanes):
-            dist.all_to_all_single(rv[l], vals[l].contiguous(), output_split_sizes=recv, input_split_sizes=send)
+            exchange_parts(dist, rv[l], vals[l].contiguous(), W, self.rank, in_splits=send, out_splits=recv)
         if rk.is_cuda:
             # RCCL enqueues on torch's stream; the merge below runs on the engine's own HIP
             # stream, so the received entries must have landed before it is launched
@@ -335,9 +382,9 @@ class DistCounter:
         keys, vals = self.eng.table_tensors()          # [P*S], [L, P*S]
         rk = torch.empty_like(keys)                     # rk[s*n:(s+1)*n] = rank s's slice of MY range
         rv = torch.empty_like(vals)
-        dist.all_to_all_single(rk, keys)
+        exchange_parts(dist, rk, keys, W, self.rank)
         for l in range(n_lanes):
-            dist.all_to_all_single(rv[l], vals[l])
+            exchange_parts(dist, rv[l], vals[l], W, self.rank)
         if rk.is_cuda:
             torch.cuda.synchronize()
         p0, p1 = self.rank * per, (self.rank + 1) * per

@@ -182,11 +182,15 @@ def _worker(rank, world, port, k, chunks, histo_max, n_reads, out_dir, dense=Fal
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,chunks,n_reads,dense", [(21, 1, 2500, False), (15, 3, 4321, False), (9, 0, 1800, False),
-                                                      (15, 3, 4321, True)])
-def test_two_rank_merge_matches_single_oracle(orc, tmp_path, k, chunks, n_reads, dense):
-    """Compact exchange (occupied entries, uneven all_to_all splits) and the dense one (page ranges)."""
+@pytest.mark.parametrize("k,chunks,n_reads,dense,max_msg", [(21, 1, 2500, False, 0), (15, 3, 4321, False, 0), (9, 0, 1800, False, 0),
+                                                              (15, 3, 4321, True, 0), (15, 3, 4321, False, 2048), (15, 3, 4321, True, 4096)])
+def test_two_rank_merge_matches_single_oracle(orc, tmp_path, monkeypatch, k, chunks, n_reads, dense, max_msg):
+    """Compact exchange (occupied entries, uneven all_to_all splits) and the dense one (page ranges).  max_msg: the
+    message limit of sharkmer_amd.dist pinned so low that every exchange goes in pieces (grouped send/recv pairs over
+    slices, the own part by a copy) — the path that keeps messages below what RCCL was measured to deliver whole."""
     import sharkmer_amd as sa
+    if max_msg:
+        monkeypatch.setenv("SHK_DIST_MAX_MESSAGE", str(max_msg))
     histo_max = 40
     port = _free_port()
     mp.spawn(_worker, args=(2, port, k, chunks, histo_max, n_reads, str(tmp_path), dense), nprocs=2, join=True)
@@ -365,13 +369,17 @@ def _owner_input(sa, n_reads, poly):
     return bases, offsets
 
 
-@pytest.mark.parametrize("k,chunks,n_reads,log_p1,cap,poly", [(21, 10, 3300, 10, 1024, False), (15, 3, 2500, 4, 1024, True),
-                                                             (9, 0, 1800, 1, 2048, False)])
-def test_two_rank_owner_partitioned_ingest_matches_single_oracle(orc, tmp_path, k, chunks, n_reads, log_p1, cap, poly):
+@pytest.mark.parametrize("k,chunks,n_reads,log_p1,cap,poly,max_msg", [(21, 10, 3300, 10, 1024, False, 0), (15, 3, 2500, 4, 1024, True, 0),
+                                                                     (9, 0, 1800, 1, 2048, False, 0), (21, 10, 3300, 10, 1024, False, 8192),
+                                                                     (15, 3, 2500, 4, 1024, True, 1000)])
+def test_two_rank_owner_partitioned_ingest_matches_single_oracle(orc, tmp_path, monkeypatch, k, chunks, n_reads, log_p1, cap, poly, max_msg):
     """World 2, 10 chunk lanes (BASELINE configs[4]'s shape): every rank ingests its own 1000-read batches,
     records travel by owner every round, nothing is merged at finalize; a skewed case goes through the
-    foreign spill list."""
+    foreign spill list.  max_msg: segments above the (pinned) message limit travel in pieces and a rank's own segment
+    is absorbed where the scatter left it."""
     import sharkmer_amd as sa
+    if max_msg:
+        monkeypatch.setenv("SHK_DIST_MAX_MESSAGE", str(max_msg))
     histo_max = 40
     port = _free_port()
     mp.spawn(_owner_worker, args=(2, port, k, chunks, histo_max, n_reads, log_p1, cap, poly, str(tmp_path)), nprocs=2, join=True)
