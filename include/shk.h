@@ -426,6 +426,14 @@ const char *shk_fastq_error(const shk_fastq *r);
  * does not fit is delivered first by the next call. */
 int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint64_t *offsets,
                          uint64_t max_seqs, uint64_t *n_seqs);
+/* The same batch in the 2-bit packed input format (above: Read::from_str's layout over the batch's concatenated
+ * bases + the N mask), packed while the sequences are copied out of the parsed file — what shk_pack_reads would make
+ * of shk_fastq_next_batch's output, without the ASCII batch in between: packed takes (bases_cap+3)/4 bytes rounded up
+ * to 8, nmask (bases_cap+31)/32 words; offsets are base indices from 0.  A byte outside ACGTN among the reads handed
+ * out is SHK_ERR_INVALID_CHAR with the text of encoding.rs:353-356 (those reads are ones the reference would have
+ * drained, io.rs:340-343, so it would have met the byte too). */
+int shk_fastq_next_batch_packed(shk_fastq *r, uint8_t *packed, uint32_t *nmask, uint64_t bases_cap, uint64_t *offsets,
+                                uint64_t max_seqs, uint64_t *n_seqs);
 int shk_fastq_stats(const shk_fastq *r, uint64_t *n_reads_read, uint64_t *n_bases_read,
                     int *reached_max, int *done);
 

@@ -14,6 +14,7 @@
 #include "shk_front.h"
 #include "shk_inflate.h"
 
+#include <immintrin.h>
 #include <sched.h>
 
 #include <fcntl.h>
@@ -190,6 +191,97 @@ static bool any_high_bit(const uint8_t *s, size_t n) {
   uint8_t a = 0;
   for (; i < n; ++i) a |= s[i];
   return ((acc & 0x8080808080808080ull) | (a & 0x80)) != 0;
+}
+
+// An array that is not value-initialised (the line tables of a 128 MiB window are megabytes: zero-filling them, by one
+// thread, was a third of the window's parse).
+template <class T>
+struct UBuf {
+  std::unique_ptr<T[]> p;
+  size_t n = 0, cap = 0;
+  void resize_discard(size_t m) {  // (contents are lost when it has to grow)
+    if (m > cap) {
+      p.reset(new T[m]);
+      cap = m;
+    }
+    n = m;
+  }
+  T *data() { return p.get(); }
+  const T *data() const { return p.get(); }
+  size_t size() const { return n; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+};
+constexpr uint32_t NL_POS = 0x7FFFFFFFu, NL_CR = 0x80000000u;  // a line-table entry: position of the '\n' | "the byte before it is '\r'"
+
+// One pass over a share [a, b) of a window of n bytes: for every '\n' in it an entry (its position relative to `base`,
+// NL_CR when the byte in front of it is '\r' — what BufRead::lines strips with it) appended to `nl`, and the byte
+// behind it — the first byte of the next line, which is all validate_fastq_record looks at in a header or separator
+// (io.rs:169-189) — appended to `fb` (0 at the window's end); returns whether any byte of the share has its top bit
+// set.  With these the per-record pass never touches the file's bytes again.  The AVX2 form takes 64 bytes per step —
+// the compare masks of two vectors as one 64-bit word, an entry per set bit — and reads the top bits off the same
+// vectors (vpmovmskb IS the top bits); memchr line by line (a FASTQ record is four short lines) and a second pass for
+// the top bits took three times as long.
+static inline void scan_emit(const char *base, size_t n, size_t i, uint32_t *nl, uint8_t *fb, size_t at) {
+  nl[at] = (uint32_t)i | ((i && base[i - 1] == '\r') ? NL_CR : 0u);
+  fb[at] = i + 1 < n ? (uint8_t)base[i + 1] : (uint8_t)0;
+}
+static bool scan_share_scalar(const char *base, size_t n, size_t a, size_t b, std::vector<uint32_t> &nl, std::vector<uint8_t> &fb) {
+  const char *p = base + a, *e = base + b;
+  while (p < e) {
+    const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+    if (!q) break;
+    nl.push_back(0);
+    fb.push_back(0);
+    scan_emit(base, n, (size_t)(q - base), nl.data(), fb.data(), nl.size() - 1);
+    p = q + 1;
+  }
+  return any_high_bit((const uint8_t *)base + a, b - a);
+}
+__attribute__((target("avx2,bmi,bmi2"))) static bool scan_share_avx2(const char *base, size_t n, size_t a, size_t b, std::vector<uint32_t> &nl,
+                                                                   std::vector<uint8_t> &fb) {
+  size_t i = a;
+  uint32_t hi = 0;
+  const __m256i nlv = _mm256_set1_epi8('\n');
+  // room for the worst case of one step (64 entries) is kept ahead of the write cursor
+  size_t at = nl.size();
+  size_t cap = std::max<size_t>(nl.capacity(), at + 4096);
+  nl.resize(cap);
+  fb.resize(cap);
+  uint32_t *w = nl.data();
+  uint8_t *f = fb.data();
+  for (; i + 64 <= b; i += 64) {
+    const __m256i v0 = _mm256_loadu_si256((const __m256i *)(base + i));
+    const __m256i v1 = _mm256_loadu_si256((const __m256i *)(base + i + 32));
+    hi |= (uint32_t)_mm256_movemask_epi8(_mm256_or_si256(v0, v1));
+    uint64_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v0, nlv)) |
+                 ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v1, nlv)) << 32);
+    if (m) {
+      if (at + 64 > cap) {
+        cap *= 2;
+        nl.resize(cap);
+        fb.resize(cap);
+        w = nl.data();
+        f = fb.data();
+      }
+      do {
+        scan_emit(base, n, i + (size_t)_tzcnt_u64(m), w, f, at++);
+        m = _blsr_u64(m);
+      } while (m);
+    }
+  }
+  nl.resize(at);
+  fb.resize(at);
+  bool h = hi != 0;
+  if (i < b) h |= scan_share_scalar(base, n, i, b, nl, fb);
+  return h;
+}
+static bool have_avx2() {  // (SHK_NO_AVX2: the portable forms, for the tests)
+  static const bool on = !getenv("SHK_NO_AVX2") && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
+  return on;
+}
+static bool scan_share(const char *base, size_t n, size_t a, size_t b, std::vector<uint32_t> &nl, std::vector<uint8_t> &fb) {
+  return have_avx2() ? scan_share_avx2(base, n, a, b, nl, fb) : scan_share_scalar(base, n, a, b, nl, fb);
 }
 
 // ---- sources ---------------------------------------------------------------------------------------------------
@@ -395,22 +487,21 @@ struct SeqChunk {
   // them straight into the caller's batch buffer.
   std::shared_ptr<Buf> hold;
   const char *src = nullptr;
-  std::vector<uint32_t> nl;
+  const char *src_end = nullptr;   // one past the window's last byte (a 32-byte load must not start within 31 bytes of it)
+  UBuf<uint32_t> nl;  // entries: position | NL_CR
   size_t line0 = 0;
   bool last_unterminated = false;  // line nl.size()-1 has no '\n' (its '\r', if any, stays: BufRead::lines)
   bool has_lead = false;
   std::string lead_seq;
-  std::vector<uint32_t> lens;  // all records, the lead first
+  UBuf<uint32_t> lens;  // all records, the lead first
   std::vector<Flaw> flaws;     // ascending by rec
   uint64_t first_rec = 0;      // local index (within the file) of the chunk's first record
   size_t bytes() const { return lens.size() * 4 + nl.size() * 4 + lead_seq.size() + (hold ? hold->v.size() : 0); }
   void seq_line(size_t j, const char **p, size_t *len) const {  // j: index among the whole records
     const size_t l = line0 + 4 * j + 1;
-    const size_t s0 = (size_t)nl[l - 1] + 1, s1 = nl[l];
-    size_t n = s1 - s0;
-    if (!(last_unterminated && l == nl.size() - 1) && n && src[s1 - 1] == '\r') --n;
+    const size_t s0 = (size_t)(nl[l - 1] & NL_POS) + 1, s1 = nl[l] & NL_POS;
     *p = src + s0;
-    *len = n;
+    *len = s1 - s0 - (nl[l] >> 31);  // (an unterminated last line's entry never carries NL_CR: its '\r', if any, stays)
   }
 };
 // how a file ended
@@ -561,7 +652,10 @@ struct Producer {
   }
 
   // ---- the parse ---------------------------------------------------------------------------------------------------
-  std::vector<std::vector<uint32_t>> tl_nl;  // the newline positions each pool thread found in its share of the window
+  // what each pool thread found in its share of the window (kept across windows: no allocation after the first)
+  std::vector<std::vector<uint32_t>> tl_nl;
+  std::vector<std::vector<uint8_t>> tl_fb;
+  UBuf<uint8_t> FB;  // first byte of the line behind every '\n' of the window
   // the lines of a record begun in one window and not finished there (at most three), as BufRead::lines yields them
   std::vector<std::string> carry;
   std::vector<uint8_t> carry_valid;  // are they UTF-8
@@ -576,30 +670,22 @@ struct Producer {
     const bool dbg = getenv("SHK_FASTQ_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = now();
-    // 1. newline positions: every share of the window is scanned ONCE — a thread keeps the positions it finds in a list
-    // of its own (kept across windows: no allocation after the first) — and, their places among all the lines known
-    // from a prefix sum, the lists are copied into the window's line table (4 B per line, ≈ 5 % of the window's bytes).
-    // The same pass notes whether a share has any byte ≥ 0x80 (only then is anything checked for UTF-8) and, for a gzip
-    // member, sums the share's CRC-32.
+    // 1. the line table: every share of the window is scanned ONCE (scan_share) into lists of the scanning thread's own
+    // and, their places among all the lines known from a prefix sum, the lists are copied into the window's tables (5 B
+    // per line, ≈ 6 % of the window's bytes).  The same pass notes whether a share has any byte ≥ 0x80 (only then is
+    // anything checked for UTF-8) and, for a gzip member, sums the share's CRC-32.
     const uint32_t TT = n >= (1u << 16) ? T : 1;
     std::vector<size_t> first(TT + 1, 0);
     std::vector<uint8_t> high(TT, 0);
     std::vector<uint32_t> crcs(TT, 0);
-    if (tl_nl.size() < TT) tl_nl.resize(TT);
+    if (tl_nl.size() < TT) tl_nl.resize(TT), tl_fb.resize(TT);
     const bool want_crc = src->wants_crc();
     auto scan = [&](uint32_t t) {
       const size_t a = n * t / TT, b = n * (t + 1) / TT;
-      const char *p = base + a, *e = base + b;
-      std::vector<uint32_t> &v = tl_nl[t];
-      v.clear();
-      while (p < e) {
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
-        if (!nl) break;
-        v.push_back((uint32_t)(nl - base));
-        p = nl + 1;
-      }
-      first[t + 1] = v.size();
-      high[t] = any_high_bit((const uint8_t *)base + a, b - a);
+      tl_nl[t].clear();
+      tl_fb[t].clear();
+      high[t] = scan_share(base, n, a, b, tl_nl[t], tl_fb[t]);
+      first[t + 1] = tl_nl[t].size();
       if (want_crc) crcs[t] = crc32_update(0, (const uint8_t *)base + a, b - a);
     };
     if (TT == 1) scan(0);
@@ -613,9 +699,14 @@ struct Producer {
     }
     total_bytes += n;
     size_t M = first[TT];  // complete ('\n'-terminated) lines in the window
-    std::vector<uint32_t> NL(M + 1);
+    UBuf<uint32_t> NL;
+    NL.resize_discard(M + 1);
+    FB.resize_discard(M + 1);
     auto gather = [&](uint32_t t) {
-      if (!tl_nl[t].empty()) memcpy(NL.data() + first[t], tl_nl[t].data(), tl_nl[t].size() * 4);
+      if (!tl_nl[t].empty()) {
+        memcpy(NL.data() + first[t], tl_nl[t].data(), tl_nl[t].size() * 4);
+        memcpy(FB.data() + first[t], tl_fb[t].data(), tl_fb[t].size());
+      }
     };
     if (TT == 1) gather(0);
     else pool->parallel_for(TT, gather);
@@ -624,20 +715,20 @@ struct Producer {
       end_err = src->finish(crc, total_bytes);
       // a last line without '\n' (it has ≥ 1 byte) is a line — unless reading on fails: then what had been read of it
       // goes with the error (read_line returns the Err)
-      if (end_err.kind == IO_NONE && (M == 0 ? n > 0 : (size_t)NL[M - 1] + 1 < n)) {
-        NL[M] = (uint32_t)n;
+      if (end_err.kind == IO_NONE && (M == 0 ? n > 0 : (size_t)(NL[M - 1] & NL_POS) + 1 < n)) {
+        NL[M] = (uint32_t)n;  // (no NL_CR: the '\r' of an unterminated line stays, BufRead::lines)
+        FB[M] = 0;
         ++M;
         last_unterminated = true;
       }
     }
-    NL.resize(M);
-    // line ℓ = [ℓ ? NL[ℓ-1]+1 : 0, NL[ℓ]), '\r' stripped (not from an unterminated last line)
+    // line ℓ = [ℓ ? NL[ℓ-1]+1 : 0, NL[ℓ]), a '\r' in front of the '\n' stripped
+    auto line_start = [&](size_t l) -> size_t { return l ? (size_t)(NL[l - 1] & NL_POS) + 1 : 0; };
+    auto line_len = [&](size_t l) -> size_t { return (size_t)(NL[l] & NL_POS) - line_start(l) - (NL[l] >> 31); };
+    auto line_first = [&](size_t l) -> uint8_t { return l ? FB[l - 1] : (uint8_t)base[0]; };  // (only looked at when the line is not empty)
     auto line_at = [&](size_t l, const char **p, size_t *len) {
-      const size_t s0 = l ? (size_t)NL[l - 1] + 1 : 0, s1 = NL[l];
-      size_t k = s1 - s0;
-      if (!(last_unterminated && l == M - 1) && k && base[s1 - 1] == '\r') --k;
-      *p = base + s0;
-      *len = k;
+      *p = base + line_start(l);
+      *len = line_len(l);
     };
     SeqChunk c;
     c.first_rec = rec;
@@ -670,35 +761,37 @@ struct Producer {
     }
     const size_t R = (M - l0) / 4;  // whole records from line l0 on
     const size_t n_lead = c.has_lead ? 1 : 0;
-    c.lens.resize(n_lead + R);
+    c.lens.resize_discard(n_lead + R);
     if (c.has_lead) c.lens[0] = (uint32_t)c.lead_seq.size();
     const double t_c = now();
-    // 3. sequence lengths + flaws, records shared out evenly (the sequences themselves stay where they are)
+    // 3. sequence lengths + flaws, records shared out evenly: arithmetic on the tables alone (the file's bytes are only
+    // looked at again for the text of a flaw, or when the window has bytes ≥ 0x80)
     const uint32_t TR = R >= 4096 ? T : 1;
     std::vector<std::vector<Flaw>> fl(TR);
     auto per_record = [&](uint32_t t) {
       const size_t r0 = R * t / TR, r1 = R * (t + 1) / TR;
       for (size_t r = r0; r < r1; ++r) {
-        const char *h, *sq, *sp, *ql;
-        size_t hl, sl, spl, qll;
-        line_at(l0 + 4 * r, &h, &hl);
-        line_at(l0 + 4 * r + 1, &sq, &sl);
-        line_at(l0 + 4 * r + 2, &sp, &spl);
-        line_at(l0 + 4 * r + 3, &ql, &qll);
+        const size_t l = l0 + 4 * r;
+        const size_t hl = line_len(l), sl = line_len(l + 1), spl = line_len(l + 2), qll = line_len(l + 3);
         c.lens[n_lead + r] = (uint32_t)sl;
-        Flaw f;
         if (any_high) {  // BufRead::lines: a line that is not UTF-8 is an error of the read, whatever the cadence
-          const char *lp[4] = {h, sq, sp, ql};
           const size_t ll[4] = {hl, sl, spl, qll};
           int bad = -1;
-          for (int i = 0; i < 4 && bad < 0; ++i)
-            if (any_high_bit((const uint8_t *)lp[i], ll[i]) && !valid_utf8((const uint8_t *)lp[i], ll[i])) bad = i;
+          for (int i = 0; i < 4 && bad < 0; ++i) {
+            const uint8_t *lp = (const uint8_t *)base + line_start(l + i);
+            if (any_high_bit(lp, ll[i]) && !valid_utf8(lp, ll[i])) bad = i;
+          }
           if (bad >= 0) {
             fl[t].emplace_back(Flaw{rec + n_lead + r, FLAW_UTF8, (uint8_t)bad, std::string(), 0, 0});
             continue;
           }
         }
-        if (find_flaw(h, hl, sl, sp, spl, qll, rec + n_lead + r, &f)) fl[t].emplace_back(std::move(f));
+        // validate_fastq_record's checks (io.rs:169-196) off the tables; the lines themselves only for a flaw's text
+        const bool h_ok = hl && line_first(l) == '@', sp_ok = spl && line_first(l + 2) == '+';
+        if (!h_ok || !sp_ok || qll != sl) {
+          Flaw f;
+          if (find_flaw(base + line_start(l), hl, sl, base + line_start(l + 2), spl, qll, rec + n_lead + r, &f)) fl[t].emplace_back(std::move(f));
+        }
       }
     };
     if (TR == 1) per_record(0);
@@ -715,9 +808,10 @@ struct Producer {
     }
     c.hold = w.hold;
     c.src = base;
+    c.src_end = base + n;
     c.line0 = l0;
     c.last_unterminated = last_unterminated && l0 + 4 * R == M;  // (else the unterminated line is not among the records')
-    NL.resize(l0 + 4 * R);
+    NL.n = l0 + 4 * R;
     c.nl = std::move(NL);
     rec += n_lead + R;
     const double t_d = now();
@@ -732,6 +826,8 @@ struct Producer {
     Window w;
     bool saw_last = false;
     while (!cancelled() && src->next(&w)) {
+      if (w.n > NL_POS)  // (a single line of 2 GiB: the line tables hold 31-bit positions)
+        return finish(FileEnd{END_STREAM, (int)carry.size(), IoError{IO_OTHER, "line longer than 2 GiB"}});
       parse_window(w);
       saw_last = w.last;
       w = Window();
@@ -749,6 +845,136 @@ struct Producer {
     if (end_err.kind != IO_NONE) return finish(FileEnd{END_STREAM, (int)carry.size(), end_err});
     if (!carry.empty()) return finish(FileEnd{END_TRUNCATED, (int)carry.size(), {}});
     finish(FileEnd{});
+  }
+};
+
+}  // namespace
+
+// ---- 2-bit packing straight out of the parsed windows ---------------------------------------------------------
+// The batch's concatenated bases as ONE sequence in the layout of the reference's Read::from_str (encoding.rs:60-95:
+// four bases per byte, the first in the top two bits; A 00, C 01, G 10, T 11) + an N mask (bit p % 32 of word p / 32;
+// an N is 00 in the stream) — what shk_pack_reads makes of an ASCII batch, made here while the sequences are copied
+// out of the mapped file, so that a batch crosses PCIe at 0.3 B per base and is never written as ASCII at all.
+namespace {
+
+// up to 32 bases → their codes as a big-endian 64-bit word (first base on top, missing bases 0), the N bits and the
+// bits of bytes outside ACGTN (bit i = base i)
+struct Conv32 {
+  uint64_t be;
+  uint32_t nbits, bad;
+};
+static inline Conv32 conv32_scalar(const uint8_t *p, uint32_t n) {
+  static const struct Lut {
+    uint8_t t[256];
+    Lut() {
+      memset(t, 0xFF, sizeof t);
+      t[(unsigned)'A'] = 0, t[(unsigned)'C'] = 1, t[(unsigned)'G'] = 2, t[(unsigned)'T'] = 3, t[(unsigned)'N'] = 4;
+    }
+  } lut;
+  Conv32 r{0, 0, 0};
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint8_t c = lut.t[p[i]];
+    if (c == 0xFF) r.bad |= 1u << i;
+    else if (c == 4) r.nbits |= 1u << i;
+    else r.be |= (uint64_t)c << (62 - 2 * i);
+  }
+  return r;
+}
+__attribute__((target("avx2,bmi,bmi2"))) static inline Conv32 conv32_avx2(const uint8_t *p, uint32_t n) {
+  const __m256i v = _mm256_loadu_si256((const __m256i *)p);
+  const __m256i isn = _mm256_cmpeq_epi8(v, _mm256_set1_epi8('N'));
+  const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(v, _mm256_set1_epi8('C'))),
+                                     _mm256_or_si256(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('G')), _mm256_or_si256(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('T')), isn)));
+  const uint32_t live = n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u;
+  Conv32 r;
+  r.nbits = (uint32_t)_mm256_movemask_epi8(isn) & live;
+  r.bad = ~(uint32_t)_mm256_movemask_epi8(ok) & live;
+  // A 41 C 43 G 47 T 54: bits 2..1 are 00 01 11 10 — the code is t ^ (t >> 1); an N (and anything else) becomes 00
+  __m256i t = _mm256_and_si256(_mm256_srli_epi16(v, 1), _mm256_set1_epi8(3));
+  t = _mm256_xor_si256(t, _mm256_and_si256(_mm256_srli_epi16(t, 1), _mm256_set1_epi8(1)));
+  t = _mm256_andnot_si256(isn, t);
+  // four codes → one byte, first on top: (c0·64 + c1·16) + (c2·4 + c3)
+  const __m256i w16 = _mm256_maddubs_epi16(t, _mm256_set1_epi32(0x01041040));
+  const __m256i w32 = _mm256_madd_epi16(w16, _mm256_set1_epi16(1));
+  const __m256i b = _mm256_shuffle_epi8(w32, _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1,
+                                                               -1, -1, -1, -1, -1, -1, -1, -1, -1));
+  const uint64_t le = (uint32_t)_mm256_extract_epi32(b, 0) | ((uint64_t)(uint32_t)_mm256_extract_epi32(b, 4) << 32);  // bytes in stream order
+  uint64_t be = __builtin_bswap64(le);
+  if (n < 32) be &= ~0ull << (64 - 2 * n);  // (bytes past the sequence's end were converted too)
+  r.be = be;
+  return r;
+}
+
+// Appends bases to a packed stream at any base position: the words are big-endian 64-bit groups of 32 bases.
+struct PackWriter {
+  uint8_t *packed;
+  uint32_t *nmask;
+  uint64_t word;   // index of the 32-base word being filled
+  uint32_t fill;   // bases it holds
+  uint64_t acc;    // … on top
+  uint32_t nacc;   // their N bits (low `fill` bits)
+  uint64_t first_bad = ~0ull;  // (position << 8) | byte of the first byte outside ACGTN
+  bool avx2;
+  void open(uint8_t *pk, uint32_t *nm, uint64_t pos, bool merge_first) {
+    packed = pk, nmask = nm;
+    word = pos >> 5, fill = (uint32_t)(pos & 31);
+    acc = 0, nacc = 0;
+    if (fill && merge_first) {  // the word's first bases are there already (the chunk before wrote them, zeros behind them)
+      uint64_t be;
+      memcpy(&be, packed + word * 8, 8);
+      acc = __builtin_bswap64(be);
+      nacc = nmask[word];
+    }
+    avx2 = have_avx2();
+  }
+  inline void put(const Conv32 &c, uint32_t n, uint64_t pos, const uint8_t *src) {
+    if (c.bad && first_bad == ~0ull) {
+      const uint32_t i = (uint32_t)__builtin_ctz(c.bad);
+      first_bad = ((pos + i) << 8) | src[i];
+    }
+    acc |= fill ? c.be >> (2 * fill) : c.be;
+    const uint64_t nb = (uint64_t)c.nbits << fill;
+    nacc |= (uint32_t)nb;
+    if (fill + n >= 32) {
+      const uint64_t be = __builtin_bswap64(acc);
+      memcpy(packed + word * 8, &be, 8);
+      nmask[word] = nacc;
+      ++word;
+      acc = fill ? c.be << (64 - 2 * fill) : 0;
+      nacc = (uint32_t)(nb >> 32);
+      fill = fill + n - 32;
+    } else {
+      fill += n;
+    }
+  }
+  // `len` bases at `p` (absolute position `pos`); lim: one past the last byte that may be read
+  void append(const uint8_t *p, size_t len, uint64_t pos, const uint8_t *lim) {
+    size_t i = 0;
+    if (avx2) {
+      for (; i + 32 <= len; i += 32) put(conv32_avx2(p + i, 32), 32, pos + i, p + i);
+      if (i < len) {
+        const uint32_t n = (uint32_t)(len - i);
+        if (p + i + 32 <= lim) {
+          put(conv32_avx2(p + i, n), n, pos + i, p + i);
+        } else {
+          uint8_t tmp[32] = {0};
+          memcpy(tmp, p + i, n);
+          put(conv32_avx2(tmp, n), n, pos + i, p + i);
+        }
+      }
+    } else {
+      for (; i < len; i += 32) {
+        const uint32_t n = (uint32_t)std::min<size_t>(32, len - i);
+        put(conv32_scalar(p + i, n), n, pos + i, p + i);
+      }
+    }
+  }
+  void close() {  // a last, partial word: its unused bits are zero (the next chunk may go on in it)
+    if (fill) {
+      const uint64_t be = __builtin_bswap64(acc);
+      memcpy(packed + word * 8, &be, 8);
+      nmask[word] = nacc;
+    }
   }
 };
 
@@ -964,17 +1190,17 @@ int shk_fastq_stats(const shk_fastq *r, uint64_t *n_reads_read, uint64_t *n_base
   return SHK_OK;
 }
 
-// Fill (bases, offsets) with up to max_seqs sequences / max_bases bytes in input order.
-// offsets[0] = 0.  *n_seqs = 0 with SHK_OK means end of input.  Sequences are never split; a
-// sequence longer than bases_cap is an error.
-int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint64_t *offsets,
-                         uint64_t max_seqs, uint64_t *n_seqs) {
-  if (!r || !bases || !offsets || !n_seqs) return SHK_ERR_BAD_ARG;
+// Fill (bases, offsets) — or (packed, nmask, offsets) — with up to max_seqs sequences / bases_cap bases in input
+// order.  offsets[0] = 0.  *n_seqs = 0 with SHK_OK means end of input.  Sequences are never split; a sequence longer
+// than bases_cap is an error.
+static int next_batch_impl(shk_fastq *r, uint8_t *bases, uint8_t *packed, uint32_t *nmask, uint64_t bases_cap, uint64_t *offsets,
+                           uint64_t max_seqs, uint64_t *n_seqs) {
   *n_seqs = 0;
   offsets[0] = 0;
   if (r->err_code) return r->err_code;
   uint64_t used = 0, n = 0;
   bool stop = false;
+  uint64_t first_bad = ~0ull;
   while (!stop && n < max_seqs) {
     if (r->n_reads_read == r->limit()) {
       if (r->state == shk_fastq::RUNNING) {
@@ -1007,31 +1233,71 @@ int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint6
       used += len;
       offsets[++n] = used;
     }
-    if (take) {  // the sequences of records [seq_begin, seq_begin + take): where they lie → batch buffer
-      size_t j0 = 0;
-      if (c.has_lead && seq_begin == 0) {
-        memcpy(bases + offsets[n_begin], c.lead_seq.data(), c.lead_seq.size());
-        j0 = 1;
+    if (!take) continue;
+    const size_t lead = c.has_lead ? 1 : 0;
+    // record j of this hand-out (j in [0, take)): where its sequence lies
+    auto seq_of = [&](size_t j, const char **p, size_t *len, const char **lim) {
+      if (lead && seq_begin + j == 0) {
+        *p = c.lead_seq.data(), *len = c.lead_seq.size(), *lim = c.lead_seq.data() + c.lead_seq.size();
+      } else {
+        c.seq_line(seq_begin + j - lead, p, len);
+        *lim = c.src_end;
       }
-      const size_t lead = c.has_lead ? 1 : 0;
-      const size_t cnt = take - j0;
-      const uint32_t TT = cnt >= 4096 ? r->cpool->size() : 1;
+    };
+    const uint32_t TT = take >= 4096 ? r->cpool->size() : 1;
+    if (!packed) {  // ASCII: record by record
       auto copy = [&](uint32_t t) {
-        const size_t a = j0 + cnt * t / TT, b = j0 + cnt * (t + 1) / TT;
+        const size_t a = take * t / TT, b = take * (t + 1) / TT;
         for (size_t j = a; j < b; ++j) {
-          const char *sq;
+          const char *sq, *lim;
           size_t sl;
-          c.seq_line(seq_begin + j - lead, &sq, &sl);
+          seq_of(j, &sq, &sl, &lim);
           memcpy(bases + offsets[n_begin + j], sq, sl);
         }
       };
       if (TT == 1) copy(0);
       else r->cpool->parallel_for(TT, copy);
-      h.next += take;
-      r->n_reads_read += take;                    // io.rs:337
-      r->n_bases_read += used - offsets[n_begin];  // io.rs:335 (N included)
+    } else {
+      // packed: the hand-out's base range, cut at multiples of 32 bases so that no two threads share a word; the first
+      // cut goes on in the word the hand-out before left unfinished
+      const uint64_t B0 = offsets[n_begin], B1 = used;
+      std::vector<uint64_t> bad(TT, ~0ull);
+      auto pack = [&](uint32_t t) {
+        uint64_t P0 = t == 0 ? B0 : (B0 + (B1 - B0) * t / TT) & ~31ull, P1 = t + 1 == TT ? B1 : (B0 + (B1 - B0) * (t + 1) / TT) & ~31ull;
+        if (t > 0 && P0 < B0) P0 = B0;  // (tiny ranges: a cut may round below the start)
+        if (P1 < P0) P1 = P0;
+        if (P0 >= P1) return;
+        // the record that holds position P0
+        size_t lo = 0, hi = take;
+        while (lo + 1 < hi) {
+          const size_t mid = (lo + hi) / 2;
+          if (offsets[n_begin + mid] <= P0) lo = mid;
+          else hi = mid;
+        }
+        PackWriter w;
+        w.open(packed, nmask, P0, /*merge_first=*/true);  // (only the part that starts at the hand-out's own, unaligned start finds a word begun: every other cut is a multiple of 32)
+        for (size_t j = lo; j < take && offsets[n_begin + j] < P1; ++j) {
+          const char *sq, *lim;
+          size_t sl;
+          seq_of(j, &sq, &sl, &lim);
+          const uint64_t r0 = offsets[n_begin + j];
+          const uint64_t a = std::max(P0, r0), b = std::min<uint64_t>(P1, r0 + sl);
+          if (a < b) w.append((const uint8_t *)sq + (a - r0), (size_t)(b - a), a, (const uint8_t *)lim);
+        }
+        w.close();
+        bad[t] = w.first_bad;
+      };
+      if (TT == 1) pack(0);
+      else r->cpool->parallel_for(TT, pack);
+      for (uint64_t v : bad) first_bad = std::min(first_bad, v);
     }
+    h.next += take;
+    r->n_reads_read += take;                    // io.rs:337
+    r->n_bases_read += used - offsets[n_begin];  // io.rs:335 (N included)
+    if (first_bad != ~0ull) break;
   }
+  if (first_bad != ~0ull)  // identical text to encoding.rs:353-356 — these reads are ones the reference would have drained
+    return r->fail(SHK_ERR_INVALID_CHAR, fmt("Invalid character '%s' in sequence. Only ACGTN allowed.", byte_as_char((uint8_t)(first_bad & 0xFF)).c_str()));
   if (r->n_reads_read == r->limit() && r->state != shk_fastq::RUNNING) {
     if (r->state == shk_fastq::FAILED) {
       if (n == 0) return r->fail(r->pending_code, r->pending_err);
@@ -1043,6 +1309,18 @@ int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint6
   }
   *n_seqs = n;
   return SHK_OK;
+}
+
+int shk_fastq_next_batch(shk_fastq *r, uint8_t *bases, uint64_t bases_cap, uint64_t *offsets,
+                         uint64_t max_seqs, uint64_t *n_seqs) {
+  if (!r || !bases || !offsets || !n_seqs) return SHK_ERR_BAD_ARG;
+  return next_batch_impl(r, bases, nullptr, nullptr, bases_cap, offsets, max_seqs, n_seqs);
+}
+
+int shk_fastq_next_batch_packed(shk_fastq *r, uint8_t *packed, uint32_t *nmask, uint64_t bases_cap, uint64_t *offsets,
+                                uint64_t max_seqs, uint64_t *n_seqs) {
+  if (!r || !packed || !nmask || !offsets || !n_seqs) return SHK_ERR_BAD_ARG;
+  return next_batch_impl(r, nullptr, packed, nmask, bases_cap, offsets, max_seqs, n_seqs);
 }
 
 // ---- writers ---------------------------------------------------------------------------------------

@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 
 #include <cerrno>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -63,15 +64,34 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     shk_fastq_close(rd);
     return v;
   }
-  // super-batches through pinned buffers; the engine stripes by its own running read index,
-  // which is exactly drain_batch's cadence (io.rs:340-343,355-361) whatever the batch size
+  // Super-batches through pinned buffers, in the 2-bit PACKED input format: the front-end's copy-out threads pack the
+  // sequences straight out of the parsed file (shk_fastq_next_batch_packed), so a batch crosses PCIe at 0.3 B per base
+  // and is never written as ASCII on the host at all; the engine stripes by its own running read index, which is
+  // exactly drain_batch's cadence (io.rs:340-343,355-361) whatever the batch size.  SHK_RUN_ASCII=1: the ASCII path.
+  const bool ascii = getenv("SHK_RUN_ASCII") != nullptr;
   const uint64_t max_seqs = rc->batch_reads ? rc->batch_reads : 1000000;
-  // (pinning host memory costs ≈ 45 µs per MB each way: two 256 MB buffers were 40 ms of a 1.2 Gbase job; 64 MB
-  // batches keep every launch large enough, and a read that is longer gets larger buffers when it shows up)
+  // (pinning host memory costs ≈ 45 µs per MB each way: two 256 MB buffers were 40 ms of a 1.2 Gbase job; batches of
+  // 64 M bases keep every launch large enough, and a read that is longer gets larger buffers when it shows up)
   uint64_t cap_bases = rc->batch_bases ? rc->batch_bases : (64ull << 20);
   // two batch buffers: while the engine takes batch i (copy + count), the front-end fills batch i+1
-  uint8_t *bases2[2] = {(uint8_t *)shk_alloc_pinned(cap_bases), nullptr};
-  uint64_t *offs2[2] = {(uint64_t *)shk_alloc_pinned((max_seqs + 1) * 8), nullptr};
+  struct BatchBuf {
+    uint8_t *data = nullptr;   // ASCII bases, or the packed stream
+    uint32_t *nmask = nullptr;
+    uint64_t *offs = nullptr;
+  } bb2[2];
+  auto data_bytes = [&](uint64_t cap) { return ascii ? cap : ((cap + 3) / 4 + 7) / 8 * 8 + 64; };
+  auto alloc_buf = [&](BatchBuf &b, bool with_offs) {
+    b.data = (uint8_t *)shk_alloc_pinned(data_bytes(cap_bases));
+    if (!ascii) b.nmask = (uint32_t *)shk_alloc_pinned(((cap_bases + 31) / 32 + 16) * 4);
+    if (with_offs) b.offs = (uint64_t *)shk_alloc_pinned((max_seqs + 1) * 8);
+    return b.data && (ascii || b.nmask) && b.offs;
+  };
+  auto free_data = [&](BatchBuf &b) {
+    shk_free_pinned(b.data);
+    shk_free_pinned(b.nmask);
+    b.data = nullptr;
+    b.nmask = nullptr;
+  };
   std::thread ingest_th;
   int ingest_rc = SHK_OK;
   auto join_ingest = [&]() {
@@ -81,44 +101,47 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
   auto cleanup = [&]() {
     (void)join_ingest();
     for (int i = 0; i < 2; ++i) {
-      shk_free_pinned(bases2[i]);
-      shk_free_pinned(offs2[i]);
+      free_data(bb2[i]);
+      shk_free_pinned(bb2[i].offs);
     }
     shk_destroy(ctx);
     shk_fastq_close(rd);
   };
-  if (!bases2[0] || !offs2[0]) {
+  if (!alloc_buf(bb2[0], true)) {
     cleanup();
     g_run_error = "pinned buffer allocation failed";
     return SHK_ERR_NOMEM;
   }
+  auto next_batch = [&](BatchBuf &b, uint64_t *n) {
+    return ascii ? shk_fastq_next_batch(rd, b.data, cap_bases, b.offs, max_seqs, n)
+                 : shk_fastq_next_batch_packed(rd, b.data, b.nmask, cap_bases, b.offs, max_seqs, n);
+  };
   for (int cur = 0;; cur ^= 1) {  // any batch size keeps the striping: the engine counts reads itself
-    if (!bases2[cur]) {  // (the second pair is only allocated when there is a second batch)
-      bases2[cur] = (uint8_t *)shk_alloc_pinned(cap_bases);
-      offs2[cur] = (uint64_t *)shk_alloc_pinned((max_seqs + 1) * 8);
-      if (!bases2[cur] || !offs2[cur]) {
+    if (!bb2[cur].data) {  // (the second pair is only allocated when there is a second batch)
+      if (!alloc_buf(bb2[cur], true)) {
         cleanup();
         g_run_error = "pinned buffer allocation failed";
         return SHK_ERR_NOMEM;
       }
     }
     uint64_t n = 0;
-    v = shk_fastq_next_batch(rd, bases2[cur], cap_bases, offs2[cur], max_seqs, &n);
+    v = next_batch(bb2[cur], &n);
     while (v == SHK_ERR_BAD_ARG && !rc->batch_bases && cap_bases < (16ull << 30) &&
            strstr(shk_fastq_error(rd), "longer than the batch buffer")) {  // a very long read: larger buffers, same call again
       if (join_ingest() != SHK_OK) break;  // (the other buffer was still being read by the engine; its outcome comes first, below)
       cap_bases *= 4;
-      for (int i = 0; i < 2; ++i) {
-        if (!bases2[i]) continue;  // (not in use yet: allocated at the new size when it is)
-        shk_free_pinned(bases2[i]);
-        bases2[i] = (uint8_t *)shk_alloc_pinned(cap_bases);
-        if (!bases2[i]) {
-          cleanup();
-          g_run_error = "pinned buffer allocation failed";
-          return SHK_ERR_NOMEM;
-        }
+      bool ok = true;
+      for (int i = 0; i < 2 && ok; ++i) {
+        if (!bb2[i].data) continue;  // (not in use yet: allocated at the new size when it is)
+        free_data(bb2[i]);
+        ok = alloc_buf(bb2[i], false);
       }
-      v = shk_fastq_next_batch(rd, bases2[cur], cap_bases, offs2[cur], max_seqs, &n);
+      if (!ok) {
+        cleanup();
+        g_run_error = "pinned buffer allocation failed";
+        return SHK_ERR_NOMEM;
+      }
+      v = next_batch(bb2[cur], &n);
     }
     // the batch before this one: its outcome comes first, as in the reference, which ingests what it has read
     // before it reads on (io.rs:340-343)
@@ -134,10 +157,12 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
       return v;
     }
     if (n) {
-      uint8_t *bb = bases2[cur];
-      uint64_t *oo = offs2[cur];
+      const BatchBuf b = bb2[cur];
       ingest_rc = SHK_OK;
-      ingest_th = std::thread([&ingest_rc, ctx, bb, oo, n] { ingest_rc = shk_ingest_reads(ctx, bb, oo, n); });
+      if (ascii)
+        ingest_th = std::thread([&ingest_rc, ctx, b, n] { ingest_rc = shk_ingest_reads(ctx, b.data, b.offs, n); });
+      else
+        ingest_th = std::thread([&ingest_rc, ctx, b, n] { ingest_rc = shk_ingest_packed(ctx, b.data, b.nmask, b.offs, n); });
     }
     int done = 0;
     shk_fastq_stats(rd, nullptr, nullptr, nullptr, &done);

@@ -105,7 +105,7 @@ ABI_SYMBOLS = [
     "shk_merge_entries",
     "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
     "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_synth_reads_device",
-    "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_stats",
+    "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_next_batch_packed", "shk_fastq_stats",
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
     "shk_run_error", "shk_run_files",
     "shk_xchg_scatter_device", "shk_xchg_absorb", "shk_xchg_spill", "shk_xchg_spill_clear", "shk_insert_device",
@@ -142,7 +142,7 @@ def _share_hip_runtime_with_torch():
 
 
 FRONT_SYMBOLS = [
-    "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_stats",
+    "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_next_batch_packed", "shk_fastq_stats",
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args", "shk_run_error",
     "shk_packed_sizes", "shk_pack_reads",
 ]
@@ -160,6 +160,7 @@ def _type_front(L):
     L.shk_fastq_error.argtypes = [vp]
     L.shk_fastq_error.restype = C.c_char_p
     L.shk_fastq_next_batch.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    L.shk_fastq_next_batch_packed.argtypes = [vp, vp, vp, u64, vp, u64, C.POINTER(u64)]
     L.shk_fastq_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.shk_write_histo.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, vp]
     L.shk_write_final_histo.argtypes = [C.c_char_p, C.c_char_p, u32, u32, u64, vp]
@@ -801,6 +802,21 @@ class FastqReader:
             raise ShkError(rc, (self._L.shk_fastq_error(self._h) or b"").decode("utf-8", "replace"))
         n = int(n.value)
         return bases[:int(offsets[n])].copy(), offsets[:n + 1].copy()
+
+    def next_batch_packed(self, max_seqs: int = 1_000_000, max_bases: int = 64 << 20) -> "PackedReads":
+        """The next batch in the 2-bit packed input format (shk_fastq_next_batch_packed): what pack_reads would make
+        of next_batch's output, without the ASCII batch in between."""
+        packed = np.zeros(((max_bases + 3) // 4 + 7) // 8 * 8, dtype=np.uint8)
+        nmask = np.zeros((max_bases + 31) // 32, dtype=np.uint32)
+        offsets = np.zeros(max_seqs + 1, dtype=np.uint64)
+        n = C.c_uint64(0)
+        rc = self._L.shk_fastq_next_batch_packed(self._h, packed.ctypes.data, nmask.ctypes.data, max_bases,
+                                                 offsets.ctypes.data, max_seqs, C.byref(n))
+        if rc != 0:
+            raise ShkError(rc, (self._L.shk_fastq_error(self._h) or b"").decode("utf-8", "replace"))
+        n = int(n.value)
+        nb = int(offsets[n])
+        return PackedReads(packed[:(nb + 3) // 4].copy(), nmask[:(nb + 31) // 32].copy(), offsets[:n + 1].copy(), nb)
 
     def stats(self) -> dict:
         a, b, m, d = C.c_uint64(0), C.c_uint64(0), C.c_int(0), C.c_int(0)

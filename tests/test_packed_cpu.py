@@ -87,3 +87,79 @@ def test_pack_threads_agree_and_first_invalid_byte_wins():
         sa.pack_reads(b, o, threads=7)
     with pytest.raises(sa.ShkError, match="Invalid character 'a' in sequence"):
         _pack(b"ACGTacgt")
+
+
+# ---- the reader's packed batches (shk_fastq_next_batch_packed) -------------------------------------------------------
+
+def _fastq_file(tmp_path, name, seqs, gz=False):
+    import zlib
+    text = "".join(f"@r{i} x\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(seqs)).encode()
+    p = tmp_path / name
+    if gz:
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        text = co.compress(text) + co.flush()
+    p.write_bytes(text)
+    return str(p)
+
+
+@pytest.mark.parametrize("window_kb,batch,gz", [(0, (1_000_000, 1 << 22), False), (3, (777, 50_000), False), (16, (5_000, 1 << 20), True),
+                                                (64, (4_096, 100_000), False)])
+def test_reader_packed_batches_equal_packed_ascii_batches(tmp_path, monkeypatch, window_kb, batch, gz):
+    """The packed batch is what shk_pack_reads makes of the ASCII batch (the reference's Read::from_str layout,
+    encoding.rs:60-95, over the batch's concatenated bases + the N mask): same calls, same batch boundaries, ragged
+    lengths incl. empty reads, N runs, windows of a few KiB so that records straddle parse windows and a batch is put
+    together from several chunks (a word of 32 bases is then begun by one chunk and finished by the next)."""
+    if window_kb:
+        monkeypatch.setenv("SHK_FASTQ_WINDOW_KB", str(window_kb))
+    rng = np.random.default_rng(window_kb + batch[0])
+    seqs = []
+    for i in range(9_000):
+        L = int(rng.integers(0, 220)) if i % 50 else int(rng.integers(0, 3))
+        seqs.append("".join(rng.choice(list("ACGTN"), size=L, p=[0.24, 0.24, 0.24, 0.24, 0.04])))
+    p = _fastq_file(tmp_path, "r.fastq" + (".gz" if gz else ""), seqs, gz)
+    ra, rp = sa.FastqReader([p]), sa.FastqReader([p])
+    n_tot = 0
+    while True:
+        b, o = ra.next_batch(max_seqs=batch[0], max_bases=batch[1])
+        pk = rp.next_batch_packed(max_seqs=batch[0], max_bases=batch[1])
+        assert np.array_equal(pk.offsets, o) and pk.n_bases == int(o[-1])
+        want = sa.pack_reads(b, o, threads=1)
+        assert np.array_equal(pk.packed, want.packed) and np.array_equal(pk.nmask, want.nmask)
+        n_tot += len(o) - 1
+        if ra.stats()["done"]:
+            assert rp.stats()["done"] and rp.stats() == ra.stats()
+            break
+    assert n_tot == len(seqs)
+    ra.close()
+    rp.close()
+
+
+def test_reader_packed_reports_the_first_invalid_byte(tmp_path, monkeypatch):
+    """encoding.rs:353-356 on a packed hand-out: the first byte outside ACGTN in read order, lowercase included; and
+    only among reads the reference would have drained (io.rs:340-343) — a bad byte behind the last full thousand in
+    front of a reading error is never met."""
+    monkeypatch.setenv("SHK_FASTQ_WINDOW_KB", "8")
+    rng = np.random.default_rng(2)
+    seqs = ["".join(rng.choice(list("ACGT"), size=100)) for _ in range(2_500)]
+    bad = list(seqs)
+    bad[1_800] = bad[1_800][:40] + "x" + bad[1_800][41:]
+    bad[700] = bad[700][:99] + "R"
+    p = _fastq_file(tmp_path, "bad.fastq", bad)
+    r = sa.FastqReader([p])
+    with pytest.raises(sa.ShkError, match="Invalid character 'R' in sequence. Only ACGTN allowed."):
+        while not r.stats()["done"]:
+            r.next_batch_packed(max_seqs=600, max_bases=1 << 20)
+    r.close()
+    # the file cut inside record 1901: reads 1000..1899 are never drained, so 'x' in read 1800 is never seen
+    text = open(p, "rb").read().split(b"\n")
+    only_x = list(seqs)
+    only_x[1_800] = bad[1_800]
+    q = _fastq_file(tmp_path, "cut.fastq", only_x)
+    lines = open(q, "rb").read().split(b"\n")
+    open(q, "wb").write(b"\n".join(lines[:4 * 1_900 + 2]) + b"\n")
+    r = sa.FastqReader([q])
+    with pytest.raises(sa.ShkError, match="Truncated FASTQ record at record 1901"):
+        while not r.stats()["done"]:
+            r.next_batch_packed(max_seqs=600, max_bases=1 << 20)
+    assert r.stats()["n_reads_read"] == 1_000
+    r.close()
