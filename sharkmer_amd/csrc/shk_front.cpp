@@ -1020,18 +1020,16 @@ struct shk_fastq {
   }
   void start_producers() {
     if (!pool) {
-      // The parsing pool is the pipeline's critical path (the producer never waits for the consumer: a 128 MB window
-      // is split in ≈5 ms, its sequences are copied out in less), so it gets every CPU this process may really use
-      // — a container's CFS quota counts, not the host's core count — and the copying pool half of that
-      // (measured on a 16-CPU quota, Gbases/s of an 8 M-read plain file, three runs each, parse/copy threads: 8/8
-      // 8.6, 12/4 9.0, 16/4 9.4 and 8.8, 14/2 7.1, 24/4 9.6, 24/8 10.0, 32/4 8.7 — a quota is an AVERAGE over 100 ms:
-      // bursts wider than it are not throttled, and the pools idle half of the time).
+      // Two pools: the producers' (window parse: ≈1.5 ms per 128 MiB window) and the consumer's (prefix sums, copy-out or
+      // packing: the larger share of the work since the parse became lean).  Each gets as many threads as this process may
+      // really keep busy — a container's CFS quota counts, not the host's core count; they overlap only while a
+      // producer is ahead of the consumer.
       const uint32_t usable = usable_cpus();
       const char *ev = getenv("SHK_FASTQ_THREADS");
       const char *evc = getenv("SHK_FASTQ_COPY_THREADS");
-      T = ev && atoi(ev) > 0 ? (uint32_t)atoi(ev) : std::max(2u, std::min(24u, usable + usable / 2));
+      T = ev && atoi(ev) > 0 ? (uint32_t)atoi(ev) : std::max(2u, std::min(32u, usable));
       pool.reset(new Pool(T));
-      cpool.reset(new Pool(evc && atoi(evc) > 0 ? (uint32_t)atoi(evc) : std::max(2u, std::min(8u, usable / 2))));
+      cpool.reset(new Pool(evc && atoi(evc) > 0 ? (uint32_t)atoi(evc) : std::max(2u, std::min(32u, usable + usable / 2))));
     }
     while (started < paths.size() && started < scout_file + LOOKAHEAD) {
       auto p = std::make_unique<Producer>();
@@ -1217,21 +1215,54 @@ static int next_batch_impl(shk_fastq *r, uint8_t *bases, uint8_t *packed, uint32
     const uint64_t n_begin = n;
     const uint64_t room = std::min<uint64_t>(max_seqs - n, r->limit() - r->n_reads_read);
     size_t take = (size_t)std::min<uint64_t>(room, h.n - h.next);
-    for (size_t j = 0; j < take; ++j) {
-      const uint64_t len = c.lens[seq_begin + j];
-      // (a sequence that no batch of this size can hold: reported when it is the FIRST of a batch, with nothing
-      // consumed — the caller may come back with a larger buffer; shk_run_files does)
-      if (len > bases_cap && n == 0) {
-        r->err = "sequence longer than the batch buffer";  // (not sticky: the same call with a larger buffer goes on)
-        return SHK_ERR_BAD_ARG;
-      }
-      if (used + len > bases_cap) {  // does not fit: it is delivered first thing next call
+    // (a sequence that no batch of this size can hold: reported when it is the FIRST of a batch, with nothing
+    // consumed — the caller may come back with a larger buffer; shk_run_files does)
+    if (take && n == 0 && c.lens[seq_begin] > bases_cap) {
+      r->err = "sequence longer than the batch buffer";  // (not sticky: the same call with a larger buffer goes on)
+      return SHK_ERR_BAD_ARG;
+    }
+    // how many of them fit, and their offsets: a prefix sum over the lengths — by the copy pool when there are many
+    // (a million additions by the caller's thread alone were a third of a batch's time)
+    {
+      const uint32_t TS = take >= 65536 ? r->cpool->size() : 1;
+      std::vector<uint64_t> part(TS + 1, 0);
+      auto sum = [&](uint32_t t) {
+        const size_t a = take * t / TS, b = take * (t + 1) / TS;
+        uint64_t sacc = 0;
+        for (size_t j = a; j < b; ++j) sacc += c.lens[seq_begin + j];
+        part[t + 1] = sacc;
+      };
+      if (TS == 1) sum(0);
+      else r->cpool->parallel_for(TS, sum);
+      for (uint32_t t = 0; t < TS; ++t) part[t + 1] += part[t];
+      if (used + part[TS] > bases_cap) {  // not all of them: the first that does not fit is delivered first thing next call
+        uint32_t t = 0;
+        while (used + part[t + 1] <= bases_cap) ++t;
+        size_t j = take * t / TS;
+        uint64_t u = used + part[t];
+        while (u + c.lens[seq_begin + j] <= bases_cap) u += c.lens[seq_begin + j++];
         take = j;
         stop = true;
-        break;
       }
-      used += len;
-      offsets[++n] = used;
+      if (!stop && TS > 1) {
+        auto wr = [&](uint32_t t) {
+          const size_t a = take * t / TS, b = take * (t + 1) / TS;
+          uint64_t u = used + part[t];
+          for (size_t j = a; j < b; ++j) {
+            u += c.lens[seq_begin + j];
+            offsets[n + 1 + j] = u;
+          }
+        };
+        r->cpool->parallel_for(TS, wr);
+      } else {
+        uint64_t u = used;
+        for (size_t j = 0; j < take; ++j) {
+          u += c.lens[seq_begin + j];
+          offsets[n + 1 + j] = u;
+        }
+      }
+      if (take) used = offsets[n + take];
+      n += take;
     }
     if (!take) continue;
     const size_t lead = c.has_lead ? 1 : 0;

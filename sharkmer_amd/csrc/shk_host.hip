@@ -9,6 +9,8 @@
 #include <sys/stat.h>
 
 #include <cerrno>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -22,6 +24,17 @@ extern "C" {
 
 int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
   if (!rc) return SHK_ERR_BAD_ARG;
+  const bool trace = getenv("SHK_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
+  double t_mark = t_start;
+  auto mark = [&](const char *what) {
+    if (trace) {
+      const double t = now();
+      fprintf(stderr, "[shk] run_files: %-28s %7.2f ms (at %7.2f)\n", what, (t - t_mark) * 1e3, (t - t_start) * 1e3);
+      t_mark = t;
+    }
+  };
   g_run_error.clear();
   int v = shk_validate_args(rc->k, rc->histo_max, rc->sample);
   if (v != SHK_OK) return v;
@@ -64,11 +77,12 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     shk_fastq_close(rd);
     return v;
   }
+  mark("reader open + context create");
   // Super-batches through pinned buffers, in the 2-bit PACKED input format: the front-end's copy-out threads pack the
   // sequences straight out of the parsed file (shk_fastq_next_batch_packed), so a batch crosses PCIe at 0.3 B per base
   // and is never written as ASCII on the host at all; the engine stripes by its own running read index, which is
   // exactly drain_batch's cadence (io.rs:340-343,355-361) whatever the batch size.  SHK_RUN_ASCII=1: the ASCII path.
-  const bool ascii = getenv("SHK_RUN_ASCII") != nullptr;
+  const bool ascii = getenv("SHK_RUN_ASCII") != nullptr || rc->n_devices > 1;  // (a multi-device context deals ASCII host batches to its devices)
   const uint64_t max_seqs = rc->batch_reads ? rc->batch_reads : 1000000;
   // (pinning host memory costs ≈ 45 µs per MB each way: two 256 MB buffers were 40 ms of a 1.2 Gbase job; batches of
   // 64 M bases keep every launch large enough, and a read that is longer gets larger buffers when it shows up)
@@ -98,14 +112,31 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     if (ingest_th.joinable()) ingest_th.join();
     return ingest_rc;
   };
+  // Tearing down costs as much as a fifth of a 1.2-Gbase job — unmapping the file and joining the reader's threads
+  // (7–12 ms), unpinning the batch buffers (5 ms), freeing the table (5 ms) — so the three go side by side, and the
+  // reader is closed in the background as soon as its last batch is out (close_reader_early).
+  std::thread close_th;
+  uint64_t nrr = 0, nbr = 0;
+  auto close_reader_early = [&]() {
+    if (!rd) return;
+    shk_fastq_stats(rd, &nrr, &nbr, nullptr, nullptr);
+    shk_fastq *r0 = rd;
+    rd = nullptr;
+    close_th = std::thread([r0] { shk_fastq_close(r0); });
+  };
   auto cleanup = [&]() {
     (void)join_ingest();
-    for (int i = 0; i < 2; ++i) {
-      free_data(bb2[i]);
-      shk_free_pinned(bb2[i].offs);
-    }
+    close_reader_early();
+    std::thread unpin([&] {
+      for (int i = 0; i < 2; ++i) {
+        free_data(bb2[i]);
+        shk_free_pinned(bb2[i].offs);
+      }
+    });
     shk_destroy(ctx);
-    shk_fastq_close(rd);
+    unpin.join();
+    if (close_th.joinable()) close_th.join();
+    mark("  buffers unpinned, context destroyed, reader closed");
   };
   if (!alloc_buf(bb2[0], true)) {
     cleanup();
@@ -116,6 +147,7 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     return ascii ? shk_fastq_next_batch(rd, b.data, cap_bases, b.offs, max_seqs, n)
                  : shk_fastq_next_batch_packed(rd, b.data, b.nmask, cap_bases, b.offs, max_seqs, n);
   };
+  mark("first pinned buffers");
   for (int cur = 0;; cur ^= 1) {  // any batch size keeps the striping: the engine counts reads itself
     if (!bb2[cur].data) {  // (the second pair is only allocated when there is a second batch)
       if (!alloc_buf(bb2[cur], true)) {
@@ -168,22 +200,24 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     shk_fastq_stats(rd, nullptr, nullptr, nullptr, &done);
     if (done) break;
   }
+  mark("batches read and handed over");
+  close_reader_early();  // (every batch is out: the mapping and the reader's threads go while the engine finishes)
   v = join_ingest();
   if (v != SHK_OK) {
     g_run_error = shk_last_error(ctx);
     cleanup();
     return v;
   }
+  mark("last ingest joined");
   v = shk_finalize(ctx);
   if (v != SHK_OK) {
     g_run_error = shk_last_error(ctx);
     cleanup();
     return v;
   }
+  mark("finalize");
   shk_counters cn{};
   shk_get_counters(ctx, &cn);
-  uint64_t nrr = 0, nbr = 0;
-  shk_fastq_stats(rd, &nrr, &nbr, nullptr, nullptr);
   const char *version = rc->version ? rc->version : "3.1.0";
   std::string sample = rc->sample;
   if (rc->chunks > 0) {  // io.rs:1051-1094
@@ -222,7 +256,9 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     out_stats->command = nullptr;
     out_stats->sample = nullptr;
   }
+  mark("output files");
   cleanup();
+  mark("cleanup");
   if (v != SHK_OK) g_run_error = "Failed to create stats file";
   return v;
 }

@@ -163,3 +163,27 @@ def test_reader_packed_reports_the_first_invalid_byte(tmp_path, monkeypatch):
             r.next_batch_packed(max_seqs=600, max_bases=1 << 20)
     assert r.stats()["n_reads_read"] == 1_000
     r.close()
+
+
+def test_large_hand_outs_take_the_parallel_prefix_sum(tmp_path):
+    """Hand-outs of ≥ 65536 reads: the offsets come from a prefix sum by the copy pool, and a batch that the base
+    capacity cuts short is cut inside one thread's share — same reads, same order, same batches as the packed path."""
+    rng = np.random.default_rng(11)
+    lens = rng.integers(0, 40, size=300_000)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [letters[rng.integers(0, 4, size=int(L))].tobytes().decode() for L in lens]
+    p = _fastq_file(tmp_path, "many.fastq", seqs)
+    ra, rp = sa.FastqReader([p]), sa.FastqReader([p])
+    got, n_batches = [], 0
+    while not ra.stats()["done"]:
+        b, o = ra.next_batch(max_seqs=1_000_000, max_bases=2_100_000)
+        pk = rp.next_batch_packed(max_seqs=1_000_000, max_bases=2_100_000)
+        assert np.array_equal(pk.offsets, o)
+        want = sa.pack_reads(b, o, threads=1)
+        assert np.array_equal(pk.packed, want.packed) and np.array_equal(pk.nmask, want.nmask)
+        assert int(o[-1]) <= 2_100_000
+        got += [b[int(o[i]):int(o[i + 1])].tobytes().decode() for i in range(len(o) - 1)]
+        n_batches += 1
+    assert got == seqs and n_batches >= 3
+    ra.close()
+    rp.close()
