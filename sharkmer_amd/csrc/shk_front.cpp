@@ -31,6 +31,7 @@
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <new>
 
 namespace shk {
 
@@ -142,8 +143,66 @@ using namespace shk;
 // input is known to end cleanly.
 namespace {
 
+// A window's bytes when they are not the mapped file's: a block that is neither zero-filled (std::vector would: 16 MiB
+// per inflated window, a tenth of the inflate thread's time) nor handed back to the allocator after every window (a block
+// this large comes from mmap: thousands of page faults each time) — a few blocks of each size in use are kept for reuse.
 struct Buf {
-  std::vector<uint8_t> v;
+  struct Bytes {
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    void resize(size_t m) {  // (contents are NOT kept: every caller copies what it needs itself)
+      release(p, n);
+      p = acquire(m);
+      n = m;
+    }
+    ~Bytes() { release(p, n); }
+    Bytes() = default;
+    Bytes(const Bytes &) = delete;
+    Bytes &operator=(const Bytes &) = delete;
+  } v;
+
+ private:
+  struct Cache {
+    std::mutex m;
+    std::vector<std::pair<size_t, uint8_t *>> blocks;
+    ~Cache() {
+      for (auto &b : blocks) free(b.second);
+    }
+  };
+  static Cache &cache() {
+    static Cache c;
+    return c;
+  }
+  static uint8_t *acquire(size_t n) {
+    if (!n) return nullptr;
+    {
+      Cache &c = cache();
+      std::lock_guard<std::mutex> lk(c.m);
+      for (size_t i = 0; i < c.blocks.size(); ++i)
+        if (c.blocks[i].first == n) {
+          uint8_t *p = c.blocks[i].second;
+          c.blocks.erase(c.blocks.begin() + (long)i);
+          return p;
+        }
+    }
+    uint8_t *p = (uint8_t *)malloc(n);
+    if (!p) throw std::bad_alloc();
+    return p;
+  }
+  static void release(uint8_t *p, size_t n) {
+    if (!p) return;
+    Cache &c = cache();
+    {
+      std::lock_guard<std::mutex> lk(c.m);
+      if (c.blocks.size() < 12) {
+        c.blocks.emplace_back(n, p);
+        return;
+      }
+    }
+    free(p);
+  }
 };
 struct Window {
   std::shared_ptr<Buf> hold;  // what keeps the bytes alive (null: the producer's mapping)
@@ -302,7 +361,8 @@ struct MappedSource final : Source {  // a regular file, not gzip: slices of the
   MappedSource(const char *d, size_t n) : data(d), size(n) {}
   bool next(Window *w) override {
     if (pos >= size) return false;
-    size_t want = window;
+    // (the first window is a small one: the consumer — and behind it the GPU — has something to do 4 ms sooner)
+    size_t want = pos == 0 ? std::min<size_t>(window, 16u << 20) : window;
     for (;;) {
       const size_t end = size - pos <= want ? size : pos + want;
       if (end == size) {
@@ -367,7 +427,12 @@ struct FdSource final : Source {  // a pipe, stdin, anything that cannot be mapp
         return true;
       }
       cap *= 2;  // a line longer than the buffer
-      b->v.resize(cap);
+      {
+        auto nb = std::make_shared<Buf>();
+        nb->v.resize(cap);
+        memcpy(nb->v.data(), b->v.data(), have);
+        b = std::move(nb);
+      }
     }
   }
   IoError finish(uint32_t, uint64_t) override { return err; }
@@ -1199,10 +1264,15 @@ static int next_batch_impl(shk_fastq *r, uint8_t *bases, uint8_t *packed, uint32
   uint64_t used = 0, n = 0;
   bool stop = false;
   uint64_t first_bad = ~0ull;
+  const bool dbg = getenv("SHK_FASTQ_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_wait = 0, t_sum = 0, t_move = 0;
   while (!stop && n < max_seqs) {
     if (r->n_reads_read == r->limit()) {
       if (r->state == shk_fastq::RUNNING) {
+        const double t0 = now();
         r->scout_more();
+        t_wait += now() - t0;
         continue;
       }
       break;
@@ -1223,6 +1293,7 @@ static int next_batch_impl(shk_fastq *r, uint8_t *bases, uint8_t *packed, uint32
     }
     // how many of them fit, and their offsets: a prefix sum over the lengths — by the copy pool when there are many
     // (a million additions by the caller's thread alone were a third of a batch's time)
+    const double t_s0 = now();
     {
       const uint32_t TS = take >= 65536 ? r->cpool->size() : 1;
       std::vector<uint64_t> part(TS + 1, 0);
@@ -1265,6 +1336,8 @@ static int next_batch_impl(shk_fastq *r, uint8_t *bases, uint8_t *packed, uint32
       n += take;
     }
     if (!take) continue;
+    const double t_m0 = now();
+    t_sum += t_m0 - t_s0;
     const size_t lead = c.has_lead ? 1 : 0;
     // record j of this hand-out (j in [0, take)): where its sequence lies
     auto seq_of = [&](size_t j, const char **p, size_t *len, const char **lim) {
@@ -1322,6 +1395,7 @@ static int next_batch_impl(shk_fastq *r, uint8_t *bases, uint8_t *packed, uint32
       else r->cpool->parallel_for(TT, pack);
       for (uint64_t v : bad) first_bad = std::min(first_bad, v);
     }
+    t_move += now() - t_m0;
     h.next += take;
     r->n_reads_read += take;                    // io.rs:337
     r->n_bases_read += used - offsets[n_begin];  // io.rs:335 (N included)
@@ -1338,6 +1412,9 @@ static int next_batch_impl(shk_fastq *r, uint8_t *bases, uint8_t *packed, uint32
       r->held.clear();
     }
   }
+  if (dbg)
+    fprintf(stderr, "[fastq batch %llu reads, %llu bases] waited for the parse %.1f ms  offsets %.1f ms  %s %.1f ms\n", (unsigned long long)n,
+            (unsigned long long)used, t_wait * 1e3, t_sum * 1e3, packed ? "pack" : "copy", t_move * 1e3);
   *n_seqs = n;
   return SHK_OK;
 }

@@ -288,3 +288,25 @@ def test_record_longer_than_a_parse_window(tmp_path, monkeypatch):
     p = _tmp(tmp_path, "wide.fastq", "".join(f"@r\n{s}\n+\n{'I' * len(s)}\n" for s in seqs))
     bases, offs, _ = read_all([p])
     assert [bases[int(offs[i]):int(offs[i + 1])].tobytes().decode() for i in range(3)] == seqs
+
+
+def test_histo_files_load_the_way_the_viewer_loads_them(orc, tmp_path):
+    """The consumer of the output format: sharkmer_viewer reads a .histo with pandas' read_csv(sep="\\t", comment="#")
+    (sharkmer_viewer.py:117-131: the `#` line is skipped, the header row names the columns, column 0 is the count) and
+    genomescopemovie.sh slices the numeric rows column by column (:37-50)."""
+    pd = pytest.importorskip("pandas")
+    paths = [os.path.join(G, "reads_main.fastq.gz"), os.path.join(G, "reads_part2.fastq")]
+    ref = oracle_read(orc, paths, chunks=3).finish()
+    h = ref.histograms()
+    sa.write_histo(str(tmp_path / "v.histo"), h, 21, 50)
+    sa.write_final_histo(str(tmp_path / "v.final.histo"), h, 21, 50)
+    df = pd.read_csv(tmp_path / "v.histo", sep="\t", comment="#")
+    assert list(df.columns) == ["count", "chunk_1", "chunk_2", "chunk_3"] and len(df) == 51
+    assert list(df["count"]) == list(range(1, 52))
+    for j in range(3):
+        assert np.array_equal(df[f"chunk_{j + 1}"].to_numpy(dtype=np.uint64), h[j, 1:])
+    fin = pd.read_csv(tmp_path / "v.final.histo", sep="\t", comment="#")
+    assert list(fin.columns) == ["count", "frequency"] and np.array_equal(fin["frequency"].to_numpy(dtype=np.uint64), h[2, 1:])
+    # genomescopemovie.sh: the numeric rows, one column at a time, as "count<space>frequency" pairs
+    rows = [ln.split("\t") for ln in (tmp_path / "v.histo").read_text().splitlines() if ln and ln[0].isdigit()]
+    assert len(rows) == 51 and [int(r[0]) for r in rows] == list(range(1, 52)) and [int(r[2]) for r in rows] == list(h[1, 1:])
