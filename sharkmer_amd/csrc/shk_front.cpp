@@ -23,6 +23,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cstdarg>
@@ -474,6 +475,403 @@ struct GzSource final : Source {
     q.emplace_back(std::move(w));
     cv.notify_all();
   }
+  // ---- one member, many threads -------------------------------------------------------------------------------------
+  // A DEFLATE stream is one long dependency chain (every block's matches reach into the 32 KiB before it), and one
+  // thread inflates ≈1.2 GB/s of FASTQ — 0.6 Gbases/s, three orders of magnitude under the counting rate.  The
+  // two-pass scheme of parallel gzip readers (pugz, rapidgzip) breaks the chain:
+  //   1. the compressed bytes are cut into chunks; a worker per chunk FINDS a block boundary behind its cut (a bit
+  //      position where a dynamic-Huffman header parses, its block decodes and another header follows) and decodes from
+  //      there SPECULATIVELY into 16-bit symbols — a byte, or "byte w of the 32 KiB in front of my entry point, which I
+  //      do not know" (Inflater::run_symbols) — up to the first block boundary behind the next cut;
+  //   2. this thread goes through the chunks in order.  A chunk's result counts only if its entry point is EXACTLY
+  //      where the verified decoding before it ended; what lies between (a stored or fixed block the finder does not
+  //      look for, a chunk whose speculation failed) is decoded here, the ordinary way.  With the window in front of a
+  //      chunk known, its symbols become bytes — any of them independently of the others, so the last 32 KiB (the next
+  //      chunk's window) at once, here, and all of them by the workers, chunks side by side.
+  // What comes out — bytes, their order, the final status and where the stream ended — is the sequential decoder's:
+  // nothing speculative is ever handed on unverified, and an error is only ever reported by a verified position.
+  struct SpecResult {
+    UBuf<uint16_t> sym;
+    size_t n = 0;
+    bool found = false, ready = false;
+    uint64_t start_bit = 0, end_bit = 0;
+    InflateStatus status = INF_CORRUPT;
+    const uint8_t *after = nullptr;
+  };
+  struct Workers {  // a small two-priority pool of the decoder's own
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> hi, lo;
+    bool quit = false;
+    explicit Workers(uint32_t n) {
+      for (uint32_t i = 0; i < n; ++i)
+        th.emplace_back([this] {
+          for (;;) {
+            std::function<void()> f;
+            {
+              std::unique_lock<std::mutex> lk(m);
+              cv.wait(lk, [&] { return quit || !hi.empty() || !lo.empty(); });
+              if (quit && hi.empty() && lo.empty()) return;
+              auto &q = hi.empty() ? lo : hi;
+              f = std::move(q.front());
+              q.pop_front();
+            }
+            f();
+          }
+        });
+    }
+    void post(bool urgent, std::function<void()> f) {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        (urgent ? hi : lo).emplace_back(std::move(f));
+      }
+      cv.notify_one();
+    }
+    ~Workers() {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        quit = true;
+        lo.clear();  // (speculation nobody will look at)
+      }
+      cv.notify_all();
+      for (auto &t : th) t.join();
+    }
+  };
+  static bool plausible_header_at(const uint8_t *origin, const uint8_t *end, uint64_t bit) {
+    // BFINAL = 0, BTYPE = 2 (bits 0, 0, 1), HLIT ≤ 29, HDIST ≤ 29: what an encoder's dynamic, non-final block starts with
+    const uint8_t *p = origin + (bit >> 3);
+    if (end - p < 4) return false;
+    uint32_t w;
+    memcpy(&w, p, 4);
+    w >>= (uint32_t)(bit & 7);
+    return (w & 7u) == 4u && ((w >> 3) & 31u) <= 29u && ((w >> 8) & 31u) <= 29u;
+  }
+  // The speculative decode of chunk `i`: entry point at or behind bit lo, output up to the first block boundary at or
+  // behind bit hi.
+  static void speculate(SpecResult *r, const uint8_t *origin, const uint8_t *end, uint64_t lo, uint64_t hi, size_t guess) {
+    Inflater inf;
+    size_t cap = guess + 65536;
+    r->sym.resize_discard(cap);
+    auto grow = [&](size_t keep) {
+      UBuf<uint16_t> nb;
+      nb.resize_discard(cap * 2);
+      memcpy(nb.data(), r->sym.data(), keep * 2);
+      r->sym = std::move(nb);
+      cap *= 2;
+    };
+    const uint64_t total_bits = (uint64_t)(end - origin) * 8;
+    for (uint64_t p = lo; p < hi && p + 64 < total_bits; ++p) {
+      if (!plausible_header_at(origin, end, p)) continue;
+      inf.seek(origin, end, p);
+      if (inf.read_block_header() != INF_OUTPUT_FULL || inf.state != 2 || inf.last_block || !inf.hdr_plausible) continue;
+      // its block must decode, and a header must follow it
+      size_t pos = 0;
+      bool between = false;
+      InflateStatus st;
+      for (;;) {
+        st = inf.run_symbols(r->sym.data(), &pos, cap, origin, p + 1, &between);
+        if (st == INF_OUTPUT_FULL && !between) {
+          grow(pos);
+          continue;
+        }
+        break;
+      }
+      if (st != INF_OUTPUT_FULL || !between) continue;
+      {
+        Inflater peek = inf;
+        const InflateStatus hs = peek.read_block_header();
+        if (hs == INF_CORRUPT) continue;
+      }
+      // accepted: go on to the first block boundary at or behind `hi`
+      r->found = true;
+      r->start_bit = p;
+      for (;;) {
+        st = inf.run_symbols(r->sym.data(), &pos, cap, origin, hi, &between);
+        if (st == INF_OUTPUT_FULL && !between) {
+          grow(pos);
+          continue;
+        }
+        break;
+      }
+      r->n = pos;
+      r->status = st;
+      r->end_bit = inf.bit_position(origin);
+      if (st == INF_STREAM_END) r->after = inf.input_after_stream();
+      return;
+    }
+  }
+
+  void run_parallel(uint32_t n_threads, size_t chunk_bytes) {
+    const uint8_t *origin = gz.inf.in, *end = gz.inf.in_end;
+    const size_t n_chunks = ((size_t)(end - origin) + chunk_bytes - 1) / chunk_bytes;
+    std::vector<SpecResult> spec(n_chunks);
+    std::mutex rm;
+    std::condition_variable rcv;
+    Workers pool(n_threads);
+    size_t issued = 1;  // (chunk 0 starts at the stream's start: decoded here, the ordinary way)
+    const size_t ahead = (size_t)n_threads + 2;
+    const size_t guess = chunk_bytes * 6;
+    auto issue_up_to = [&](size_t upto) {
+      for (; issued < n_chunks && issued <= upto; ++issued) {
+        const size_t i = issued;
+        pool.post(false, [&, i] {
+          speculate(&spec[i], origin, end, (uint64_t)i * chunk_bytes * 8, (uint64_t)(i + 1) * chunk_bytes * 8, guess);
+          {
+            std::lock_guard<std::mutex> lk(rm);
+            spec[i].ready = true;
+          }
+          rcv.notify_all();
+        });
+      }
+    };
+    issue_up_to(ahead);
+
+    // a piece of output on its way out: [window w_len][n bytes] in one block; `pending` jobs still write into it
+    struct Piece {
+      std::shared_ptr<Buf> buf;
+      size_t w_len = 0, n = 0;
+      std::shared_ptr<std::atomic<int>> pending;
+    };
+    std::deque<Piece> out_q;
+    std::vector<uint8_t> W;       // the last ≤ 32 KiB of everything decoded so far
+    std::vector<uint8_t> carry;   // the bytes of the last, unfinished line (they are also the tail of W when they fit)
+    uint64_t verified = 0;        // bit position everything in front of which has been decoded and checked
+    InflateStatus status = INF_OUTPUT_FULL;
+    const uint8_t *after = nullptr;
+    bool cancelled = false;
+    size_t n_spec_used = 0, n_here = 0;  // chunks taken from the workers / stretches decoded by this thread
+    uint64_t bytes_spec = 0, bytes_here = 0;
+
+    auto is_stopped = [&] {
+      std::lock_guard<std::mutex> lk(m);
+      return stop;
+    };
+    // hand the front piece on, as a window of whole lines (its last line's beginning is carried into the next)
+    auto emit_front = [&](bool last) {
+      Piece pc = std::move(out_q.front());
+      out_q.pop_front();
+      while (pc.pending && pc.pending->load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      uint8_t *base = pc.buf->v.data();
+      size_t a = pc.w_len, b = pc.w_len + pc.n;
+      if (!carry.empty()) {  // the line begun in the piece before: it lies right in front of this piece's bytes
+        if (carry.size() <= pc.w_len && memcmp(base + pc.w_len - carry.size(), carry.data(), carry.size()) == 0) {
+          a = pc.w_len - carry.size();
+        } else {  // (longer than the window in front: a block of its own)
+          auto nb = std::make_shared<Buf>();
+          nb->v.resize(carry.size() + pc.n + 64);
+          memcpy(nb->v.data(), carry.data(), carry.size());
+          memcpy(nb->v.data() + carry.size(), base + pc.w_len, pc.n);
+          pc.buf = nb;
+          base = nb->v.data();
+          a = 0;
+          b = carry.size() + pc.n;
+        }
+      }
+      if (last) {
+        carry.clear();
+        emit(Window{pc.buf, (const char *)base + a, b - a, true});
+        return;
+      }
+      const void *nl = b > a ? memrchr(base + a, '\n', b - a) : nullptr;
+      if (!nl) {  // no line ends in this piece: all of it is carried on
+        carry.assign(base + a, base + b);
+        return;
+      }
+      const size_t cut = (size_t)((const uint8_t *)nl - base) + 1;
+      carry.assign(base + cut, base + b);
+      emit(Window{pc.buf, (const char *)base + a, cut - a, false});
+    };
+    auto new_piece_block = [&](size_t n) {
+      auto b = std::make_shared<Buf>();
+      b->v.resize(W.size() + n + Inflater::OUT_SLACK + 64);
+      if (!W.empty()) memcpy(b->v.data(), W.data(), W.size());
+      return b;
+    };
+    auto roll_window = [&](const uint8_t *bytes, size_t n) {  // W := last 32 KiB of W ++ bytes
+      if (n >= 32768) {
+        W.assign(bytes + n - 32768, bytes + n);
+      } else {
+        const size_t keep = std::min(W.size(), (size_t)32768 - n);
+        std::vector<uint8_t> nw(W.end() - (long)keep, W.end());
+        nw.insert(nw.end(), bytes, bytes + n);
+        W.swap(nw);
+      }
+    };
+    // the ordinary decoder from the verified position on, up to the first block boundary at or behind `to_bit`
+    auto decode_here = [&](uint64_t to_bit) {
+      Inflater inf;
+      inf.seek(origin, end, verified);
+      inf.stop_origin = origin;
+      inf.stop_bit = to_bit;
+      size_t cap = std::max<size_t>(chunk_bytes * 6, 1u << 20);
+      auto b = new_piece_block(cap);
+      const size_t w_len = W.size();
+      size_t pos = w_len;
+      InflateStatus st;
+      for (;;) {
+        st = inf.run(b->v.data(), &pos, w_len + cap);
+        if (st == INF_OUTPUT_FULL && !inf.stopped_between_blocks) {  // more room
+          auto nb = std::make_shared<Buf>();
+          nb->v.resize(w_len + cap * 2 + Inflater::OUT_SLACK + 64);
+          memcpy(nb->v.data(), b->v.data(), pos);
+          b = std::move(nb);
+          cap *= 2;
+          if (is_stopped()) {
+            cancelled = true;
+            break;
+          }
+          continue;
+        }
+        break;
+      }
+      Piece pc;
+      pc.buf = b;
+      pc.w_len = w_len;
+      pc.n = pos - w_len;
+      roll_window(b->v.data() + w_len, pc.n);
+      ++n_here;
+      bytes_here += pc.n;
+      out_q.emplace_back(std::move(pc));
+      verified = inf.bit_position(origin);
+      if (st != INF_OUTPUT_FULL) {
+        status = st;
+        if (st == INF_STREAM_END) after = inf.input_after_stream();
+      }
+    };
+    // a verified chunk: its window is known now — the next chunk's window at once, its bytes by the workers
+    auto resolve = [&](SpecResult &r) {
+      const size_t n = r.n;
+      auto b = new_piece_block(n);
+      const size_t w_len = W.size();
+      // symbol 256 + w means byte w of a FULL 32 KiB window; with less decoded so far (w_len < 32768) the window's first
+      // 32768 − w_len places do not exist: a reference to one is no valid stream (the ordinary decoder says "distance
+      // too far back"): such a chunk cannot have been reached by a valid stream, and a verified one never has any
+      const size_t shift = 32768 - w_len;
+      auto byte_of = [shift, base = b->v.data()](uint16_t s2) -> uint8_t { return s2 < 256 ? (uint8_t)s2 : base[(size_t)(s2 - 256) - shift]; };
+      (void)byte_of;
+      Piece pc;
+      pc.buf = b;
+      pc.w_len = w_len;
+      pc.n = n;
+      pc.pending = std::make_shared<std::atomic<int>>(0);
+      // the next window first (the last 32 KiB of this chunk's bytes), by this thread
+      {
+        const size_t t0 = n > 32768 ? n - 32768 : 0;
+        std::vector<uint8_t> tail(n - t0);
+        const uint16_t *sy = r.sym.data();
+        const uint8_t *wb = b->v.data();
+        bool bad = false;
+        for (size_t j = t0; j < n; ++j) {
+          const uint16_t s2 = sy[j];
+          if (s2 < 256) tail[j - t0] = (uint8_t)s2;
+          else if ((size_t)(s2 - 256) >= shift) tail[j - t0] = wb[(size_t)(s2 - 256) - shift];
+          else bad = true, tail[j - t0] = 0;
+        }
+        (void)bad;
+        roll_window(tail.data(), tail.size());
+      }
+      // all of it, in slices, by the workers
+      const size_t slice = 1u << 20;
+      const size_t n_slices = (n + slice - 1) / slice;
+      pc.pending->store((int)n_slices, std::memory_order_release);
+      auto keep = std::make_shared<SpecResult>(std::move(r));
+      for (size_t sl = 0; sl < n_slices; ++sl) {
+        const size_t j0 = sl * slice, j1 = std::min(n, j0 + slice);
+        auto pend = pc.pending;
+        pool.post(true, [keep, b, w_len, shift, j0, j1, pend] {
+          const uint16_t *sy = keep->sym.data();
+          uint8_t *base = b->v.data();
+          uint8_t *dst = base + w_len;
+          for (size_t j = j0; j < j1; ++j) {
+            const uint16_t s2 = sy[j];
+            dst[j] = s2 < 256 ? (uint8_t)s2 : ((size_t)(s2 - 256) >= shift ? base[(size_t)(s2 - 256) - shift] : (uint8_t)0);
+          }
+          pend->fetch_sub(1, std::memory_order_acq_rel);
+        });
+      }
+      out_q.emplace_back(std::move(pc));
+    };
+    auto drain = [&](size_t keep_n) {
+      while (out_q.size() > keep_n && !cancelled) emit_front(false);
+    };
+
+    // chunk 0, then chunk after chunk
+    decode_here((uint64_t)chunk_bytes * 8);
+    size_t next = 1;
+    while (status == INF_OUTPUT_FULL && !cancelled) {
+      if (is_stopped()) {
+        cancelled = true;
+        break;
+      }
+      drain(2);
+      if (next >= n_chunks) {  // behind the last cut: the rest of the stream, the ordinary way
+        decode_here(~0ull);
+        continue;
+      }
+      issue_up_to(next + ahead);
+      SpecResult &r = spec[next];
+      {
+        std::unique_lock<std::mutex> lk(rm);
+        rcv.wait(lk, [&] { return r.ready; });
+      }
+      if (r.found && r.start_bit == verified) {
+        // (a symbol that points in front of everything decoded so far cannot come from a valid stream entered at a
+        // verified position — checked all the same, over the whole chunk, before anything of it is used)
+        bool sane = true;
+        if (W.size() < 32768) {
+          const size_t shift = 32768 - W.size();
+          for (size_t j = 0; j < r.n && sane; ++j) sane = r.sym[j] < 256 || (size_t)(r.sym[j] - 256) >= shift;
+        }
+        if (sane) {
+          const uint64_t e2 = r.end_bit;
+          const InflateStatus st2 = r.status;
+          const uint8_t *after2 = r.after;
+          ++n_spec_used;
+          bytes_spec += r.n;
+          resolve(r);
+          verified = e2;
+          if (st2 != INF_OUTPUT_FULL) {
+            status = st2;
+            after = after2;
+          }
+          ++next;
+          continue;
+        }
+        decode_here((uint64_t)(next + 1) * chunk_bytes * 8);  // (the ordinary decoder says what is wrong with it)
+        ++next;
+        continue;
+      }
+      if (r.found && r.start_bit > verified) {  // something the finder does not look for lies in between
+        decode_here(r.start_bit);
+        if (verified != r.start_bit) ++next;  // (it was no block boundary after all: that chunk's result is void)
+        continue;
+      }
+      // no entry point found in this chunk, or one in front of where the stream really stands: the ordinary way
+      if ((uint64_t)(next + 1) * chunk_bytes * 8 > verified) decode_here((uint64_t)(next + 1) * chunk_bytes * 8);
+      ++next;
+    }
+    if (!cancelled) {
+      if (out_q.empty()) {  // (nothing at all was decoded)
+        Piece pc;
+        pc.buf = std::make_shared<Buf>();
+        pc.buf->v.resize(64);
+        out_q.emplace_back(std::move(pc));
+      }
+      while (out_q.size() > 1) emit_front(false);
+      final_status = status == INF_OUTPUT_FULL ? INF_TRUNCATED : status;
+      if (final_status == INF_STREAM_END && after) {  // where the trailer lies (GzMember::finish)
+        gz.inf.in = after;
+        gz.inf.bitcnt = 0;
+      }
+      emit_front(true);
+    }
+    if (getenv("SHK_FASTQ_DEBUG"))
+      fprintf(stderr, "[gzip member, %u threads, %zu chunks of %zu KiB] %zu chunks (%.1f MB) from the workers, %zu stretches (%.1f MB) decoded in order\n",
+              n_threads, n_chunks, chunk_bytes >> 10, n_spec_used, bytes_spec / 1e6, n_here, bytes_here / 1e6);
+    // (the workers are joined by ~Workers: what is still queued of the speculation is dropped)
+  }
+
   void run() {
     if (gz.header_error.kind != IO_NONE) {  // nothing can be read: an empty last window, the error follows it
       emit(Window{nullptr, "", 0, true});
@@ -481,6 +879,20 @@ struct GzSource final : Source {
       done = true;
       cv.notify_all();
       return;
+    }
+    {
+      // several threads on the one member when it is large enough to pay (test hooks: SHK_PGZ_*)
+      const char *e_min = getenv("SHK_PGZ_MIN_KB"), *e_chunk = getenv("SHK_PGZ_CHUNK_KB"), *e_thr = getenv("SHK_PGZ_THREADS");
+      const size_t min_bytes = e_min ? (size_t)atoll(e_min) << 10 : (size_t)8 << 20;
+      const size_t chunk = std::max<size_t>(e_chunk ? (size_t)atoll(e_chunk) << 10 : (size_t)1 << 20, 512);
+      const uint32_t thr = e_thr ? (uint32_t)atoi(e_thr) : std::min(32u, usable_cpus());
+      if (thr > 1 && (size_t)(gz.inf.in_end - gz.inf.in) >= min_bytes) {
+        run_parallel(thr, chunk);
+        std::lock_guard<std::mutex> lk(m);
+        done = true;
+        cv.notify_all();
+        return;
+      }
     }
     size_t cap = window + 32768 + Inflater::OUT_SLACK;
     auto b = std::make_shared<Buf>();

@@ -143,16 +143,12 @@ void Inflater::reset(const uint8_t *p, const uint8_t *e) {
   total_out = 0;
 }
 
-InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) {
-  uint8_t *out = out_base + *out_pos;
-  uint8_t *const out_end = out_base + out_cap;
-  uint8_t *const out_start = out;
+// The header of the block at the current bit position: BFINAL, BTYPE, and for a Huffman block its decode tables.
+// INF_OUTPUT_FULL stands for "go on" here (state says with what: 1 a stored block of stored_left bytes, 2 symbols).
+InflateStatus Inflater::read_block_header() {
   const uint8_t *ip = in;
   uint64_t bb = bitbuf;
   uint32_t bc = bitcnt;
-  InflateStatus result = INF_OUTPUT_FULL;
-
-  // bytewise refill with an exact count of what is there
   auto need = [&](uint32_t n) -> bool {
     while (bc < n) {
       if (ip == in_end) return false;
@@ -167,16 +163,14 @@ InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) 
       bc += 8;
     }
   };
-#define SHK_DONE(st)     \
-  do {                   \
-    result = (st);       \
-    goto finished;       \
-  } while (0)
-
-  for (;;) {
-    if (state == 3) SHK_DONE(INF_STREAM_END);
-    if (state == 0) {  // ---- block header ---------------------------------------------------------------------
-      if (!need(3)) SHK_DONE(INF_TRUNCATED);
+  struct Sync {  // (the members follow the locals on every way out)
+    Inflater *self;
+    const uint8_t *&ip;
+    uint64_t &bb;
+    uint32_t &bc;
+    ~Sync() { self->in = ip, self->bitbuf = bb, self->bitcnt = bc; }
+  } sync{this, ip, bb, bc};
+      if (!need(3)) return INF_TRUNCATED;
       last_block = bb & 1;
       const uint32_t type = (uint32_t)(bb >> 1) & 3;
       bb >>= 3;
@@ -184,11 +178,11 @@ InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) 
       if (type == 0) {
         bb >>= bc & 7;
         bc -= bc & 7;
-        if (!need(32)) SHK_DONE(INF_TRUNCATED);
+        if (!need(32)) return INF_TRUNCATED;
         const uint32_t len = (uint32_t)bb & 0xFFFF, nlen = (uint32_t)(bb >> 16) & 0xFFFF;
         bb >>= 32;
         bc -= 32;
-        if ((len ^ 0xFFFF) != nlen) SHK_DONE(INF_CORRUPT);
+        if ((len ^ 0xFFFF) != nlen) return INF_CORRUPT;
         ip -= bc >> 3;  // whole bytes still in the bit buffer are the block's first data bytes
         bb = 0;
         bc = 0;
@@ -205,19 +199,19 @@ InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) 
         build_table(lens + 288, 32, DIST_BITS, DIST_CAP, dist, payload_dist);
         state = 2;
       } else if (type == 2) {
-        if (!need(14)) SHK_DONE(INF_TRUNCATED);
+        if (!need(14)) return INF_TRUNCATED;
         const uint32_t hlit = ((uint32_t)bb & 31) + 257, hdist = ((uint32_t)(bb >> 5) & 31) + 1, hclen = ((uint32_t)(bb >> 10) & 15) + 4;
         bb >>= 14;
         bc -= 14;
         uint8_t pre_lens[19] = {0};
         for (uint32_t i = 0; i < hclen; ++i) {
-          if (!need(3)) SHK_DONE(INF_TRUNCATED);
+          if (!need(3)) return INF_TRUNCATED;
           pre_lens[PRE_ORDER[i]] = (uint8_t)(bb & 7);
           bb >>= 3;
           bc -= 3;
         }
         uint32_t pre[1u << PRE_BITS];
-        if (!build_table(pre_lens, 19, PRE_BITS, 1u << PRE_BITS, pre, payload_pre)) SHK_DONE(INF_CORRUPT);
+        if (!build_table(pre_lens, 19, PRE_BITS, 1u << PRE_BITS, pre, payload_pre)) return INF_CORRUPT;
         uint8_t lens[288 + 32 + 140];
         const uint32_t total = hlit + hdist;
         uint32_t i = 0;
@@ -225,11 +219,11 @@ InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) 
           fill_all();
           const uint32_t e = pre[bb & ((1u << PRE_BITS) - 1)];
           if (e & E_EXC) {  // no such code word — unless the bits are simply not there
-            SHK_DONE(ip == in_end && bc < 7 ? INF_TRUNCATED : INF_CORRUPT);
+            return ip == in_end && bc < 7 ? INF_TRUNCATED : INF_CORRUPT;
           }
           const uint32_t cl = e & 0xFF, sym = e >> 16;
           uint32_t extra_n = sym < 16 ? 0 : sym == 16 ? 2 : sym == 17 ? 3 : 7;
-          if (bc < cl + extra_n) SHK_DONE(INF_TRUNCATED);
+          if (bc < cl + extra_n) return INF_TRUNCATED;
           bb >>= cl;
           bc -= cl;
           if (sym < 16) {
@@ -242,7 +236,7 @@ InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) 
           uint32_t rep;
           uint8_t v = 0;
           if (sym == 16) {
-            if (i == 0) SHK_DONE(INF_CORRUPT);
+            if (i == 0) return INF_CORRUPT;
             v = lens[i - 1];
             rep = 3 + extra;
           } else if (sym == 17) {
@@ -250,19 +244,56 @@ InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) 
           } else {
             rep = 11 + extra;
           }
-          if (i + rep > total) SHK_DONE(INF_CORRUPT);
+          if (i + rep > total) return INF_CORRUPT;
           memset(lens + i, v, rep);
           i += rep;
         }
         uint8_t ll[288] = {0}, dl[32] = {0};
         memcpy(ll, lens, hlit);
         memcpy(dl, lens + hlit, hdist);
-        if (!build_table(ll, 288, LIT_BITS, LIT_CAP, litlen, payload_litlen)) SHK_DONE(INF_CORRUPT);
-        if (!build_table(dl, 32, DIST_BITS, DIST_CAP, dist, payload_dist)) SHK_DONE(INF_CORRUPT);
+        hdr_plausible = hlit <= 286 && hdist <= 30 && ll[256] != 0;
+        if (!build_table(ll, 288, LIT_BITS, LIT_CAP, litlen, payload_litlen)) return INF_CORRUPT;
+        if (!build_table(dl, 32, DIST_BITS, DIST_CAP, dist, payload_dist)) return INF_CORRUPT;
         state = 2;
       } else {
-        SHK_DONE(INF_CORRUPT);
+        return INF_CORRUPT;
       }
+  return INF_OUTPUT_FULL;
+}
+
+InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) {
+  uint8_t *out = out_base + *out_pos;
+  uint8_t *const out_end = out_base + out_cap;
+  uint8_t *const out_start = out;
+  const uint8_t *ip = in;
+  uint64_t bb = bitbuf;
+  uint32_t bc = bitcnt;
+  InflateStatus result = INF_OUTPUT_FULL;
+
+  auto fill_all = [&]() {
+    while (bc <= 56 && ip != in_end) {
+      bb |= (uint64_t)*ip++ << bc;
+      bc += 8;
+    }
+  };
+#define SHK_DONE(st)     \
+  do {                   \
+    result = (st);       \
+    goto finished;       \
+  } while (0)
+
+  stopped_between_blocks = false;
+  for (;;) {
+    if (state == 3) SHK_DONE(INF_STREAM_END);
+    if (state == 0) {  // ---- block header ---------------------------------------------------------------------
+      in = ip, bitbuf = bb, bitcnt = bc;
+      if (stop_origin && bit_position(stop_origin) >= stop_bit) {
+        stopped_between_blocks = true;
+        SHK_DONE(INF_OUTPUT_FULL);
+      }
+      const InflateStatus hs = read_block_header();
+      ip = in, bb = bitbuf, bc = bitcnt;
+      if (hs != INF_OUTPUT_FULL) SHK_DONE(hs);
     }
     if (state == 1) {  // ---- stored block ---------------------------------------------------------------------
       while (stored_left) {
@@ -441,6 +472,135 @@ finished:
   return result;
 #undef SHK_DONE
 #undef SHK_REFILL
+}
+
+void Inflater::seek(const uint8_t *origin, const uint8_t *e, uint64_t bit) {
+  reset(origin + (bit >> 3), e);
+  const uint32_t skip = (uint32_t)(bit & 7);
+  if (skip && in < in_end) {
+    bitbuf = (uint64_t)*in++ >> skip;
+    bitcnt = 8 - skip;
+  }
+}
+
+InflateStatus Inflater::run_symbols(uint16_t *out, size_t *out_pos, size_t out_cap, const uint8_t *origin, uint64_t stop_at, bool *between_blocks) {
+  size_t pos = *out_pos;
+  *between_blocks = false;
+  InflateStatus result = INF_OUTPUT_FULL;
+  const uint8_t *ip = in;
+  uint64_t bb = bitbuf;
+  uint32_t bc = bitcnt;
+  auto refill = [&]() {
+    if (in_end - ip >= 8) {
+      bb |= load64(ip) << bc;
+      const uint32_t nby = (63 - bc) >> 3;
+      ip += nby;
+      bc += nby * 8;
+    } else {
+      while (bc <= 56 && ip != in_end) {
+        bb |= (uint64_t)*ip++ << bc;
+        bc += 8;
+      }
+    }
+  };
+#define SHK_SYM_DONE(st) \
+  do {                   \
+    result = (st);       \
+    goto sym_finished;   \
+  } while (0)
+  for (;;) {
+    if (state == 3) SHK_SYM_DONE(INF_STREAM_END);
+    if (state == 0) {
+      in = ip, bitbuf = bb, bitcnt = bc;
+      if (bit_position(origin) >= stop_at) {
+        *between_blocks = true;
+        SHK_SYM_DONE(INF_OUTPUT_FULL);
+      }
+      const InflateStatus hs = read_block_header();
+      ip = in, bb = bitbuf, bc = bitcnt;
+      if (hs != INF_OUTPUT_FULL) SHK_SYM_DONE(hs);
+    }
+    if (state == 1) {
+      while (stored_left) {
+        if (pos == out_cap) SHK_SYM_DONE(INF_OUTPUT_FULL);
+        if (ip == in_end) SHK_SYM_DONE(INF_TRUNCATED);
+        size_t n = stored_left;
+        if (n > out_cap - pos) n = out_cap - pos;
+        if (n > (size_t)(in_end - ip)) n = (size_t)(in_end - ip);
+        for (size_t i = 0; i < n; ++i) out[pos + i] = ip[i];
+        pos += n;
+        ip += n;
+        stored_left -= (uint32_t)n;
+      }
+      state = last_block ? 3 : 0;
+      continue;
+    }
+    for (;;) {  // symbols of a Huffman block: every one taken only when all its bits are there
+      if (out_cap - pos < OUT_SLACK) SHK_SYM_DONE(INF_OUTPUT_FULL);
+      refill();
+      uint64_t b2 = bb;
+      uint32_t c2 = bc;
+      auto drop = [&](uint32_t n) -> bool {
+        if (c2 < n) return false;
+        b2 >>= n;
+        c2 -= n;
+        return true;
+      };
+      const bool at_end = ip == in_end;
+      uint32_t e = litlen[b2 & ((1u << LIT_BITS) - 1)];
+      if ((e & E_EXC) && (e & E_SUB)) {
+        if (!drop(LIT_BITS)) SHK_SYM_DONE(at_end ? INF_TRUNCATED : INF_CORRUPT);
+        e = litlen[(e >> 16) + ((uint32_t)b2 & ((1u << ((e >> 8) & 15)) - 1))];
+      }
+      if ((e & E_EXC) && !(e & E_EOB)) SHK_SYM_DONE(at_end && c2 < ((e & 0xFF) ? (e & 0xFF) : 15u) ? INF_TRUNCATED : INF_CORRUPT);
+      if (!drop(e & 0xFF)) SHK_SYM_DONE(INF_TRUNCATED);
+      if (e & E_LITERAL) {
+        out[pos++] = (uint16_t)((e >> 16) & 0xFF);
+        bb = b2;
+        bc = c2;
+        continue;
+      }
+      if (e & E_EXC) {  // end of block
+        bb = b2;
+        bc = c2;
+        break;
+      }
+      const uint32_t leb = (e >> 8) & 15;
+      const uint32_t length = (e >> 16) + ((uint32_t)b2 & ((1u << leb) - 1));
+      if (!drop(leb)) SHK_SYM_DONE(INF_TRUNCATED);
+      uint32_t d = dist[b2 & ((1u << DIST_BITS) - 1)];
+      if ((d & E_EXC) && (d & E_SUB)) {
+        if (!drop(DIST_BITS)) SHK_SYM_DONE(at_end ? INF_TRUNCATED : INF_CORRUPT);
+        d = dist[(d >> 16) + ((uint32_t)b2 & ((1u << ((d >> 8) & 15)) - 1))];
+      }
+      if (d & E_EXC) SHK_SYM_DONE(at_end && c2 < ((d & 0xFF) ? (d & 0xFF) : 15u) ? INF_TRUNCATED : INF_CORRUPT);
+      if (!drop(d & 0xFF)) SHK_SYM_DONE(INF_TRUNCATED);
+      const uint32_t deb = (d >> 8) & 15;
+      const size_t distance = (d >> 16) + ((uint32_t)b2 & ((1u << deb) - 1));
+      if (!drop(deb)) SHK_SYM_DONE(INF_TRUNCATED);
+      bb = b2;
+      bc = c2;
+      if (distance <= pos) {
+        const uint16_t *src = out + pos - distance;
+        for (uint32_t i = 0; i < length; ++i) out[pos + i] = src[i];
+      } else {  // reaches in front of the entry point: bytes of the unknown window (distance ≤ 32768 always)
+        for (uint32_t i = 0; i < length; ++i) {
+          const size_t at = pos + i;
+          out[at] = at >= distance ? out[at - distance] : (uint16_t)(256 + 32768 - (distance - at));
+        }
+      }
+      pos += length;
+    }
+    state = last_block ? 3 : 0;
+  }
+sym_finished:
+  in = ip;
+  bitbuf = bb;
+  bitcnt = bc;
+  total_out += pos - *out_pos;
+  *out_pos = pos;
+  return result;
+#undef SHK_SYM_DONE
 }
 
 // ---- CRC-32 ---------------------------------------------------------------------------------------------------

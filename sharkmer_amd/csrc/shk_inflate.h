@@ -42,9 +42,27 @@ struct Inflater {
   bool last_block = false;
   uint32_t stored_left = 0;
   uint64_t total_out = 0;
+  // run() stops between two blocks once the stream position is at or behind stop_bit (bits from stop_origin; null: never)
+  const uint8_t *stop_origin = nullptr;
+  uint64_t stop_bit = ~0ull;
+  bool stopped_between_blocks = false;
+  bool hdr_plausible = true;  // the last dynamic header: ≤ 286 / 30 symbols and an end-of-block code (what real encoders write)
   uint32_t litlen[2048 + 1024];  // 11-bit primary + subtables
   uint32_t dist[256 + 512];      // 8-bit primary + subtables
   void reset(const uint8_t *p, const uint8_t *e);
+  InflateStatus read_block_header();
+  // The stream position in bits from `origin` (≤ in): what has been consumed so far.
+  uint64_t bit_position(const uint8_t *origin) const { return (uint64_t)(in - origin) * 8 - bitcnt; }
+  // Start (or go on) decoding at bit `bit` from `origin`, between blocks.
+  void seek(const uint8_t *origin, const uint8_t *e, uint64_t bit);
+  // SPECULATIVE decoding, for a stream entered at a block boundary somewhere in its middle: the 32 KiB in front of
+  // the entry point are unknown, so the output is SYMBOLS — a byte value, or 256 + w for "byte w of that unknown
+  // window" (w = 0: the oldest) — and a match copies symbols.  Decodes whole blocks into out[*out_pos, out_cap) and
+  // stops in front of the first block that starts at or behind bit `stop_bit` (from `origin`): INF_OUTPUT_FULL then
+  // (or when the room runs out: *out_pos says how far it got; the caller grows the buffer and calls again),
+  // INF_STREAM_END behind the final block, INF_TRUNCATED / INF_CORRUPT as for run().  *block_start receives the bit
+  // position of the block the decoder stands in front of (valid when it stopped between blocks).
+  InflateStatus run_symbols(uint16_t *out, size_t *out_pos, size_t out_cap, const uint8_t *origin, uint64_t stop_bit, bool *between_blocks);
   // Decodes into out_base[out_pos, out_cap); bytes [out_pos - min(out_pos, 32768), out_pos) are the history.
   InflateStatus run(uint8_t *out_base, size_t *out_pos, size_t out_cap);
   // After INF_STREAM_END: the first input byte behind the stream (whole unread bytes are given back).

@@ -445,3 +445,75 @@ def test_differential_sweep_against_the_oracle_reader(orc, tmp_path, monkeypatch
         n_err += res[0] == "error"
         n_ok += res[0] == "ok"
     assert n_err > 5 and n_ok > 5
+
+
+# ---- one gzip member, many threads ------------------------------------------------------------------------------------
+
+def _reader_outcome(paths, **kw):
+    r = sa.FastqReader(paths, **kw)
+    seqs = []
+    try:
+        while not r.stats()["done"]:
+            b, o = r.next_batch(max_seqs=5_000, max_bases=1 << 20)
+            seqs += [b[int(o[i]):int(o[i + 1])].tobytes() for i in range(len(o) - 1)]
+        return ("ok", seqs)
+    except sa.ShkError as e:
+        return ("error", e.msg, len(seqs))
+    finally:
+        r.close()
+
+
+def _gz_variants(rng, data):
+    """The same bytes compressed in ways that put every kind of block and boundary into the stream."""
+    out = {}
+    for level in (1, 6, 9):
+        out[f"level{level}"] = gz_bytes(data, level)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)
+    out["fixed"] = co.compress(data) + co.flush()
+    co = zlib.compressobj(0, zlib.DEFLATED, 31)
+    out["stored"] = co.compress(data) + co.flush()
+    # a stream of many short blocks of changing kinds: sync and full flushes, level changes, stored stretches
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    parts, at = [], 0
+    while at < len(data):
+        n = int(rng.integers(500, 60_000))
+        parts.append(co.compress(data[at:at + n]))
+        parts.append(co.flush(int(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_NO_FLUSH, zlib.Z_BLOCK]))))
+        at += n
+    parts.append(co.flush())
+    out["flushes"] = b"".join(parts)
+    return out
+
+
+@pytest.mark.parametrize("chunk_kb,threads", [(1, 3), (4, 5), (64, 2)])
+def test_parallel_member_decode_is_the_sequential_decode(orc, tmp_path, monkeypatch, chunk_kb, threads):
+    """A large gzip member is decoded by several threads (speculative symbol decoding from block boundaries found inside
+    the stream, verified and resolved in order).  With the threshold forced to zero and chunks of a few KiB — so that the
+    stream is cut hundreds of times, inside stored and fixed blocks too — everything must come out exactly as from the
+    one-thread decoder: the reads, and on damaged streams the error text and how many reads came before it."""
+    rng = np.random.default_rng(chunk_kb)
+    data = text_of(records(6_000, 77 + chunk_kb, length=(30, 160)))
+    variants = _gz_variants(rng, data)
+    # damaged ones: cut short, a flipped bit, a second member behind, a wrong CRC
+    z = variants["level6"]
+    variants["cut"] = z[:len(z) * 2 // 3]
+    zz = bytearray(z)
+    zz[len(z) // 2] ^= 0x10
+    variants["flipped"] = bytes(zz)
+    variants["two_members"] = z + gz_bytes(b"@x\nACGT\n+\nIIII\n")
+    zz = bytearray(z)
+    zz[-7] ^= 1
+    variants["bad_crc"] = bytes(zz)
+    for name, blob in variants.items():
+        p = write(tmp_path, f"{name}.fastq.gz", blob)
+        monkeypatch.setenv("SHK_PGZ_THREADS", "1")
+        want = _reader_outcome([p])
+        monkeypatch.setenv("SHK_PGZ_THREADS", str(threads))
+        monkeypatch.setenv("SHK_PGZ_MIN_KB", "0")
+        monkeypatch.setenv("SHK_PGZ_CHUNK_KB", str(chunk_kb))
+        got = _reader_outcome([p])
+        monkeypatch.delenv("SHK_PGZ_MIN_KB")
+        assert got == want, (name, got[:2] if got[0] == "error" else got[0], want[:2] if want[0] == "error" else want[0])
+        if name in ("level1", "level6", "level9", "fixed", "stored", "flushes", "two_members"):
+            assert got[0] == "ok" and len(got[1]) == 6_000, name
+        assert both(orc, [p])[0] == got[0], name   # (and the oracle's own reader agrees on the kind of outcome)
