@@ -497,6 +497,7 @@ struct GzSource final : Source {
     uint64_t start_bit = 0, end_bit = 0;
     InflateStatus status = INF_CORRUPT;
     const uint8_t *after = nullptr;
+    double seconds = 0, find_seconds = 0;  // (debug: the worker's time on this chunk, and of it the search for the entry point)
   };
   struct Workers {  // a small two-priority pool of the decoder's own
     std::vector<std::thread> th;
@@ -504,15 +505,20 @@ struct GzSource final : Source {
     std::condition_variable cv;
     std::deque<std::function<void()>> hi, lo;
     bool quit = false;
-    explicit Workers(uint32_t n) {
-      for (uint32_t i = 0; i < n; ++i)
-        th.emplace_back([this] {
+    // n threads take whatever there is, urgent work first; n_urgent more take urgent work only — a chunk's bytes are
+    // wanted NOW (the windows go out in order), and a worker deep in a 10 ms speculative decode is no help with that
+    Workers(uint32_t n, uint32_t n_urgent) {
+      for (uint32_t i = 0; i < n + n_urgent; ++i)
+        th.emplace_back([this, only_urgent = i >= n] {
           for (;;) {
             std::function<void()> f;
             {
               std::unique_lock<std::mutex> lk(m);
-              cv.wait(lk, [&] { return quit || !hi.empty() || !lo.empty(); });
-              if (quit && hi.empty() && lo.empty()) return;
+              cv.wait(lk, [&] { return quit || !hi.empty() || (!only_urgent && !lo.empty()); });
+              if (hi.empty() && (only_urgent || lo.empty())) {
+                if (quit) return;
+                continue;
+              }
               auto &q = hi.empty() ? lo : hi;
               f = std::move(q.front());
               q.pop_front();
@@ -526,7 +532,7 @@ struct GzSource final : Source {
         std::lock_guard<std::mutex> lk(m);
         (urgent ? hi : lo).emplace_back(std::move(f));
       }
-      cv.notify_one();
+      cv.notify_all();
     }
     ~Workers() {
       {
@@ -550,6 +556,12 @@ struct GzSource final : Source {
   // The speculative decode of chunk `i`: entry point at or behind bit lo, output up to the first block boundary at or
   // behind bit hi.
   static void speculate(SpecResult *r, const uint8_t *origin, const uint8_t *end, uint64_t lo, uint64_t hi, size_t guess) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Note {
+      SpecResult *r;
+      std::chrono::steady_clock::time_point t0;
+      ~Note() { r->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    } note{r, t_begin};
     Inflater inf;
     size_t cap = guess + 65536;
     r->sym.resize_discard(cap);
@@ -586,6 +598,7 @@ struct GzSource final : Source {
       // accepted: go on to the first block boundary at or behind `hi`
       r->found = true;
       r->start_bit = p;
+      r->find_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
       for (;;) {
         st = inf.run_symbols(r->sym.data(), &pos, cap, origin, hi, &between);
         if (st == INF_OUTPUT_FULL && !between) {
@@ -608,7 +621,7 @@ struct GzSource final : Source {
     std::vector<SpecResult> spec(n_chunks);
     std::mutex rm;
     std::condition_variable rcv;
-    Workers pool(n_threads);
+    Workers pool(n_threads, std::max(2u, n_threads / 4));
     size_t issued = 1;  // (chunk 0 starts at the stream's start: decoded here, the ordinary way)
     const size_t ahead = (size_t)n_threads + 2;
     const size_t guess = chunk_bytes * 6;
@@ -642,6 +655,8 @@ struct GzSource final : Source {
     bool cancelled = false;
     size_t n_spec_used = 0, n_here = 0;  // chunks taken from the workers / stretches decoded by this thread
     uint64_t bytes_spec = 0, bytes_here = 0;
+    double t_workers = 0, t_find = 0, t_wait_spec = 0, t_wait_resolve = 0, t_emit = 0;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
     auto is_stopped = [&] {
       std::lock_guard<std::mutex> lk(m);
@@ -651,7 +666,17 @@ struct GzSource final : Source {
     auto emit_front = [&](bool last) {
       Piece pc = std::move(out_q.front());
       out_q.pop_front();
-      while (pc.pending && pc.pending->load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      {
+        const double t0 = tnow();
+        while (pc.pending && pc.pending->load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        t_wait_resolve += tnow() - t0;
+      }
+      const double t_e0 = tnow();
+      struct EmitNote {
+        double &acc, t0;
+        decltype(tnow) &now;
+        ~EmitNote() { acc += now() - t0; }
+      } emit_note{t_emit, t_e0, tnow};
       uint8_t *base = pc.buf->v.data();
       size_t a = pc.w_len, b = pc.w_len + pc.n;
       if (!carry.empty()) {  // the line begun in the piece before: it lies right in front of this piece's bytes
@@ -804,7 +829,7 @@ struct GzSource final : Source {
         cancelled = true;
         break;
       }
-      drain(2);
+      drain(6);
       if (next >= n_chunks) {  // behind the last cut: the rest of the stream, the ordinary way
         decode_here(~0ull);
         continue;
@@ -812,8 +837,12 @@ struct GzSource final : Source {
       issue_up_to(next + ahead);
       SpecResult &r = spec[next];
       {
+        const double t0 = tnow();
         std::unique_lock<std::mutex> lk(rm);
         rcv.wait(lk, [&] { return r.ready; });
+        t_wait_spec += tnow() - t0;
+        t_workers += r.seconds;
+        t_find += r.find_seconds;
       }
       if (r.found && r.start_bit == verified) {
         // (a symbol that points in front of everything decoded so far cannot come from a valid stream entered at a
@@ -868,7 +897,9 @@ struct GzSource final : Source {
     }
     if (getenv("SHK_FASTQ_DEBUG"))
       fprintf(stderr, "[gzip member, %u threads, %zu chunks of %zu KiB] %zu chunks (%.1f MB) from the workers, %zu stretches (%.1f MB) decoded in order\n",
-              n_threads, n_chunks, chunk_bytes >> 10, n_spec_used, bytes_spec / 1e6, n_here, bytes_here / 1e6);
+              n_threads, n_chunks, chunk_bytes >> 10, n_spec_used, bytes_spec / 1e6, n_here, bytes_here / 1e6),
+          fprintf(stderr, "   workers %.0f ms in all (%.0f ms of it looking for entry points); this thread waited %.0f ms for chunks, %.0f ms for their bytes, %.0f ms handing windows on\n",
+                  t_workers * 1e3, t_find * 1e3, t_wait_spec * 1e3, t_wait_resolve * 1e3, t_emit * 1e3);
     // (the workers are joined by ~Workers: what is still queued of the speculation is dropped)
   }
 

@@ -535,8 +535,103 @@ InflateStatus Inflater::run_symbols(uint16_t *out, size_t *out_pos, size_t out_c
       state = last_block ? 3 : 0;
       continue;
     }
-    for (;;) {  // symbols of a Huffman block: every one taken only when all its bits are there
+    for (;;) {  // symbols of a Huffman block
       if (out_cap - pos < OUT_SLACK) SHK_SYM_DONE(INF_OUTPUT_FULL);
+      if (in_end - ip >= 16) {
+        // away from the input's end every bit a symbol can need is in the buffer after one refill (run()'s fast path,
+        // with 16-bit symbols going out)
+        {
+          bb |= load64(ip) << bc;
+          const uint32_t nby = (63 - bc) >> 3;
+          ip += nby;
+          bc += nby * 8;
+        }
+        uint32_t e = litlen[bb & ((1u << LIT_BITS) - 1)];
+        if (e & E_LITERAL) {
+          bb >>= (uint8_t)e;
+          bc -= (uint8_t)e;
+          out[pos++] = (uint16_t)((e >> 16) & 0xFF);
+          e = litlen[bb & ((1u << LIT_BITS) - 1)];
+          if (e & E_LITERAL) {
+            bb >>= (uint8_t)e;
+            bc -= (uint8_t)e;
+            out[pos++] = (uint16_t)((e >> 16) & 0xFF);
+            e = litlen[bb & ((1u << LIT_BITS) - 1)];
+            if (e & E_LITERAL) {
+              bb >>= (uint8_t)e;
+              bc -= (uint8_t)e;
+              out[pos++] = (uint16_t)((e >> 16) & 0xFF);
+              continue;
+            }
+          }
+          if (bc < 48) {
+            bb |= load64(ip) << bc;
+            const uint32_t nby = (63 - bc) >> 3;
+            ip += nby;
+            bc += nby * 8;
+          }
+        }
+        if (e & E_EXC) {
+          if (e & E_SUB) {
+            bb >>= LIT_BITS;
+            bc -= LIT_BITS;
+            e = litlen[(e >> 16) + ((uint32_t)bb & ((1u << ((e >> 8) & 15)) - 1))];
+            if (e & E_LITERAL) {
+              bb >>= (uint8_t)e;
+              bc -= (uint8_t)e;
+              out[pos++] = (uint16_t)((e >> 16) & 0xFF);
+              continue;
+            }
+          }
+          if (e & E_EXC) {
+            if (!(e & E_EOB)) SHK_SYM_DONE(INF_CORRUPT);
+            bb >>= (uint8_t)e;
+            bc -= (uint8_t)e;
+            break;
+          }
+        }
+        bb >>= (uint8_t)e;
+        const uint32_t leb = (e >> 8) & 15;
+        const uint32_t length = (e >> 16) + ((uint32_t)bb & ((1u << leb) - 1));
+        bb >>= leb;
+        bc -= (uint8_t)e + leb;
+        uint32_t d = dist[bb & ((1u << DIST_BITS) - 1)];
+        if (d & E_EXC) {
+          if (!(d & E_SUB)) SHK_SYM_DONE(INF_CORRUPT);
+          bb >>= DIST_BITS;
+          bc -= DIST_BITS;
+          d = dist[(d >> 16) + ((uint32_t)bb & ((1u << ((d >> 8) & 15)) - 1))];
+          if (d & E_EXC) SHK_SYM_DONE(INF_CORRUPT);
+        }
+        bb >>= (uint8_t)d;
+        const uint32_t deb = (d >> 8) & 15;
+        const size_t distance = (d >> 16) + ((uint32_t)bb & ((1u << deb) - 1));
+        bb >>= deb;
+        bc -= (uint8_t)d + deb;
+        if (distance <= pos) {
+          const uint16_t *src = out + pos - distance;
+          uint16_t *dst = out + pos, *const dend = dst + length;
+          if (distance >= 8) {  // eight symbols (16 bytes) at a time, overshooting into the slack
+            do {
+              memcpy(dst, src, 16);
+              dst += 8;
+              src += 8;
+            } while (dst < dend);
+          } else {
+            do {
+              *dst++ = *src++;
+            } while (dst < dend);
+          }
+        } else {  // reaches in front of the entry point: bytes of the unknown window (distance ≤ 32768 always)
+          for (uint32_t i = 0; i < length; ++i) {
+            const size_t at = pos + i;
+            out[at] = at >= distance ? out[at - distance] : (uint16_t)(256 + 32768 - (distance - at));
+          }
+        }
+        pos += length;
+        continue;
+      }
+      // the input's last bytes: every symbol taken only when all its bits are there
       refill();
       uint64_t b2 = bb;
       uint32_t c2 = bc;
