@@ -15,6 +15,7 @@ tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 reads = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 21
+batches = int(sys.argv[5]) if len(sys.argv) > 5 else 4   # bench.py rotates its steps over this many distinct resident batches
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 
@@ -50,7 +51,8 @@ for kn in sorted({key[0] for key in list(fetch) + list(write)}):
     fb, wb = 2 * (fs or 0) * 1024, (ws or 0) * 1024
     kernels[short] = {"kernel": kn, "fetch_bytes_corrected": int(fb), "write_bytes": int(wb),
                       "hbm_bytes_per_launch": int(fb + wb)}
-json.dump({"reads": reads, "k": k, "source": f"tools/profile_round.sh {tag}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-           "in separate passes over `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`",
+json.dump({"reads": reads, "k": k, "batches": batches, "source": f"tools/profile_round.sh {tag}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+           "in separate passes over `python3 bench.py --no-cpu-baseline --no-extras` (the default run: steps rotate over "
+           f"{batches} distinct batches)",
            "kernels": kernels}, open(f"profiles/{rnd}_traffic.json", "w"), indent=1)
 print(json.dumps(kernels, indent=1))
