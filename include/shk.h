@@ -381,9 +381,24 @@ int shk_xchg_scatter_device(shk_ctx *ctx, const void *d_bases, const void *d_off
 int shk_xchg_absorb(shk_ctx *ctx, const void *d_records, const void *d_cursors, const shk_xchg_layout *layout);
 int shk_xchg_spill(shk_ctx *ctx, void **d_kmers, void **d_lanes, void **d_counts, uint64_t *n);
 int shk_xchg_spill_clear(shk_ctx *ctx);
+/* The exchange round for k-mers the owner layout cannot take (4-byte records need 2k − layout.log_p1 ≤ 32: k ≤ 21 at
+ * the default fan-out; ≤ 16 chunk lanes) — any k, any number of lanes, slower: the batch is validated, its canonical
+ * k-mers (kmers_from_ascii, encoding.rs:332-371) are extracted as whole 64-bit values and grouped by owner:
+ *   *d_kmers u64[Σ counts], owner o's k-mers at [Σ_{o'<o} counts[o'], …) in no particular order;
+ *   *d_lanes u32[Σ counts], each k-mer's chunk lane (read i → lane (i / 1000) % n_chunks, io.rs:340-361);
+ *   counts   u64[n_owners], on the host.
+ * The caller moves owner o's piece of both arrays to rank o (all-to-all with these split sizes) and every rank hands
+ * what it receives to shk_insert_device with d_counts = NULL (one occurrence each: KmerCounts::ingest_seq's
+ * saturating add, counting.rs:82-85, by device-scope atomics).  The call returns when the arrays are complete; an
+ * invalid byte is reported here (SHK_ERR_INVALID_CHAR) and poisons the context.  The arrays stay valid until the next
+ * scatter call on the context.  shk_xchg_feasible: 1 when the owner-layout rounds (shk_xchg_scatter_device) can take
+ * this context's batches at its present table geometry, 0 when only the wide round can. */
+int shk_xchg_wide_scatter_device(shk_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_seqs,
+                                 uint64_t n_bases, void **d_kmers, void **d_lanes, uint64_t *counts);
+int shk_xchg_feasible(shk_ctx *ctx);
 /* KmerCounts::insert (counting.rs:152-154) from device memory with a chunk lane per record:
  * saturating add of d_counts[i] to d_kmers[i] in lane d_lanes[i]; k-mers the context does not own
- * are dropped.  Synchronous. */
+ * are dropped; d_counts = NULL: one occurrence each.  Synchronous. */
 int shk_insert_device(shk_ctx *ctx, const void *d_kmers, const void *d_lanes, const void *d_counts, uint64_t n);
 /* The context's HIP stream (hipStream_t): device work queued by the calls above is ordered on it, so
  * a host that runs its collectives on the same stream needs no host-side synchronisation. */

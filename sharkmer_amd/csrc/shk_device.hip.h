@@ -986,6 +986,66 @@ __global__ void __launch_bounds__(WG) k_direct(BatchRef b, TableRef tb, DevStats
   if ((threadIdx.x & 63) == 0 && n_new) atomicAdd(&stats->n_distinct, (unsigned long long)n_new);
 }
 
+// ---- the WIDE exchange: k-mers too long for the owner layout's 4-byte records (k > 21 at a fan-out of 1024) ----------
+// The batch's canonical k-mers (kmers_from_ascii, encoding.rs:332-371) as whole 64-bit values, grouped by OWNER — the
+// top owner_bits of the mixed key, what home_of reads — with their chunk lanes beside them.  Two launches of this
+// kernel: PLACE = false counts every owner's k-mers (owner_count[o] += …), the host turns the counts into segment
+// bases, PLACE = true writes them (owner_count[o] then is owner o's running cursor, starting at its segment's base).
+// Per tile: the k-mers are counted by owner in LDS, one device-scope add per (tile, owner) reserves a run, and a second
+// walk of the same tile (walk_tile is deterministic) puts every k-mer at run base + its rank.
+__device__ __forceinline__ uint32_t owner_of(uint64_t key, uint32_t key_bits, uint32_t owner_bits) {
+  return owner_bits ? hash64(key, key_bits) >> (32 - owner_bits) : 0u;
+}
+template <bool PLACE>
+__global__ void __launch_bounds__(WG) k_xw_scatter(BatchRef b, uint32_t key_bits, uint32_t owner_bits, DevStats *__restrict__ stats,
+                                                   unsigned long long *__restrict__ owner_count, uint64_t *__restrict__ out_kmers,
+                                                   uint32_t *__restrict__ out_lanes) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[STAGE_BYTES];
+  __shared__ uint32_t cnt[64];
+  __shared__ unsigned long long run_base[64];
+  if (stats->bad != ~0ull) return;  // k_scan found an invalid byte: nothing is handed on
+  const uint32_t W = 1u << owner_bits;
+  uint64_t t = blockIdx.x, t0, t1;
+  uint32_t lane;
+  bool have = next_tile(b, t, false, 0, t0, t1, lane);
+  StageRegs<WG> pre;
+  if (have) stage_prefetch<WG>(b, t0, pre);
+  while (have) {
+    __syncthreads();
+    stage_tile<false, WG>(b, t0, t1, lds, stats, pre);
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    uint64_t tn = t + gridDim.x, n0, n1;
+    uint32_t nl;
+    const bool hn = next_tile(b, tn, false, 0, n0, n1, nl);
+    if (hn) stage_prefetch<WG>(b, n0, pre);
+    __syncthreads();
+    walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) { atomicAdd(&cnt[owner_of(kmer, key_bits, owner_bits)], 1u); });
+    __syncthreads();
+    if (threadIdx.x < W) {
+      const uint32_t c1 = cnt[threadIdx.x];
+      const unsigned long long at = c1 ? atomicAdd(&owner_count[threadIdx.x], (unsigned long long)c1) : 0ull;
+      if (PLACE) {
+        run_base[threadIdx.x] = at;
+        cnt[threadIdx.x] = 0;
+      }
+    }
+    if (PLACE) {
+      __syncthreads();
+      walk_tile(lds, t0, t1, b.k, [&](uint64_t kmer) {
+        const uint32_t o = owner_of(kmer, key_bits, owner_bits);
+        const unsigned long long at = run_base[o] + atomicAdd(&cnt[o], 1u);
+        out_kmers[at] = kmer;
+        out_lanes[at] = lane;
+      });
+    }
+    t = tn;
+    t0 = n0;
+    t1 = n1;
+    lane = nl;
+    have = hn;
+  }
+}
+
 // ==========================================================================================
 // K_INSERT: (kmer, lane, count) records — KmerCounts::insert (counting.rs:152-154) and the
 // re-insert of spilled k-mers after a grow.  lanes == nullptr ⇒ all records use lane0;

@@ -33,8 +33,18 @@ static int settle_light(shk_ctx *c);
 static int flush_acc(shk_ctx *c);
 static int replay_held_spills(shk_ctx *c);
 static uint64_t acc_records_est(const shk_ctx *c, uint64_t kmers_ub);
-struct XchgOut;
+struct XchgOut {
+  uint64_t layout_bases;  // in: what every rank sizes its segments for (0: this batch)
+  void *d_records, *d_cursors;
+  shk_xchg_layout lay;
+  uint64_t n_foreign;
+  // the wide round (shk_xchg_wide_scatter_device): whole k-mers + lanes grouped by owner, counts on the host
+  bool wide = false;
+  void *d_kmers = nullptr, *d_lanes = nullptr;
+  uint64_t *counts = nullptr;
+};
 static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo);
+static int xw_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo);
 static int xchg_prepare_cursors(shk_ctx *c, uint32_t *n_words);
 static bool trace_on() {
   static const bool on = getenv("SHK_TRACE") != nullptr;
@@ -149,6 +159,7 @@ struct shk_ctx {
   HostBuf h_rebased[3];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
   DevBuf in_bases, in_offsets, in_bases2, in_offsets2, in_bases3, in_offsets3, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
   DevBuf pk_stage[3], nm_stage[3], nz_dev[3], pk_ascii;
+  DevBuf xw_kmers, xw_lanes, xw_count;  // the wide exchange round's output (shk_xchg_wide_scatter_device)
   HostBuf nz_host[3];             // … and the non-zero words of a slice's N mask, when they are few (index, word)  // packed input: the staged streams of a slice; a whole batch unpacked (device-resident packed ingest)
   DevBuf xbuf, xspill;            // owner layout: the level-1 records of a launch by [owner][lane][super-page]; the foreign spill list
   uint64_t xspill_cap = 0;
@@ -472,7 +483,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   }
   if (lane_fixed < 0) c->n_reads_read += n_seqs;  // explicit-lane batches do not advance striping
   c->n_bases_read += n_bases;
-  if (n_seqs == 0 || n_bases == 0) return xo ? xchg_scatter_launch(c, BatchRef{}, 0, xo) : SHK_OK;
+  if (n_seqs == 0 || n_bases == 0) return xo ? (xo->wide ? xw_scatter_launch(c, BatchRef{}, 0, xo) : xchg_scatter_launch(c, BatchRef{}, 0, xo)) : SHK_OK;
 
   // 1. read-start bitmap (+ tile list when the batch spans several chunk lanes)
   const size_t sb_words = (size_t)(n_bases / 32 + 3);
@@ -502,7 +513,10 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     c->cur_kmer_ratio = cut < (double)n_bases ? std::max(0.125, 1.0 - cut / (double)n_bases) : 0.125;
   }
   uint32_t n_cursor_words = 0;
-  if (xo) {  // exchange round: level-1 scatter only, every owner's records (shk_xchg_scatter_device)
+  if (xo && xo->wide) {  // the wide exchange round: no partition cursors at all
+    if (n_tiles_ub > tiles_per_sub) return fail(c, SHK_ERR_BAD_ARG, "an exchange batch takes at most %llu bases", (unsigned long long)MAX_SUB_BASES);
+    HIPC(c, c->part_meta.ensure(64));
+  } else if (xo) {  // exchange round: level-1 scatter only, every owner's records (shk_xchg_scatter_device)
     if (n_tiles_ub > tiles_per_sub) return fail(c, SHK_ERR_BAD_ARG, "an exchange batch takes at most %llu bases", (unsigned long long)MAX_SUB_BASES);
     int rc = xchg_prepare_cursors(c, &n_cursor_words);
     if (rc != SHK_OK) return rc;
@@ -538,7 +552,7 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
   b.lane0 = lane_fixed >= 0 ? (uint32_t)lane_fixed : (striped ? (uint32_t)((g0 / 1000) % NL) : 0u);
   b.k = (int)c->cfg.k;
 
-  if (xo) return xchg_scatter_launch(c, b, n_tiles_ub * TILE_T, xo);
+  if (xo) return xo->wide ? xw_scatter_launch(c, b, n_tiles_ub * TILE_T, xo) : xchg_scatter_launch(c, b, n_tiles_ub * TILE_T, xo);
   // 3. count, in sub-ranges of tiles
   for (uint64_t ta = 0; ta < n_tiles_ub; ta += tiles_per_sub) {
     uint64_t tn = std::min(tiles_per_sub, n_tiles_ub - ta);
@@ -961,12 +975,6 @@ static int xl_count(shk_ctx *c, const BatchRef &b, const PartGeom &g, uint64_t s
 }
 
 // ---- exchange rounds between owner shares (shk_xchg_*) ------------------------------------------------
-struct XchgOut {
-  uint64_t layout_bases;  // in: what every rank sizes its segments for (0: this batch)
-  void *d_records, *d_cursors;
-  shk_xchg_layout lay;
-  uint64_t n_foreign;
-};
 // The exchange layout depends only on (layout_bases, n_lanes, geometry), never on the batch at hand: every
 // rank of a round must come out with the same segment size.
 static XlPlan xchg_plan(const shk_ctx *c, const PartGeom &g, uint64_t layout_bases) {
@@ -1059,6 +1067,56 @@ static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub,
   xo->lay.reserved = 0;
   xo->lay.segment_records = x.seg_recs;
   xo->n_foreign = c->h_stats->scratch[0];
+  return SHK_OK;
+}
+
+// The wide exchange round: validate (k_scan), count the batch's k-mers by owner, lay the owners' segments out back to
+// back, write k-mers and lanes.  Synchronous: the counts come back to the host between the two passes.
+static int xw_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo) {
+  const uint32_t W = c->n_owners;
+  for (uint32_t o = 0; o < W; ++o) xo->counts[o] = 0;
+  xo->d_kmers = xo->d_lanes = nullptr;
+  if (!kmers_ub) return SHK_OK;
+  HIPC(c, c->xw_kmers.ensure(kmers_ub * 8 + 64));
+  HIPC(c, c->xw_lanes.ensure(kmers_ub * 4 + 64));
+  HIPC(c, c->xw_count.ensure(64 * 8));
+  unsigned long long *d_cnt = (unsigned long long *)c->xw_count.p;
+  HIPC(c, hipMemsetAsync(d_cnt, 0, 64 * 8, c->stream));
+  {  // validate + count bases first (encoding.rs:353-356, 374-376); k_xw_scatter tests stats->bad
+    ScopedTimer t(c, SHK_K_SCAN);
+    hipLaunchKernelGGL(k_scan, dim3(grid_for(b.tile_count, 1, 4096)), dim3(WG), 0, c->stream, b, c->d_stats, c->d_lane_bases);
+  }
+  const uint32_t G = grid_for(b.tile_count, 1, 256 * 8);
+  {
+    ScopedTimer t(c, SHK_K_PCOUNT);
+    hipLaunchKernelGGL(k_xw_scatter<false>, dim3(G), dim3(WG), 0, c->stream, b, 2 * c->cfg.k, c->owner_bits, c->d_stats, d_cnt,
+                       (uint64_t *)nullptr, (uint32_t *)nullptr);
+  }
+  unsigned long long h_cnt[64];
+  HIPC(c, hipMemcpyAsync(h_cnt, d_cnt, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+  int rc = read_stats(c);  // (synchronises)
+  if (rc != SHK_OK) return rc;
+  if (c->h_stats->bad != ~0ull) {
+    c->poisoned = true;
+    c->poison_code = SHK_ERR_INVALID_CHAR;
+    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%s' in sequence. Only ACGTN allowed.", shk::byte_as_char((uint8_t)(c->h_stats->bad & 0xFF)).c_str());
+  }
+  unsigned long long base[64], at = 0;
+  for (uint32_t o = 0; o < W; ++o) {
+    base[o] = at;
+    at += h_cnt[o];
+    xo->counts[o] = h_cnt[o];
+  }
+  if (at > kmers_ub) return fail(c, SHK_ERR_INVARIANT, "more k-mers than end positions in an exchange batch");
+  HIPC(c, hipMemcpyAsync(d_cnt, base, (size_t)W * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedTimer t(c, SHK_K_SCATTER);
+    hipLaunchKernelGGL(k_xw_scatter<true>, dim3(G), dim3(WG), 0, c->stream, b, 2 * c->cfg.k, c->owner_bits, c->d_stats, d_cnt,
+                       (uint64_t *)c->xw_kmers.p, (uint32_t *)c->xw_lanes.p);
+  }
+  HIPC(c, hipStreamSynchronize(c->stream));  // (`base` lives on this stack; and the arrays are complete when the call returns)
+  xo->d_kmers = c->xw_kmers.p;
+  xo->d_lanes = c->xw_lanes.p;
   return SHK_OK;
 }
 
@@ -2060,6 +2118,29 @@ int shk_xchg_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offse
   *layout = xo.lay;
   if (n_foreign_spilled) *n_foreign_spilled = xo.n_foreign;
   return SHK_OK;
+}
+
+int shk_xchg_wide_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases,
+                                 void **d_kmers, void **d_lanes, uint64_t *counts) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  if (!c || !d_kmers || !d_lanes || !counts) return SHK_ERR_BAD_ARG;
+  if (!c->is_share()) return fail(c, SHK_ERR_STATE, "not an owner share (shk_config.n_owners = 0: say 1 for a share that is the whole key space)");
+  HIPC(c, hipSetDevice(c->cfg.device));
+  if (n_bases > SHK_XCHG_MAX_BASES) return fail(c, SHK_ERR_BAD_ARG, "an exchange batch takes at most %llu bases", (unsigned long long)SHK_XCHG_MAX_BASES);
+  XchgOut xo{};
+  xo.wide = true;
+  xo.counts = counts;
+  int rc = ingest_core(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_seqs, n_bases, c->xchg_lane_fixed, &xo);
+  if (rc != SHK_OK) return rc;
+  *d_kmers = xo.d_kmers;
+  *d_lanes = xo.d_lanes;
+  return SHK_OK;
+}
+
+int shk_xchg_feasible(shk_ctx *c) {
+  if (!c || c->group || !c->is_share()) return 0;
+  const PartGeom g = part_geom(c);
+  return xl_feasible(c, g) && count_path(c, 0) == PATH_DEFER ? 1 : 0;
 }
 
 int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, const shk_xchg_layout *lay) {

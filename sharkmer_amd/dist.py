@@ -39,18 +39,21 @@ MAX_MESSAGE_BYTES = int(os.environ.get("SHK_DIST_MAX_MESSAGE", 1 << 28))   # (th
 
 
 def exchange_parts(dist, out: torch.Tensor, inp: torch.Tensor, world: int, rank: int, in_splits=None, out_splits=None,
-                   skip_self: bool = False):
+                   skip_self: bool = False, in_pieces=None):
     """all_to_all_single — part s of `inp` (in_splits[s] elements; equal parts when None) goes to rank s, part s of
     `out` comes from rank s — that never hands the communicator a message above MAX_MESSAGE_BYTES: when every part is
     below it, ONE all_to_all_single; otherwise grouped send/recv pairs over slices of the parts (the fully connected
     mesh still carries a rank's W−1 transfers at once), the rank's own part by a device copy (skip_self: not at all —
-    the caller uses it where it lies)."""
+    the caller uses it where it lies).  in_pieces: with UNEQUAL parts every rank must take the same route — the caller
+    then says which (True: send/recv pairs), from a maximum it has reduced over the ranks."""
     if in_splits is None:
         per = inp.numel() // world
         assert inp.numel() == per * world and out.numel() == inp.numel()
         in_splits = out_splits = [per] * world
     esz = inp.element_size()
-    if max(max(in_splits), max(out_splits)) * esz <= MAX_MESSAGE_BYTES or not hasattr(dist, "batch_isend_irecv"):
+    if in_pieces is None:
+        in_pieces = max(max(in_splits), max(out_splits)) * esz > MAX_MESSAGE_BYTES
+    if not in_pieces or not hasattr(dist, "batch_isend_irecv"):
         if in_splits[0] * world == inp.numel() and len(set(in_splits)) == 1 and list(in_splits) == list(out_splits):
             dist.all_to_all_single(out, inp)   # (in-process test transports have nothing else)
         else:
@@ -123,6 +126,7 @@ class OwnerCounter:
         self.device = device
         self.round_bases = int(round_bases)
         self._recv = None
+        self._wide = None   # rounds take the wide route (engine.xchg_feasible() is False)
         self.n_rounds = 0
         self.n_foreign_rounds = 0   # rounds in which somebody had foreign spills to hand on
         self.wire_bytes = 0
@@ -141,6 +145,15 @@ class OwnerCounter:
         """batch = (bases, offsets, n_seqs, n_bases, first_read_index) — device pointers for the HIP
         engine — or None.  n_bases ≤ round_bases."""
         dist, W = self.dist, self.world
+        if self._wide is None:
+            # decided ONCE, by all ranks together (feasibility looks at the share's table geometry, which a rank's
+            # capacity hint sets): the 4-byte owner layout if every rank can take it, the wide round otherwise
+            ok = self._dev(torch.tensor([1 if not hasattr(self.eng, "xchg_feasible") or self.eng.xchg_feasible() else 0], dtype=torch.int64))
+            with self._on_engine_stream():
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                self._wide = int(ok.item()) == 0
+        if self._wide:
+            return self._round_wide(batch)
         err = None
         try:
             if batch is not None:
@@ -174,6 +187,47 @@ class OwnerCounter:
         self.n_rounds += 1
         self.wire_bytes += (W - 1) * (lay.segment_records + lay.regions) * 4
         return lay
+
+    def _round_wide(self, batch):
+        """The round for k-mers that do not fit the owner layout's 4-byte records (k > 21 at the default fan-out;
+        engine.xchg_feasible() is False — a function of the configuration, so every rank answers alike): the batch's
+        k-mers travel whole — 8 B k-mer + 4 B lane, grouped by owner, as many as there are — and the receiver inserts them
+        through the table's general path (shk_insert_device).  Exact for every k ≤ 32; three times the bytes on the
+        links and the slow side of the table, which is what the 4-byte layout exists to avoid."""
+        dist, W = self.dist, self.world
+        err, km, ln, counts = None, None, None, [0] * W
+        try:
+            if batch is not None:
+                self.eng.set_read_index(batch[4])
+                km, ln, counts = self.eng.xchg_wide_scatter_tensors(batch[0], batch[1], batch[2], batch[3])
+        except Exception as e:  # noqa: BLE001 — reported to every rank below
+            err = e
+        with self._on_engine_stream():
+            st = self._dev(torch.tensor([1 if err is not None else 0, max(counts)], dtype=torch.int64))
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            any_err, max_part = (int(x) for x in st.cpu())
+            if any_err:
+                raise err if err is not None else RuntimeError("a peer rank failed in this exchange round")
+            mine = self._dev(torch.tensor(counts, dtype=torch.int64))
+            theirs = torch.empty_like(mine)
+            dist.all_to_all_single(theirs, mine)
+            got = [int(x) for x in theirs.cpu()]
+            n_in = sum(got)
+            if km is None:
+                km = self._dev(torch.empty(0, dtype=torch.int64))
+                ln = self._dev(torch.empty(0, dtype=torch.int32))
+            rk = torch.empty(n_in, dtype=torch.int64, device=km.device)
+            rl = torch.empty(n_in, dtype=torch.int32, device=km.device)
+            pieces = max_part * 8 > MAX_MESSAGE_BYTES
+            if W > 1 or n_in:
+                exchange_parts(dist, rk, km, W, self.rank, counts, got, in_pieces=pieces)
+                exchange_parts(dist, rl, ln, W, self.rank, counts, got, in_pieces=pieces)
+            if km.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            self.eng.insert_tensors(rk, rl, None)
+        self.n_rounds += 1
+        self.wire_bytes += (sum(counts) - counts[self.rank]) * 12
+        return None
 
     def _exchange_spills(self):
         """All-gather the foreign spill lists; every rank inserts what it owns (insert drops the rest)."""

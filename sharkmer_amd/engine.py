@@ -109,6 +109,7 @@ ABI_SYMBOLS = [
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
     "shk_run_error", "shk_run_files",
     "shk_xchg_scatter_device", "shk_xchg_absorb", "shk_xchg_spill", "shk_xchg_spill_clear", "shk_insert_device",
+    "shk_xchg_wide_scatter_device", "shk_xchg_feasible",
     "shk_stream", "shk_compact_owners_packed", "shk_compact_owners_fixed", "shk_merge_pieces_max", "shk_merge_pieces", "shk_set_owner_share", "shk_finalize_begin", "shk_finalize_end",
     "shk_packed_sizes", "shk_pack_reads", "shk_ingest_packed", "shk_ingest_packed_device", "shk_pack_reads_device",
     "shk_unpack_reads_device",
@@ -248,6 +249,8 @@ def load_library():
     L.shk_xchg_spill.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.shk_xchg_spill_clear.argtypes = [vp]
     L.shk_insert_device.argtypes = [vp, vp, vp, vp, u64]
+    L.shk_xchg_wide_scatter_device.argtypes = [vp, vp, vp, u64, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.shk_xchg_feasible.argtypes = [vp]
     L.shk_stream.argtypes = [vp]
     L.shk_stream.restype = vp
     L.shk_ingest_packed.argtypes = [vp, vp, vp, vp, u64]
@@ -543,6 +546,18 @@ class KmerEngine:
     def xchg_spill_clear(self):
         self._check(self._L.shk_xchg_spill_clear(self._h))
 
+    def xchg_feasible(self) -> bool:
+        """Does this share's key width fit the owner layout's 4-byte records (shk_xchg_scatter_device)?  If not
+        (k > 21 at the default fan-out), rounds go through xchg_wide_scatter_device + insert_device."""
+        return bool(self._L.shk_xchg_feasible(self._h))
+
+    def xchg_wide_scatter_device(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int):
+        """→ (d_kmers, d_lanes, counts[n_owners]): the batch's k-mers as whole 64-bit values grouped by owner."""
+        km, ln = C.c_void_p(), C.c_void_p()
+        counts = (C.c_uint64 * 64)()
+        self._check(self._L.shk_xchg_wide_scatter_device(self._h, d_bases, d_offsets, n_seqs, n_bases, C.byref(km), C.byref(ln), counts))
+        return int(km.value or 0), int(ln.value or 0), [int(counts[i]) for i in range(max(self.n_owners, 1))]
+
     def insert_device(self, d_kmers: int, d_lanes: int, d_counts: int, n: int):
         self._check(self._L.shk_insert_device(self._h, d_kmers, d_lanes, d_counts, n))
 
@@ -682,11 +697,19 @@ class KmerEngine:
         k, l, c, n = self.xchg_spill()
         return self._raw_tensor(k, n, "<i8", self._tdev), self._raw_tensor(l, n, "<i4", self._tdev), self._raw_tensor(c, n, "<i4", self._tdev)
 
-    def insert_tensors(self, kmers_t, lanes_t, counts_t):
+    def insert_tensors(self, kmers_t, lanes_t, counts_t=None):
+        """counts_t None: every record counts once."""
         n = kmers_t.numel()
         if n:
-            assert kmers_t.is_contiguous() and lanes_t.is_contiguous() and counts_t.is_contiguous()
-            self.insert_device(kmers_t.data_ptr(), lanes_t.data_ptr(), counts_t.data_ptr(), n)
+            assert kmers_t.is_contiguous() and lanes_t.is_contiguous() and (counts_t is None or counts_t.is_contiguous())
+            self.insert_device(kmers_t.data_ptr(), lanes_t.data_ptr(), counts_t.data_ptr() if counts_t is not None else None, n)
+
+    def xchg_wide_scatter_tensors(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int):
+        """→ (kmers int64[n], lanes int32[n], counts list[n_owners]) — views of the context's buffers, valid until the
+        next scatter."""
+        km, ln, counts = self.xchg_wide_scatter_device(d_bases, d_offsets, n_seqs, n_bases)
+        n = sum(counts)
+        return self._raw_tensor(km, n, "<i8", self._tdev), self._raw_tensor(ln, n, "<i4", self._tdev), counts
 
     # -- device memory + synthetic input ---------------------------------------------
     def alloc_device(self, nbytes: int) -> int:

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 class _ReduceOp:
     SUM = "sum"
     MAX = "max"
+    MIN = "min"
 
 
 class ThreadGroup:
@@ -44,7 +45,7 @@ class ThreadGroup:
         self.s.slots[self.rank] = t.clone()
         self.s.barrier.wait()
         stack = torch.stack(self.s.slots)
-        res = stack.sum(0) if op == _ReduceOp.SUM else stack.max(0).values
+        res = stack.sum(0) if op == _ReduceOp.SUM else stack.max(0).values if op == _ReduceOp.MAX else stack.min(0).values
         self.s.barrier.wait()
         t.copy_(res)
         torch.cuda.synchronize()

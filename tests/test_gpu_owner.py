@@ -161,8 +161,11 @@ def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint):
     return results
 
 
-@pytest.mark.parametrize("W,k,chunks,lvl1", [(2, 21, 10, 10), (4, 21, 3, 10), (2, 17, 1, 5), (8, 19, 0, 6)])
+@pytest.mark.parametrize("W,k,chunks,lvl1", [(2, 21, 10, 10), (4, 21, 3, 10), (2, 17, 1, 5), (8, 19, 0, 6),
+                                             (2, 31, 10, 10), (4, 27, 3, 10), (8, 23, 0, 10), (2, 22, 1, 10)])
 def test_exchange_between_contexts_like_ranks(orc, monkeypatch, W, k, chunks, lvl1):
+    """k > 21: 2k − 10 level-1 bits > 32 — no 4-byte record holds the rest of the key, shk_xchg_feasible says so and the
+    rounds take the wide route (whole k-mers grouped by owner, shk_xchg_wide_scatter_device + shk_insert_device)."""
     monkeypatch.setenv("SHK_LEVEL1_LOG", str(lvl1))
     spec = sa.SynthSpec(genome_len=80_000, sub_per_64k=250, n_per_64k=50)
     bases, offsets = sa.synth_reads(spec, 0, 20_500)
@@ -180,14 +183,25 @@ def test_exchange_with_skewed_input_goes_through_the_foreign_spill_list(orc, mon
     assert any(r[3] > 0 for r in res), "the skew was meant to overflow a level-1 region"
 
 
-def test_exchange_invalid_byte_fails_every_rank(monkeypatch):
+@pytest.mark.parametrize("k", [19, 31])
+def test_exchange_invalid_byte_fails_every_rank(monkeypatch, k):
     monkeypatch.setenv("SHK_LEVEL1_LOG", "8")
     spec = sa.SynthSpec(genome_len=50_000)
     bases, offsets = sa.synth_reads(spec, 0, 4_000)
     bad = bases.copy()
     bad[int(offsets[2_500]) + 3] = ord("x")
     with pytest.raises(AssertionError, match="Invalid character 'x'"):
-        _exchange_run(None, bad, offsets, 19, 1, 100, 2, hint=1_000_000)
+        _exchange_run(None, bad, offsets, k, 1, 100, 2, hint=1_000_000)
+
+
+def test_exchange_feasibility_is_a_function_of_the_configuration(monkeypatch):
+    for k, want in ((21, True), (22, False), (31, False), (15, True)):
+        with sa.KmerEngine(k, 3, 100, capacity_hint=4_200_000, n_owners=4, owner_id=1) as eng:
+            assert eng.xchg_feasible() == want, k
+    with sa.KmerEngine(21, 3, 100) as eng:   # not a share at all
+        assert not eng.xchg_feasible()
+        with pytest.raises(sa.ShkError, match="not an owner share"):
+            eng.xchg_wide_scatter_device(0, 0, 0, 0)
 
 
 # ---- one owner's share of BASELINE configs[4] at its full table size ----------------------------------
