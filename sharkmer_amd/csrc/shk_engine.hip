@@ -152,15 +152,16 @@ struct shk_ctx {
   const uint64_t *h_hist = nullptr;  // → the mirror's histogram
   // scratch
   hipStream_t copy_stream = nullptr;
-  hipEvent_t copy_done[3] = {nullptr, nullptr, nullptr};
-  uint32_t stage_next = 0;        // which of the three staging sets the next slice of a host-buffer ingest takes
+  static constexpr int NST = 6;   // staging sets of a host-buffer ingest: NST − 1 slices' copies are queued ahead of the count
+  hipEvent_t copy_done[NST] = {};
+  uint32_t stage_next = 0;        // which of the staging sets the next slice of a host-buffer ingest takes
   bool zero_count_keys = false;   // some key may have been inserted with count 0 (shk_insert_counts, merges): k_histo reads the keys
   bool lds_attr_scatter = false, lds_attr_rescatter = false, lds_attr_scatter_own = false;  // hipFuncSetAttribute done for this context's device
-  HostBuf h_rebased[3];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
-  DevBuf in_bases, in_offsets, in_bases2, in_offsets2, in_bases3, in_offsets3, startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
-  DevBuf pk_stage[3], nm_stage[3], nz_dev[3], pk_ascii;
+  HostBuf h_rebased[NST];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
+  DevBuf in_bases, in_offsets, st_bases[NST], st_offsets[NST], startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
+  DevBuf pk_stage[NST], nm_stage[NST], nz_dev[NST], pk_ascii;
   DevBuf xw_kmers, xw_lanes, xw_count;  // the wide exchange round's output (shk_xchg_wide_scatter_device)
-  HostBuf nz_host[3];             // … and the non-zero words of a slice's N mask, when they are few (index, word)  // packed input: the staged streams of a slice; a whole batch unpacked (device-resident packed ingest)
+  HostBuf nz_host[NST];             // … and the non-zero words of a slice's N mask, when they are few (index, word)  // packed input: the staged streams of a slice; a whole batch unpacked (device-resident packed ingest)
   DevBuf xbuf, xspill;            // owner layout: the level-1 records of a launch by [owner][lane][super-page]; the foreign spill list
   uint64_t xspill_cap = 0;
   // host counters
@@ -769,9 +770,13 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
     // lanes each get a full-size region set; 8-byte records also need k_pages' miss queues
     const uint64_t rec_bytes = rec32 ? (NL > 1 ? 8ull : 5ull) + 1 : (NL > 1 ? 15ull : 10ull) + 8 + 1;  // regions are 1.25 × the window (× 1.5 over several lanes: each lane's share + 50 %)
     const uint64_t mem_records = (uint64_t)(free_b / 3 * 2 + c->acc_buf.cap) / rec_bytes;
-    // up to eight tables' worth of records while that is a few GiB, two tables' worth beyond
+    // up to eight tables' worth of records while that is a few GiB, two and a half tables' worth beyond — and eight
+    // again when a capacity hint says that no window will have to end for the table's sake: every page pass streams
+    // the whole table (24 GB in and out on configs[2]'s 2^30 slots), so the job should make as few as memory allows
+    // (configs[2]: 12 G records in two passes instead of five)
     const uint64_t few_gib = (8ull << 30) / (rec32 ? 4 : 8) / NL;
-    uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), c->tb.cap * 5 / 2);
+    const bool hinted = c->cfg.table_capacity_hint && (double)c->cfg.table_capacity_hint <= 0.8 * (double)c->tb.cap;
+    uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), hinted && env_int("SHK_WIDE_WINDOW", 1) ? c->tb.cap * 8 : c->tb.cap * 5 / 2);
     bmax = std::max<uint64_t>(std::min(bmax, mem_records), kmers_ub);
     // a lane's regions take a lane's share of the window (+ 50 %: blocks of uneven read lengths), but at
     // least what one launch can put into a single lane
@@ -939,6 +944,28 @@ static int xl_scatter(shk_ctx *c, const BatchRef &b, const PartGeom &g, const Xl
   return SHK_OK;
 }
 
+// k_part_rescatter32 on the context's stream.  (A 16384-record tile — 64-byte runs where 2^10 pages share a super-page
+// — was tried for the 2^33-slot tables: the kernel itself is slower, 662 against 613 µs per 1.7 M reads; an apparent
+// gain in the exchange path was the first process on a fresh box waiting longer in its collectives.)
+static uint32_t rs32_tile(uint32_t) { return (uint32_t)RS32_TILE; }
+static int launch_rescatter32(shk_ctx *c, uint32_t n_src_regions, const uint32_t *src_buf, const unsigned int *src_cursor, uint32_t cap1,
+                              uint32_t log_sub, uint32_t r1_bits, unsigned int *dst_cursor, uint32_t dst_cap, uint32_t *dst_buf,
+                              uint32_t lane, SpillRef sp, uint64_t dst_region_base, uint64_t n_dst_total, uint32_t log_src_lane,
+                              uint32_t region_hi, uint64_t dst_lane_stride) {
+  const uint32_t tile = rs32_tile(log_sub), tiles_per_region = (cap1 + tile - 1) / tile;
+  const size_t lds = (size_t)tile * 6 + ((size_t)12 << log_sub);  // records + 16-bit entries + three words per page
+  if (lds > SC32_LDS_MAX) return fail(c, SHK_ERR_INVARIANT, "level-2 pass: %zu bytes of LDS", lds);
+  if (lds > 64 * 1024 && !c->lds_attr_rescatter) {  // > 64 KiB of dynamic LDS has to be asked for
+    HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_rescatter32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
+    c->lds_attr_rescatter = true;
+  }
+  hipLaunchKernelGGL(k_part_rescatter32, dim3(n_src_regions * tiles_per_region), dim3(RS32_NT), lds, c->stream, src_buf, src_cursor, cap1,
+                     tiles_per_region, log_sub, r1_bits, 2 * c->cfg.k, dst_cursor, dst_cap, dst_buf, lane, c->d_stats, sp, dst_region_base,
+                     n_dst_total, log_src_lane, region_hi, dst_lane_stride);
+  HIPC(c, hipGetLastError());
+  return SHK_OK;
+}
+
 // Level-2 pass over ONE owner segment (this context's share: `regions` = [lane][super-page] regions of
 // `cap1` records each, fill levels in src_cursor) into the waiting (lane, page) regions.
 static int xl_absorb(shk_ctx *c, const PartGeom &g, const uint32_t *src_buf, const unsigned int *src_cursor, uint32_t cap1,
@@ -949,21 +976,10 @@ static int xl_absorb(shk_ctx *c, const PartGeom &g, const uint32_t *src_buf, con
   if (!c->acc_cur.p || c->acc_lp != g.lp || !c->acc_rec32 || c->acc_region_lanes != NL)
     return fail(c, SHK_ERR_INVARIANT, "accumulation regions not planned for the owner layout");
   const uint32_t r1_bits = 2 * c->cfg.k - g.log_p1;
-  const uint32_t S = 1u << g.log_sub;
-  const size_t lds_rs32 = (size_t)RS32_TILE * 4 + (size_t)RS32_TILE * 2 + (size_t)S * 12;
-  if (lds_rs32 > 64 * 1024 && !c->lds_attr_rescatter) {
-    HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_rescatter32),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
-    c->lds_attr_rescatter = true;
-  }
-  const uint32_t tiles_per_region = (cap1 + (uint32_t)RS32_TILE - 1) / (uint32_t)RS32_TILE;
   ScopedTimer t(c, SHK_K_PSCAN, /*chain=*/true);
-  hipLaunchKernelGGL(k_part_rescatter32, dim3(n_grp * tiles_per_region), dim3(RS32_NT), lds_rs32, c->stream, src_buf, src_cursor,
-                     cap1, tiles_per_region, g.log_sub, r1_bits, 2 * c->cfg.k, (unsigned int *)c->acc_cur.p, c->acc_cap,
-                     (uint32_t *)c->acc_buf.p, 0u, c->d_stats, sp, 0ull, (uint64_t)NL * n_pages, log_p1w,
-                     c->owner_id << log_p1w, (uint64_t)n_pages);
-  HIPC(c, hipGetLastError());
-  return SHK_OK;
+  return launch_rescatter32(c, n_grp, src_buf, src_cursor, cap1, g.log_sub, r1_bits, (unsigned int *)c->acc_cur.p, c->acc_cap,
+                            (uint32_t *)c->acc_buf.p, 0u, sp, 0ull, (uint64_t)NL * n_pages, log_p1w, c->owner_id << log_p1w,
+                            (uint64_t)n_pages);
 }
 
 // One deferred counting launch on the owner-layout route: scatter (own records only), then absorb.
@@ -1155,7 +1171,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     cap1 = (region_cap(sub_kmers_ub, P1, pads) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
   }
   const uint32_t region_lanes = all_lanes ? NL : 1;
-  const uint32_t rs_tile = rec32 ? (uint32_t)RS32_TILE : (uint32_t)RS_TILE;
+  const uint32_t rs_tile = rec32 ? rs32_tile(log_sub) : (uint32_t)RS_TILE;
   const uint32_t tiles_per_region = (cap1 + rs_tile - 1) / rs_tile;
   const uint32_t cap_pg =
       two_level ? (region_cap(sub_kmers_ub, n_pages, rec32 ? 0 : tiles_per_region) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u) : cap1;
@@ -1181,7 +1197,6 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   const size_t lds_rs = (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12;
   const size_t lds_s32 = scatter32_lds(P1);
   const bool lds32 = use_scatter32(c, pg);
-  const size_t lds_rs32 = (size_t)RS32_TILE * 4 + (size_t)RS32_TILE * 2 + (size_t)S * 12;
   const uint32_t lane_lo = multi ? 0 : b.lane0, lane_hi = multi ? c->n_lanes : b.lane0 + 1;
   // deferred: page regions and cursors are the accumulation ones and persist; only a level-1 pass
   // has cursors of its own
@@ -1218,24 +1233,16 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
     }
     if (two_level) {
       ScopedTimer t(c, SHK_K_PSCAN, /*chain=*/true);  // timer slot reused: the level-2 re-scatter
-      if (rec32 && lds_rs32 > 64 * 1024) {  // > 64 KiB of dynamic LDS has to be asked for
-        if (!c->lds_attr_rescatter) {
-          HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_rescatter32),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
-          c->lds_attr_rescatter = true;
-        }
+      if (rec32 && defer) {  // append to this lane's accumulation regions
+        int rcl = launch_rescatter32(c, P1, (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, log_sub, r1_bits,
+                                     (unsigned int *)c->acc_cur.p, c->acc_cap, (uint32_t *)c->acc_buf.p, lane, sp, (uint64_t)lane * n_pages,
+                                     (uint64_t)NL * n_pages, 31u, 0u, 0ull);
+        if (rcl != SHK_OK) return rcl;
+      } else if (rec32) {
+        int rcl = launch_rescatter32(c, P1, (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, log_sub, r1_bits, cursor_pg,
+                                     cap_pg, (uint32_t *)buf_pg.p, lane, sp, 0ull, (uint64_t)n_pages, 31u, 0u, 0ull);
+        if (rcl != SHK_OK) return rcl;
       }
-      if (rec32 && defer)  // append to this lane's accumulation regions
-        hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS32_NT), lds_rs32, c->stream,
-                           (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
-                           log_sub, r1_bits, 2 * c->cfg.k, (unsigned int *)c->acc_cur.p, c->acc_cap,
-                           (uint32_t *)c->acc_buf.p, lane, c->d_stats, sp, (uint64_t)lane * n_pages,
-                           (uint64_t)NL * n_pages, 31u, 0u, 0ull);
-      else if (rec32)
-        hipLaunchKernelGGL(k_part_rescatter32, dim3(P1 * tiles_per_region), dim3(RS32_NT), lds_rs32, c->stream,
-                           (const uint32_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region,
-                           log_sub, r1_bits, 2 * c->cfg.k, cursor_pg, cap_pg, (uint32_t *)buf_pg.p, lane,
-                           c->d_stats, sp, 0ull, (uint64_t)n_pages, 31u, 0u, 0ull);
       else if (defer)  // append to this lane's accumulation regions (8-byte records)
         hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
                            (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
@@ -1694,11 +1701,8 @@ void shk_destroy(shk_ctx *c) {
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   c->in_bases.release();
   c->in_offsets.release();
-  c->in_bases2.release();
-  c->in_offsets2.release();
-  c->in_bases3.release();
-  c->in_offsets3.release();
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < shk_ctx::NST; ++i) c->st_bases[i].release(), c->st_offsets[i].release();
+  for (int i = 0; i < shk_ctx::NST; ++i) {
     c->h_rebased[i].release();
     if (c->copy_done[i]) (void)hipEventDestroy(c->copy_done[i]);
   }
@@ -1716,7 +1720,7 @@ void shk_destroy(shk_ctx *c) {
   c->acc_cur.release();
   c->xbuf.release();
   c->xspill.release();
-  for (int i = 0; i < 3; ++i) c->pk_stage[i].release(), c->nm_stage[i].release(), c->nz_dev[i].release(), c->nz_host[i].release();
+  for (int i = 0; i < shk_ctx::NST; ++i) c->pk_stage[i].release(), c->nm_stage[i].release(), c->nz_dev[i].release(), c->nz_host[i].release();
   c->pk_ascii.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1847,21 +1851,23 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   const size_t n_slices = cut.size() - 1;
   if (!c->copy_stream) HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   if (!c->copy_done[0])
-    for (int i = 0; i < 3; ++i) HIPC(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
+    for (int i = 0; i < shk_ctx::NST; ++i) HIPC(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
   bool offsets_pinned = false;
   {
     hipPointerAttribute_t at{};
     if (hipPointerGetAttributes(&at, offsets) == hipSuccess) offsets_pinned = at.type == hipMemoryTypeHost;
     else (void)hipGetLastError();  // (ordinary host memory: not an error)
   }
-  // THREE staging sets, taken in turn across slices and across calls: while slice i is counted, the copies of
-  // slices i+1 and i+2 are queued on the copy stream, so the link never waits for the host to come back from a
-  // counting launch — and the set a call starts with is never the one the previous call's last launch (which
-  // nobody may have waited for: SHK_FLAG_DEFER_ERRORS) is still reading.
+  // NST staging sets, taken in turn across slices and across calls: while slice i is counted, the copies of slices
+  // i+1 … i+NST−1 are queued on the copy stream, so the link does not wait for the host to come back from a counting
+  // launch — nor from a deferred page pass of a large table, which holds the host for several slices' worth of copy
+  // time (config 3: ≈ 10-20 ms against 5 ms per slice) — and the set a call starts with is never the one the previous
+  // call's last launch (which nobody may have waited for: SHK_FLAG_DEFER_ERRORS) is still reading.
+  constexpr int NST = shk_ctx::NST;
   const uint32_t s0 = c->stage_next;
-  auto set_of = [&](size_t i) { return (int)((s0 + i) % 3); };
-  auto bases_of = [&](int sel) -> DevBuf & { return sel == 0 ? c->in_bases : sel == 1 ? c->in_bases2 : c->in_bases3; };
-  auto offs_of = [&](int sel) -> DevBuf & { return sel == 0 ? c->in_offsets : sel == 1 ? c->in_offsets2 : c->in_offsets3; };
+  auto set_of = [&](size_t i) { return (int)((s0 + i) % NST); };
+  auto bases_of = [&](int sel) -> DevBuf & { return c->st_bases[sel]; };
+  auto offs_of = [&](int sel) -> DevBuf & { return c->st_offsets[sel]; };
   auto issue_copy = [&](size_t i) -> int {
     const int bsel = set_of(i);
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
@@ -1909,10 +1915,13 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     HIPC(c, hipEventRecord(c->copy_done[bsel], c->copy_stream));
     return SHK_OK;
   };
-  // (sets s0 and s0+1 were last read by launches that a later launch of the previous call has waited for)
-  int rc = issue_copy(0);
-  if (rc == SHK_OK && n_slices > 1) rc = issue_copy(1);
-  if (rc != SHK_OK) return rc;
+  // (sets s0 … s0+NST−2 were last read by launches that a later launch of the previous call has waited for)
+  int rc = SHK_OK;
+  for (size_t i = 0; i < std::min<size_t>(n_slices, NST - 1) && rc == SHK_OK; ++i) rc = issue_copy(i);
+  if (rc != SHK_OK) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    return rc;
+  }
   const bool trace = env_int("SHK_HOST_TRACE", 0) != 0;
   const auto t_begin = std::chrono::steady_clock::now();
   auto now_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
@@ -1921,7 +1930,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     const double ta = now_us();
     HIPC(c, hipEventSynchronize(c->copy_done[bsel]));  // `rebased[bsel]` consumed; data resident
     if (trace) fprintf(stderr, "[slice %zu] copy waited %.0f us (at %.0f)", i, now_us() - ta, now_us());
-    // slice i-1 (launched without a host sync) read the set that slice i+2 is about to overwrite
+    // slice i-1 (launched without a host sync) read the set that slice i+NST-1 is about to overwrite
     rc = settle_light(c);
     if (rc != SHK_OK) {
       (void)hipStreamSynchronize(c->copy_stream);
@@ -1929,9 +1938,12 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     }
     HIPC(c, hipStreamSynchronize(c->stream));
     if (trace) fprintf(stderr, " count(i-1) done at %.0f\n", now_us());
-    if (i + 2 < n_slices) {
-      rc = issue_copy(i + 2);
-      if (rc != SHK_OK) return rc;
+    if (i + NST - 1 < n_slices) {
+      rc = issue_copy(i + NST - 1);
+      if (rc != SHK_OK) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        return rc;
+      }
     }
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
     DevBuf &db = bases_of(bsel);
@@ -1951,7 +1963,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
       return rc;
     }
   }
-  c->stage_next = (s0 + (uint32_t)n_slices) % 3;
+  c->stage_next = (s0 + (uint32_t)n_slices) % NST;
   // A host-buffer ingest reports its errors (an invalid byte) before returning — unless the caller asked for
   // the device-buffer behaviour (SHK_FLAG_DEFER_ERRORS): then the last slice's launch is looked at by the next
   // call, whose first copies run under it.

@@ -127,6 +127,7 @@ class OwnerCounter:
         self.round_bases = int(round_bases)
         self._recv = None
         self._wide = None   # rounds take the wide route (engine.xchg_feasible() is False)
+        self._trace = [0.0, 0.0, 0.0, 0] if os.environ.get("SHK_DIST_TRACE") else None
         self.n_rounds = 0
         self.n_foreign_rounds = 0   # rounds in which somebody had foreign spills to hand on
         self.wire_bytes = 0
@@ -155,6 +156,10 @@ class OwnerCounter:
         if self._wide:
             return self._round_wide(batch)
         err = None
+        tr = self._trace
+        if tr is not None:
+            import time as _t
+            t_in = _t.perf_counter()
         try:
             if batch is not None:
                 self.eng.set_read_index(batch[4])
@@ -163,10 +168,14 @@ class OwnerCounter:
                 rec, cur, lay, n_foreign = self.eng.xchg_scatter_tensors(0, 0, 0, 0, self.round_bases)
         except Exception as e:  # noqa: BLE001 — reported to every rank below
             err, n_foreign = e, 0
+        if tr is not None:
+            t_sc = _t.perf_counter()
         with self._on_engine_stream():
             st = self._dev(torch.tensor([1 if err is not None else 0, n_foreign], dtype=torch.int64))
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
             any_err, any_foreign = (int(x) for x in st.cpu())
+            if tr is not None:
+                t_ar = _t.perf_counter()
             if any_err:
                 raise err if err is not None else RuntimeError("a peer rank failed in this exchange round")
             if self._recv is None or self._recv[0].numel() != rec.numel() or self._recv[1].numel() != cur.numel():
@@ -184,6 +193,12 @@ class OwnerCounter:
             if any_foreign:
                 self.n_foreign_rounds += 1
                 self._exchange_spills()
+        if tr is not None:   # host-side phases of the round (SHK_DIST_TRACE): scatter incl. its sync, flags, exchange + absorb launches
+            t_out = _t.perf_counter()
+            tr[0] += t_sc - t_in
+            tr[1] += t_ar - t_sc
+            tr[2] += t_out - t_ar
+            tr[3] += 1
         self.n_rounds += 1
         self.wire_bytes += (W - 1) * (lay.segment_records + lay.regions) * 4
         return lay
@@ -263,6 +278,12 @@ class OwnerCounter:
 
     def finalize_histograms(self):
         dist = self.dist
+        if self._trace is not None and self._trace[3]:
+            import sys
+            a, b, c, n = self._trace
+            print(f"[shk] OwnerCounter rank {self.rank}: {n} rounds, host ms per round: scatter+sync {a / n * 1e3:.3f}, flags {b / n * 1e3:.3f}, "
+                  f"exchange+absorb launches {c / n * 1e3:.3f}", file=sys.stderr)
+            self._trace = [0.0, 0.0, 0.0, 0]
         err = None
         try:
             self.eng.finalize()

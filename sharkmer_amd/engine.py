@@ -354,6 +354,13 @@ class KmerEngine:
         self._check(self._L.shk_ingest_packed(self._h, pk.packed.ctypes.data, pk.nmask.ctypes.data,
                                               pk.offsets.ctypes.data, len(pk.offsets) - 1))
 
+    def ingest_packed_slice(self, pk: "PackedReads", first_seq: int, n_seqs: int):
+        """shk_ingest_packed over reads [first_seq, first_seq + n_seqs) of a packed batch: the offsets are positions in
+        the batch's streams, so a slice is the same two streams and a window of the offsets."""
+        assert 0 <= first_seq and first_seq + n_seqs <= len(pk.offsets) - 1
+        self._check(self._L.shk_ingest_packed(self._h, pk.packed.ctypes.data, pk.nmask.ctypes.data,
+                                              pk.offsets.ctypes.data + 8 * first_seq, n_seqs))
+
     def ingest_packed_device(self, d_packed: int, d_nmask: int, d_offsets: int, n_seqs: int, n_bases: int):
         self._check(self._L.shk_ingest_packed_device(self._h, d_packed, d_nmask, d_offsets, n_seqs, n_bases))
 
