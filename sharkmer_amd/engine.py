@@ -774,16 +774,25 @@ class PackedReads:
         return self.packed.nbytes + self.offsets.nbytes + mask
 
 
-def pack_reads(bases: np.ndarray, offsets: np.ndarray, threads: int = 0, pinned: bool = False) -> PackedReads:
+def pack_reads(bases: np.ndarray, offsets: np.ndarray, threads: int = 0, pinned: bool = False, out: "PackedReads" = None) -> PackedReads:
     """shk_pack_reads over a batch of concatenated ASCII reads (host, multi-threaded).  pinned: the
     output arrays live in pinned host memory (shk_alloc_pinned), owned by the PackedReads: close() — or dropping the
-    object — gives them back."""
-    L = load_library() if pinned else load_front_library()
+    object — gives them back.  out: a PackedReads of the same shape (a batch packed before) whose arrays are written
+    again — a caller that streams batches pins its buffers once."""
+    L = load_library() if (pinned or (out is not None and out._pinned)) else load_front_library()
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = int(offsets[-1]) if len(offsets) else 0
     assert len(offsets) == 0 or int(offsets[0]) == 0
     nb, nw = (n + 3) // 4, (n + 31) // 32
+    if out is not None:
+        assert out.packed.size == nb and out.nmask.size == nw and out.offsets.size == len(offsets), "out: another batch shape"
+        out.offsets[:] = offsets
+        rc = L.shk_pack_reads(bases.ctypes.data, n, out.packed.ctypes.data, out.nmask.ctypes.data, threads)
+        if rc != 0:
+            raise ShkError(rc, (L.shk_run_error() or b"").decode("utf-8", "replace"))
+        out.n_bases = n
+        return out
     if pinned:
         pp = L.shk_alloc_pinned(max(nb, 1) + 16)
         pm = L.shk_alloc_pinned(max(nw, 1) * 4 + 16)

@@ -81,6 +81,13 @@ def test_pack_threads_agree_and_first_invalid_byte_wins():
     o = np.array([0, n], dtype=np.uint64)
     one, many = sa.pack_reads(b, o, threads=1), sa.pack_reads(b, o, threads=7)
     assert np.array_equal(one.packed, many.packed) and np.array_equal(one.nmask, many.nmask)
+    # out=: the arrays of a batch packed before are written again (a streaming caller pins its buffers once)
+    b2 = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=n)].copy()
+    again = sa.pack_reads(b2, o, threads=5, out=many)
+    fresh = sa.pack_reads(b2, o, threads=1)
+    assert again is many and np.array_equal(many.packed, fresh.packed) and np.array_equal(many.nmask, fresh.nmask)
+    with pytest.raises(AssertionError, match="another batch shape"):
+        sa.pack_reads(b2[:1000], np.array([0, 1000], dtype=np.uint64), out=many)
     b[2_000_001] = ord("y")
     b[1_234_567] = ord("x")   # the first offender in input order is the one reported (encoding.rs:353-356)
     with pytest.raises(sa.ShkError, match="Invalid character 'x' in sequence. Only ACGTN allowed."):
