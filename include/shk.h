@@ -348,7 +348,9 @@ int shk_set_owned_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1);
  *      records written, grouped by owner, into the context's exchange buffer: owner o's SEGMENT is
  *      d_records + o·layout.segment_records (u32 records) with its fill levels at d_cursors + o·layout.regions
  *      (u32 words) — one contiguous piece each, so "send every peer its segment" is one all-to-all with
- *      equal splits (or W−1 peer copies).  The call returns when the kernel is done: *n_foreign_spilled
+ *      equal splits (or W−1 peer copies).  The context has TWO exchange buffers and takes them in turn: what a
+ *      call hands out stays valid until the next call BUT ONE, so round r's segments can be on the links while
+ *      round r + 1 is scattered.  The call returns when the kernel is done: *n_foreign_spilled
  *      is the fill of the context's foreign spill list (records that overflowed a region on skewed input;
  *      shk_xchg_spill), an invalid byte is reported here (SHK_ERR_INVALID_CHAR) and poisons the context.
  *   2. the caller moves segment o to rank o (RCCL all_to_all / hipMemcpyPeer), rank r's own segment
@@ -361,7 +363,8 @@ int shk_set_owned_pages(shk_ctx *ctx, uint64_t p0, uint64_t p1);
  * every rank hands every other rank's list to shk_insert_device (which drops what the context does
  * not own) and then calls shk_xchg_spill_clear.  All of it is exact for any input.
  * Needs 4-byte records at the exchange geometry: 2k − layout.log_p1 ≤ 32 (k ≤ 21 at the default
- * fan-out of 1024); otherwise SHK_ERR_STATE — merge the tables at finalize instead (shk_merge_*). */
+ * fan-out of 1024); otherwise SHK_ERR_STATE — take the wide round (shk_xchg_wide_scatter_device below) or merge
+ * the tables at finalize instead (shk_merge_*). */
 #define SHK_XCHG_MAX_BASES (1ull << 28)
 typedef struct shk_xchg_layout {
   uint32_t n_owners;        /* W */

@@ -163,6 +163,7 @@ struct shk_ctx {
   DevBuf xw_kmers, xw_lanes, xw_count;  // the wide exchange round's output (shk_xchg_wide_scatter_device)
   HostBuf nz_host[NST];             // … and the non-zero words of a slice's N mask, when they are few (index, word)  // packed input: the staged streams of a slice; a whole batch unpacked (device-resident packed ingest)
   DevBuf xbuf, xspill;            // owner layout: the level-1 records of a launch by [owner][lane][super-page]; the foreign spill list
+  DevBuf xbuf_alt, part_meta_alt;  // the OTHER exchange buffer and cursor block: shk_xchg_scatter_device takes the two in turn
   uint64_t xspill_cap = 0;
   // host counters
   std::vector<uint64_t> lane_reads;
@@ -1719,6 +1720,8 @@ void shk_destroy(shk_ctx *c) {
   c->acc_buf.release();
   c->acc_cur.release();
   c->xbuf.release();
+  c->xbuf_alt.release();
+  c->part_meta_alt.release();
   c->xspill.release();
   for (int i = 0; i < shk_ctx::NST; ++i) c->pk_stage[i].release(), c->nm_stage[i].release(), c->nz_dev[i].release(), c->nz_host[i].release();
   c->pk_ascii.release();
@@ -2129,6 +2132,14 @@ int shk_xchg_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offse
     return fail(c, SHK_ERR_BAD_ARG, "an exchange batch takes at most %llu bases", (unsigned long long)SHK_XCHG_MAX_BASES);
   XchgOut xo{};
   xo.layout_bases = layout_bases;
+  // Two exchange buffers, taken in turn: what this call hands out stays valid until the next call BUT ONE, so the
+  // caller can have round r's segments on the links (another stream, peers pulling) while round r+1 is scattered.
+  {
+    int rcs = settle_light(c);  // (the previous launch may still be reading the cursor block about to be swapped out)
+    if (rcs != SHK_OK) return rcs;
+  }
+  std::swap(c->xbuf, c->xbuf_alt);
+  std::swap(c->part_meta, c->part_meta_alt);
   int rc = ingest_core(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_seqs, n_bases, c->xchg_lane_fixed, &xo);
   if (rc != SHK_OK) return rc;
   *d_records = xo.d_records;

@@ -109,9 +109,13 @@ class OwnerCounter:
          foreign spills — records that overflowed a region on skewed input — are all-gathered and every
          rank inserts what it owns: exact for any input.
     Bytes on a link per round: one segment = regions × region_cap × 4 B ≈ 1.25 (× 1.5 with several
-    lanes) × 4 B × 0.87 × batch bases / W.  With a CUDA engine the collectives are queued on the engine's
-    own HIP stream (torch.cuda.ExternalStream), so a round needs no host-side synchronisation besides the
-    one the scatter does to report its outcome.
+    lanes) × 4 B × 0.87 × batch bases / W — at configs[3]'s shape 137 MB per link and round against ≈ 1.3 ms of
+    counting per round: the links are the bottleneck of a round taken step by step.  So the rounds are PIPELINED: with a
+    CUDA engine the collectives run on a stream of their own, step 3 of round r is deferred until round r + 1 has
+    scattered (the engine hands its exchange buffers out in turn; the receive buffers here come in two sets), and
+    events order the two streams where they meet — round r's segments cross the links while the engine absorbs
+    round r − 1 and scatters round r + 1.  The host waits twice per round: for the scatter's outcome and for the
+    2-word flags.
 
     finalize_histograms: every rank's histogram covers its share; bins are additive across disjoint key
     sets (KmerCounts::extend, counting.rs:157-166), so one all_reduce(SUM) of histogram + totals
@@ -125,7 +129,10 @@ class OwnerCounter:
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.device = device
         self.round_bases = int(round_bases)
-        self._recv = None
+        self._recv = [None, None]   # receive buffers of the rounds' exchanges, two sets taken in turn
+        self._absorbed = [None, None]   # … and the events behind the absorbs that read them last
+        self._pending = None   # the round whose exchange is in flight: absorbed at the next round or at finalize
+        self._comm = None
         self._wide = None   # rounds take the wide route (engine.xchg_feasible() is False)
         self._trace = [0.0, 0.0, 0.0, 0] if os.environ.get("SHK_DIST_TRACE") else None
         self.n_rounds = 0
@@ -135,12 +142,36 @@ class OwnerCounter:
     def _dev(self, t):
         return t if self.device is None else t.to(f"cuda:{self.device}")
 
+    def _engine_stream(self):
+        if self.device is None:
+            return None
+        return torch.cuda.ExternalStream(self.eng.stream(), device=f"cuda:{self.device}")
+
     def _on_engine_stream(self):
+        import contextlib
+        ext = self._engine_stream()
+        return contextlib.nullcontext() if ext is None else torch.cuda.stream(ext)
+
+    # The exchange's own stream: round r's collectives run under the scatter of round r + 1 and the absorbs of round
+    # r − 1 on the engine's stream; events order the two where they meet (receive buffers, two sets taken in turn).
+    def _on_comm_stream(self):
         import contextlib
         if self.device is None:
             return contextlib.nullcontext()
-        ext = torch.cuda.ExternalStream(self.eng.stream(), device=f"cuda:{self.device}")
-        return torch.cuda.stream(ext)
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=f"cuda:{self.device}")
+        return torch.cuda.stream(self._comm)
+
+    def _wait_on_comm(self, ev):
+        if ev is not None and self._comm is not None:
+            self._comm.wait_event(ev)
+
+    def _record_on_comm(self):
+        if self._comm is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._comm)
+        return ev
 
     def round(self, batch=None):
         """batch = (bases, offsets, n_seqs, n_bases, first_read_index) — device pointers for the HIP
@@ -170,28 +201,35 @@ class OwnerCounter:
             err, n_foreign = e, 0
         if tr is not None:
             t_sc = _t.perf_counter()
-        with self._on_engine_stream():
+        # What the engine counts while this round's flags and segments travel: the round BEFORE — its exchange ran
+        # under this round's scatter — and then the next round's scatter (the engine hands its exchange buffers out
+        # in turn: include/shk.h, shk_xchg_scatter_device).  Launched first, so the host's wait for the flags below
+        # costs the GPU nothing.
+        self._absorb_pending()
+        r2 = self.n_rounds & 1
+        with self._on_comm_stream():
             st = self._dev(torch.tensor([1 if err is not None else 0, n_foreign], dtype=torch.int64))
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
-            any_err, any_foreign = (int(x) for x in st.cpu())
+            any_err, any_foreign = (int(x) for x in st.cpu())   # (in stream order behind the previous round's exchange: it has arrived)
             if tr is not None:
                 t_ar = _t.perf_counter()
             if any_err:
                 raise err if err is not None else RuntimeError("a peer rank failed in this exchange round")
-            if self._recv is None or self._recv[0].numel() != rec.numel() or self._recv[1].numel() != cur.numel():
-                self._recv = (torch.empty_like(rec), torch.empty_like(cur))
-            rrec, rcur = self._recv
-            S, G = lay.segment_records, lay.regions
+            if self._recv[r2] is None or self._recv[r2][0].numel() != rec.numel() or self._recv[r2][1].numel() != cur.numel():
+                self._recv[r2] = (torch.empty_like(rec), torch.empty_like(cur))
+            rrec, rcur = self._recv[r2]
+            S = lay.segment_records
             # a segment above the message limit travels in pieces, and the rank's own segment then does not travel at
             # all: it is absorbed where the scatter left it (shk.h: "rank r's own segment needs no copy")
             big = S * rec.element_size() > MAX_MESSAGE_BYTES and hasattr(dist, "batch_isend_irecv")
+            self._wait_on_comm(self._absorbed[r2])   # these receive buffers were read by the absorbs of round r − 2
             exchange_parts(dist, rrec, rec, W, self.rank, skip_self=True)
             dist.all_to_all_single(rcur, cur)
-            for s in range(W):
-                src = rec if (big and s == self.rank) else rrec
-                self.eng.xchg_absorb_tensors(src[s * S:(s + 1) * S], rcur[s * G:(s + 1) * G], lay)
-            if any_foreign:
-                self.n_foreign_rounds += 1
+            arrived = self._record_on_comm()
+        self._pending = (rec, cur, rrec, rcur, lay, big, arrived, r2)   # (on the links now; absorbed by the next round)
+        if any_foreign:
+            self.n_foreign_rounds += 1
+            with self._on_comm_stream():
                 self._exchange_spills()
         if tr is not None:   # host-side phases of the round (SHK_DIST_TRACE): scatter incl. its sync, flags, exchange + absorb launches
             t_out = _t.perf_counter()
@@ -202,6 +240,25 @@ class OwnerCounter:
         self.n_rounds += 1
         self.wire_bytes += (W - 1) * (lay.segment_records + lay.regions) * 4
         return lay
+
+    def _absorb_pending(self):
+        """The level-2 pass over every segment of the round whose exchange was queued last (engine stream, behind the
+        exchange's completion)."""
+        if self._pending is None:
+            return
+        rec, cur, rrec, rcur, lay, big, arrived, r2 = self._pending
+        self._pending = None
+        S, G = lay.segment_records, lay.regions
+        ext = self._engine_stream()
+        if ext is not None and arrived is not None:
+            ext.wait_event(arrived)
+        for s in range(self.world):
+            src = rec if (big and s == self.rank) else rrec
+            self.eng.xchg_absorb_tensors(src[s * S:(s + 1) * S], rcur[s * G:(s + 1) * G], lay)
+        if ext is not None:
+            ev = torch.cuda.Event()
+            ev.record(ext)
+            self._absorbed[r2] = ev
 
     def _round_wide(self, batch):
         """The round for k-mers that do not fit the owner layout's 4-byte records (k > 21 at the default fan-out;
@@ -278,6 +335,7 @@ class OwnerCounter:
 
     def finalize_histograms(self):
         dist = self.dist
+        self._absorb_pending()
         if self._trace is not None and self._trace[3]:
             import sys
             a, b, c, n = self._trace

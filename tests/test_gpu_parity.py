@@ -2,6 +2,8 @@
 ctypes shim over include/shk.h), against the CPU oracle on identical inputs.  Bit-exact:
 every comparison is integer equality.  Test names follow the reference's own tests
 (src/kmer/mod.rs, src/kmer/counting.rs, tests/spcr_18s.rs) where they mirror one."""
+import os
+
 import numpy as np
 import pytest
 
@@ -488,11 +490,13 @@ def test_config4_share_on_a_table_of_2_33_slots(orc):
     """BASELINE.json configs[3]'s table on one GPU: a 3 Gb genome is a 2^33-slot table (2^20 pages,
     the most the geometry allows: page bits + 11 home-bucket bits out of 32 hash bits; 103 GB), the
     partition has two full levels (1024 × 1024) and everything is counted by deferred page passes.
-    24 M reads of one GPU's share; properties, plus an EXACT probe set (10^5 k-mers of sampled reads,
+    ALL 125 M reads of one GPU's share (SHK_SHARE4_READS: fewer, for a quick look; 28 s on the box, most of it the
+    oracle's extractor over the reads on 16 CPUs); properties, plus an EXACT probe set (10^5 k-mers of sampled reads,
     counted over all the reads by the oracle's extractor) against point lookups: the global-memory probe
     must find what the page workgroups inserted, with exactly the right count."""
     from probe_util import ProbeChecker
-    n, L, k, batch = 24_000_000, 150, 21, 4_000_000
+    n, L, k, batch = int(os.environ.get("SHK_SHARE4_READS", 125_000_000)), 150, 21, 5_000_000
+    assert n % batch == 0 and n >= 6 * batch
     spec = sa.SynthSpec(genome_len=3_000_000_000, read_len=L)
     pc = ProbeChecker(orc, k, 1, L)
     with sa.KmerEngine(k, 1, 1000, capacity_hint=3_000_000_000) as eng:
