@@ -412,6 +412,12 @@ void *shk_alloc_pinned(size_t bytes);
 void shk_free_pinned(void *p);
 void *shk_alloc_device(shk_ctx *ctx, size_t bytes);
 void shk_free_device(shk_ctx *ctx, void *p);
+/* Blocks of device and pinned host memory that a context (or shk_free_pinned) gives back are kept by the process —
+ * a bounded amount: 4 GiB per process on the devices, 512 MiB pinned, no block above 1 GiB / 160 MiB — and handed to
+ * the next request of about their size: mapping and unmapping memory is what setting a context up and taking it down
+ * costs (17-19 ms of an 80 ms FASTQ job).  This call gives everything back to the driver; the environment variable
+ * SHK_NO_MEM_CACHE=1 turns the keeping off.  (The reference has no counterpart: its allocator is the process's.) */
+void shk_release_cached_memory(void);
 
 /* ---- synthetic reads, generated on device ------------------------ */
 

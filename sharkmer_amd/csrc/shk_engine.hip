@@ -17,8 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace shk;
@@ -63,21 +65,135 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// ---- a process-wide cache of device and pinned-host blocks -------------------------------------------------
+// hipMalloc / hipFree and hipHostMalloc / hipHostFree map and unmap memory: ≈ 45-110 µs per MB of pinned memory, a few
+// hundred µs per device block, all of it serialised on the process's address space.  A job of 1.2 Gbases out of a FASTQ
+// file spent 17-19 ms of its 80 taking a context and its batch buffers down again, and a few more setting them up.
+// Blocks that are given back are therefore kept (per device, a bounded amount) and handed to the next request of about
+// their size — the next context of the process starts with warm memory.  Nothing in the engine relies on what a fresh
+// block holds.  shk_release_cached_memory() gives everything back; SHK_NO_MEM_CACHE=1 turns the cache off.
+struct MemCache {
+  struct Blk {
+    int dev;  // device (−1: pinned host memory)
+    size_t bytes;
+    void *p;
+  };
+  std::mutex m;
+  std::vector<Blk> blocks;
+  size_t dev_total = 0, host_total = 0;
+  std::unordered_map<void *, size_t> pinned_out;  // shk_alloc_pinned blocks in the caller's hands → their size
+  // … and idle streams: destroying the stream a context's host copies ran on takes 6-7 ms (its queues go with it)
+  std::vector<std::pair<int, hipStream_t>> streams;
+};
+static MemCache &mem_cache() {
+  static MemCache *c = new MemCache;  // (never destroyed: no HIP call may run from a static destructor at exit)
+  return *c;
+}
+constexpr size_t DEV_CACHE_MAX = 4ull << 30, DEV_BLOCK_MAX = 1ull << 30, HOST_CACHE_MAX = 512ull << 20, HOST_BLOCK_MAX = 160ull << 20;
+static bool mem_cache_on() {
+  static const bool on = getenv("SHK_NO_MEM_CACHE") == nullptr;
+  return on;
+}
+// a cached block of at least `bytes` (and not much more) for device `dev` (−1: pinned host), or nullptr
+static void *cache_take(int dev, size_t bytes, size_t *got) {
+  if (!mem_cache_on()) return nullptr;
+  MemCache &mc = mem_cache();
+  std::lock_guard<std::mutex> lk(mc.m);
+  size_t best = ~(size_t)0;
+  for (size_t i = 0; i < mc.blocks.size(); ++i) {
+    const MemCache::Blk &b = mc.blocks[i];
+    if (b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 2 + 65536 && (best == ~(size_t)0 || b.bytes < mc.blocks[best].bytes)) best = i;
+  }
+  if (best == ~(size_t)0) return nullptr;
+  const MemCache::Blk b = mc.blocks[best];
+  mc.blocks.erase(mc.blocks.begin() + (long)best);
+  (dev < 0 ? mc.host_total : mc.dev_total) -= b.bytes;
+  *got = b.bytes;
+  return b.p;
+}
+static bool cache_give(int dev, void *p, size_t bytes) {
+  if (!mem_cache_on()) return false;
+  MemCache &mc = mem_cache();
+  std::lock_guard<std::mutex> lk(mc.m);
+  size_t &total = dev < 0 ? mc.host_total : mc.dev_total;
+  if (bytes > (dev < 0 ? HOST_BLOCK_MAX : DEV_BLOCK_MAX) || total + bytes > (dev < 0 ? HOST_CACHE_MAX : DEV_CACHE_MAX) || mc.blocks.size() >= 256) return false;
+  mc.blocks.push_back(MemCache::Blk{dev, bytes, p});
+  total += bytes;
+  return true;
+}
+static hipError_t stream_take(hipStream_t *st) {  // a non-blocking stream on the current device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (mem_cache_on()) {
+    MemCache &mc = mem_cache();
+    std::lock_guard<std::mutex> lk(mc.m);
+    for (size_t i = 0; i < mc.streams.size(); ++i)
+      if (mc.streams[i].first == dev) {
+        *st = mc.streams[i].second;
+        mc.streams.erase(mc.streams.begin() + (long)i);
+        return hipSuccess;
+      }
+  }
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+static void stream_give(hipStream_t st) {  // (idle: the caller has synchronised it)
+  if (!st) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (mem_cache_on()) {
+    MemCache &mc = mem_cache();
+    std::lock_guard<std::mutex> lk(mc.m);
+    if (mc.streams.size() < 16) {
+      mc.streams.emplace_back(dev, st);
+      return;
+    }
+  }
+  (void)hipStreamDestroy(st);
+}
+static hipError_t dev_alloc(void **p, size_t bytes, size_t *got) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if ((*p = cache_take(dev, bytes, got))) return hipSuccess;
+  *got = bytes;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess && mem_cache_on()) {  // out of memory with blocks lying idle in the cache: give them back and try again
+    (void)hipGetLastError();
+    shk_release_cached_memory();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+static void dev_free(void *p, size_t bytes) {
+  if (!p) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  // (hipFree waits for the device; a block that goes to the cache instead must be as idle as one that is freed)
+  if (mem_cache_on() && bytes <= DEV_BLOCK_MAX && hipDeviceSynchronize() == hipSuccess && cache_give(dev, p, bytes)) return;
+  (void)hipFree(p);
+}
+static hipError_t host_alloc(void **p, size_t bytes, size_t *got) {
+  if ((*p = cache_take(-1, bytes, got))) return hipSuccess;
+  *got = bytes;
+  return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+static void host_free(void *p, size_t bytes) {
+  if (!p) return;
+  if (cache_give(-1, p, bytes)) return;
+  (void)hipHostFree(p);
+}
+
 struct DevBuf {  // grow-only device scratch
   void *p = nullptr;
   size_t cap = 0;
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = bytes + bytes / 8 + 4096;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
+    release();
+    hipError_t e = dev_alloc(&p, bytes + bytes / 8 + 4096, &cap);
+    if (e != hipSuccess) p = nullptr, cap = 0;
     return e;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    dev_free(p, cap);
     p = nullptr;
     cap = 0;
   }
@@ -88,16 +204,13 @@ struct HostBuf {  // grow-only pinned host scratch
   size_t cap = 0;
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = bytes + bytes / 8 + 4096;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-    if (e == hipSuccess) cap = want;
+    release();
+    hipError_t e = host_alloc(&p, bytes + bytes / 8 + 4096, &cap);
+    if (e != hipSuccess) p = nullptr, cap = 0;
     return e;
   }
   void release() {
-    if (p) (void)hipHostFree(p);
+    host_free(p, cap);
     p = nullptr;
     cap = 0;
   }
@@ -136,7 +249,7 @@ struct shk_ctx {
   // reduction); the LIVE per-lane base counters the counting kernels add to lie in front of it, so that a repeated
   // _begin / reduce / _end never sums a sum — k_fin_extras copies them into the summed part every time.
   uint8_t *d_ctl = nullptr, *h_ctl = nullptr;
-  size_t ctl_bytes = 0, ctl_hist_off = 0, ctl_tot_off = 0;
+  size_t ctl_bytes = 0, ctl_hist_off = 0, ctl_tot_off = 0, ctl_alloc = 0, ctl_alloc_h = 0;
   unsigned long long *d_lane_sum = nullptr, *h_lane_sum = nullptr;
   DevStats *d_stats = nullptr;
   DevStats *h_stats = nullptr;
@@ -154,7 +267,7 @@ struct shk_ctx {
   hipStream_t copy_stream = nullptr;
   static constexpr int NST = 6;   // staging sets of a host-buffer ingest: NST − 1 slices' copies are queued ahead of the count
   hipEvent_t copy_done[NST] = {};
-  uint32_t stage_next = 0;        // which of the staging sets the next slice of a host-buffer ingest takes
+  int stage_last = -1;            // the staging set the last slice of the previous host-buffer ingest took (its count may still be in flight)
   bool zero_count_keys = false;   // some key may have been inserted with count 0 (shk_insert_counts, merges): k_histo reads the keys
   bool lds_attr_scatter = false, lds_attr_rescatter = false, lds_attr_scatter_own = false;  // hipFuncSetAttribute done for this context's device
   HostBuf h_rebased[NST];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
@@ -325,6 +438,14 @@ int tb_fresh(shk_ctx *c) {
   return fill_state(c, c->tb, false);
 }
 
+static void free_table(TableRef &t) {
+  // (a block from the cache may be larger than what was asked for: it goes back under the size it was asked at — the
+  // cache matches requests against that, and the table's arrays only ever ask for powers of two times a lane count)
+  dev_free(t.keys, t.cap * sizeof(uint64_t));
+  dev_free(t.vals, t.cap * sizeof(uint32_t) * t.n_lanes);
+  t.keys = nullptr;
+  t.vals = nullptr;
+}
 int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out, bool cleared = true) {
   TableRef t{};
   t.log_pages = log_pages;
@@ -333,10 +454,12 @@ int alloc_table(shk_ctx *c, uint32_t log_pages, TableRef *out, bool cleared = tr
   t.owner_bits = c->owner_bits;
   t.owner_id = c->owner_id;
   t.cap = (uint64_t)PAGE_SLOTS << log_pages;
-  HIPC(c, hipMalloc((void **)&t.keys, t.cap * sizeof(uint64_t)));
-  hipError_t e = hipMalloc((void **)&t.vals, t.cap * sizeof(uint32_t) * t.n_lanes);
+  size_t got = 0;  // (the table's arrays are asked for and given back at their exact sizes)
+  HIPC(c, dev_alloc((void **)&t.keys, t.cap * sizeof(uint64_t), &got));
+  hipError_t e = dev_alloc((void **)&t.vals, t.cap * sizeof(uint32_t) * t.n_lanes, &got);
   if (e != hipSuccess) {
-    (void)hipFree(t.keys);
+    (void)hipGetLastError();
+    dev_free(t.keys, t.cap * sizeof(uint64_t));
     return fail(c, SHK_ERR_NOMEM, "out of device memory allocating %llu-slot table (%u lanes)",
                 (unsigned long long)t.cap, t.n_lanes);
   }
@@ -367,8 +490,7 @@ int grow_to(shk_ctx *c, uint32_t new_log_pages) {
     hipLaunchKernelGGL(k_grow, dim3(grid_for(c->tb.cap, WG, 8192)), dim3(WG), 0, c->stream, c->tb, nt);
   }
   HIPC(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(c->tb.keys);
-  (void)hipFree(c->tb.vals);
+  free_table(c->tb);
   c->tb = nt;
   c->n_grows++;
   return SHK_OK;
@@ -1643,7 +1765,7 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
       return bail(e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP);                 \
     }                                                                                        \
   } while (0)
-  HIPB(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPB(stream_take(&c->stream));
   HIPB(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
   const size_t hist_n = (size_t)std::max<uint32_t>(cfg->chunks, 1) * (cfg->histo_max + 2);
   {
@@ -1652,8 +1774,8 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
     c->ctl_hist_off = (off + 15) & ~(size_t)15;
     c->ctl_bytes = (c->ctl_hist_off + hist_n * sizeof(unsigned long long) + 15) & ~(size_t)15;
   }
-  HIPB(hipMalloc((void **)&c->d_ctl, c->ctl_bytes));
-  HIPB(hipHostMalloc((void **)&c->h_ctl, c->ctl_bytes, hipHostMallocDefault));
+  HIPB(dev_alloc((void **)&c->d_ctl, c->ctl_bytes, &c->ctl_alloc));
+  HIPB(host_alloc((void **)&c->h_ctl, c->ctl_bytes, &c->ctl_alloc_h));
   memset(c->h_ctl, 0, c->ctl_bytes);
   c->d_stats = (DevStats *)c->d_ctl;
   c->h_stats = (DevStats *)c->h_ctl;
@@ -1692,14 +1814,19 @@ void shk_destroy(shk_ctx *c) {
   if (!c) return;
   if (c->group) return group_destroy(c);
   (void)hipSetDevice(c->cfg.device);
+  const auto t_d0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (trace_on()) fprintf(stderr, "[shk] destroy: %-22s at %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d0).count());
+  };
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   resolve_timings(c);
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
-  if (c->tb.keys) (void)hipFree(c->tb.keys);
-  if (c->tb.vals) (void)hipFree(c->tb.vals);
+  lap("synced, events gone");
+  if (c->tb.keys) free_table(c->tb);
+  lap("table given back");
   if (c->done_ev) (void)hipEventDestroy(c->done_ev);
-  if (c->d_ctl) (void)hipFree(c->d_ctl);
-  if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+  if (c->d_ctl) dev_free(c->d_ctl, c->ctl_alloc);
+  if (c->h_ctl) host_free(c->h_ctl, c->ctl_alloc_h);
   c->in_bases.release();
   c->in_offsets.release();
   for (int i = 0; i < shk_ctx::NST; ++i) c->st_bases[i].release(), c->st_offsets[i].release();
@@ -1707,7 +1834,12 @@ void shk_destroy(shk_ctx *c) {
     c->h_rebased[i].release();
     if (c->copy_done[i]) (void)hipEventDestroy(c->copy_done[i]);
   }
-  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  lap("control block, staging");
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    stream_give(c->copy_stream);
+  }
+  lap("copy stream destroyed");
   c->startbits.release();
   c->tiles.release();
   c->spillA.release();
@@ -1725,7 +1857,9 @@ void shk_destroy(shk_ctx *c) {
   c->xspill.release();
   for (int i = 0; i < shk_ctx::NST; ++i) c->pk_stage[i].release(), c->nm_stage[i].release(), c->nz_dev[i].release(), c->nz_host[i].release();
   c->pk_ascii.release();
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  lap("scratch given back");
+  if (c->stream) stream_give(c->stream);  // (synchronised at the top)
+  lap("stream destroyed");
   delete c;
 }
 
@@ -1854,7 +1988,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     cut.push_back(hi);
   }
   const size_t n_slices = cut.size() - 1;
-  if (!c->copy_stream) HIPC(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->copy_stream) HIPC(c, stream_take(&c->copy_stream));
   if (!c->copy_done[0])
     for (int i = 0; i < shk_ctx::NST; ++i) HIPC(c, hipEventCreateWithFlags(&c->copy_done[i], hipEventDisableTiming));
   bool offsets_pinned = false;
@@ -1868,9 +2002,12 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   // launch — nor from a deferred page pass of a large table, which holds the host for several slices' worth of copy
   // time (config 3: ≈ 10-20 ms against 5 ms per slice) — and the set a call starts with is never the one the previous
   // call's last launch (which nobody may have waited for: SHK_FLAG_DEFER_ERRORS) is still reading.
-  constexpr int NST = shk_ctx::NST;
-  const uint32_t s0 = c->stage_next;
-  auto set_of = [&](size_t i) { return (int)((s0 + i) % NST); };
+  // A call of few slices takes few sets (at least two: one may still be read by the previous call's last launch):
+  // a stream of one-slice calls — shk_run_files' 64 M-base batches — allocates two sets, not six (and frees two:
+  // tearing the context down was 14 ms of an 80 ms job with all six in use).
+  const int NST = (int)std::min<size_t>(shk_ctx::NST, std::max<size_t>(n_slices + 1, 2));
+  const uint32_t s0 = c->stage_last >= 0 ? (uint32_t)(c->stage_last + 1) % (uint32_t)NST : 0u;
+  auto set_of = [&](size_t i) { return (int)((s0 + i) % (uint32_t)NST); };
   auto bases_of = [&](int sel) -> DevBuf & { return c->st_bases[sel]; };
   auto offs_of = [&](int sel) -> DevBuf & { return c->st_offsets[sel]; };
   auto issue_copy = [&](size_t i) -> int {
@@ -1922,7 +2059,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   };
   // (sets s0 … s0+NST−2 were last read by launches that a later launch of the previous call has waited for)
   int rc = SHK_OK;
-  for (size_t i = 0; i < std::min<size_t>(n_slices, NST - 1) && rc == SHK_OK; ++i) rc = issue_copy(i);
+  for (size_t i = 0; i < std::min<size_t>(n_slices, (size_t)NST - 1) && rc == SHK_OK; ++i) rc = issue_copy(i);
   if (rc != SHK_OK) {
     (void)hipStreamSynchronize(c->copy_stream);
     return rc;
@@ -1968,7 +2105,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
       return rc;
     }
   }
-  c->stage_next = (s0 + (uint32_t)n_slices) % NST;
+  c->stage_last = set_of(n_slices - 1);
   // A host-buffer ingest reports its errors (an invalid byte) before returning — unless the caller asked for
   // the device-buffer behaviour (SHK_FLAG_DEFER_ERRORS): then the last slice's launch is looked at by the next
   // call, whose first copies run under it.
@@ -3138,11 +3275,53 @@ int shk_set_owner_share(shk_ctx *c, uint32_t n_owners, uint32_t owner) {
 
 void *shk_alloc_pinned(size_t bytes) {
   void *p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  size_t got = 0;
+  if (host_alloc(&p, bytes ? bytes : 1, &got) != hipSuccess) return nullptr;
+  MemCache &mc = mem_cache();
+  std::lock_guard<std::mutex> lk(mc.m);
+  mc.pinned_out[p] = got;
   return p;
 }
 void shk_free_pinned(void *p) {
-  if (p) (void)hipHostFree(p);
+  if (!p) return;
+  size_t bytes = 0;
+  {
+    MemCache &mc = mem_cache();
+    std::lock_guard<std::mutex> lk(mc.m);
+    auto it = mc.pinned_out.find(p);
+    if (it != mc.pinned_out.end()) {
+      bytes = it->second;
+      mc.pinned_out.erase(it);
+    }
+  }
+  if (bytes) host_free(p, bytes);
+  else (void)hipHostFree(p);
+}
+void shk_release_cached_memory(void) {
+  std::vector<MemCache::Blk> blocks;
+  std::vector<std::pair<int, hipStream_t>> streams;
+  {
+    MemCache &mc = mem_cache();
+    std::lock_guard<std::mutex> lk(mc.m);
+    blocks.swap(mc.blocks);
+    mc.dev_total = mc.host_total = 0;
+    streams.swap(mc.streams);
+  }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (const MemCache::Blk &b : blocks) {
+    if (b.dev < 0) {
+      (void)hipHostFree(b.p);
+    } else {
+      (void)hipSetDevice(b.dev);
+      (void)hipFree(b.p);
+    }
+  }
+  for (auto &st : streams) {
+    (void)hipSetDevice(st.first);
+    (void)hipStreamDestroy(st.second);
+  }
+  (void)hipSetDevice(cur);
 }
 void *shk_alloc_device(shk_ctx *c, size_t bytes) {
   if (c && c->group) return nullptr;

@@ -122,18 +122,28 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     shk_fastq_stats(rd, &nrr, &nbr, nullptr, nullptr);
     shk_fastq *r0 = rd;
     rd = nullptr;
-    close_th = std::thread([r0] { shk_fastq_close(r0); });
+    close_th = std::thread([r0, trace, now] {
+      const double t0 = now();
+      shk_fastq_close(r0);
+      if (trace) fprintf(stderr, "[shk] run_files:   (reader closed in %.2f ms)\n", (now() - t0) * 1e3);
+    });
   };
   auto cleanup = [&]() {
     (void)join_ingest();
     close_reader_early();
     std::thread unpin([&] {
+      const double t0 = now();
       for (int i = 0; i < 2; ++i) {
         free_data(bb2[i]);
         shk_free_pinned(bb2[i].offs);
       }
+      if (trace) fprintf(stderr, "[shk] run_files:   (buffers unpinned in %.2f ms)\n", (now() - t0) * 1e3);
     });
-    shk_destroy(ctx);
+    {
+      const double t0 = now();
+      shk_destroy(ctx);
+      if (trace) fprintf(stderr, "[shk] run_files:   (context destroyed in %.2f ms)\n", (now() - t0) * 1e3);
+    }
     unpin.join();
     if (close_th.joinable()) close_th.join();
     mark("  buffers unpinned, context destroyed, reader closed");
@@ -201,7 +211,6 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     if (done) break;
   }
   mark("batches read and handed over");
-  close_reader_early();  // (every batch is out: the mapping and the reader's threads go while the engine finishes)
   v = join_ingest();
   if (v != SHK_OK) {
     g_run_error = shk_last_error(ctx);
@@ -209,6 +218,8 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     return v;
   }
   mark("last ingest joined");
+  close_reader_early();  // (every batch is out and counted: the mapping and the reader's threads go while the histogram is written —
+                         // not earlier: unmapping locks the address space, and the engine's last copies would wait for it)
   v = shk_finalize(ctx);
   if (v != SHK_OK) {
     g_run_error = shk_last_error(ctx);

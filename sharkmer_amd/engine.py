@@ -104,7 +104,7 @@ ABI_SYMBOLS = [
     "shk_export_table", "shk_lookup", "shk_find_oligos", "shk_filter_reads", "shk_kmers_from_reads", "shk_table_geometry", "shk_table_reserve_pages", "shk_owner_counts", "shk_compact_owners",
     "shk_merge_entries",
     "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
-    "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_synth_reads_device",
+    "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_release_cached_memory", "shk_synth_reads_device",
     "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_next_batch_packed", "shk_fastq_stats",
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
     "shk_run_error", "shk_run_files",
@@ -249,6 +249,8 @@ def load_library():
     L.shk_xchg_spill.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.shk_xchg_spill_clear.argtypes = [vp]
     L.shk_insert_device.argtypes = [vp, vp, vp, vp, u64]
+    L.shk_release_cached_memory.argtypes = []
+    L.shk_release_cached_memory.restype = None
     L.shk_xchg_wide_scatter_device.argtypes = [vp, vp, vp, u64, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.shk_xchg_feasible.argtypes = [vp]
     L.shk_stream.argtypes = [vp]
@@ -772,6 +774,11 @@ class PackedReads:
         nz = int(np.count_nonzero(self.nmask))
         mask = 8 * nz if nz <= self.nmask.size // 16 else self.nmask.nbytes
         return self.packed.nbytes + self.offsets.nbytes + mask
+
+
+def release_cached_memory():
+    """shk_release_cached_memory: device and pinned blocks the process keeps for the next context go back to the driver."""
+    load_library().shk_release_cached_memory()
 
 
 def pack_reads(bases: np.ndarray, offsets: np.ndarray, threads: int = 0, pinned: bool = False, out: "PackedReads" = None) -> PackedReads:

@@ -959,3 +959,24 @@ def test_sampled_kernel_timing():
             eng.ingest_reads(bases, offsets)
             eng.finalize()
         assert eng.timings()["histo"][1] == 3
+
+
+# ---- the process-wide block cache (shk_release_cached_memory) -------------------------------------------------------
+
+def test_contexts_reuse_cached_blocks_and_give_them_back(orc):
+    """Device and pinned blocks a context gives back are kept for the next one (mapping and unmapping memory is what
+    setting a context up and taking it down costs); nothing may depend on what a recycled block holds — three contexts
+    in a row over different inputs and geometries, each against the oracle — and shk_release_cached_memory hands
+    everything back to the driver."""
+    import torch
+    sa.release_cached_memory()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for seed, k, chunks, flags in ((1, 21, 3, 0), (2, 31, 1, sa.FLAG_FORCE_PAGED), (3, 17, 4, sa.FLAG_FORCE_DIRECT)):
+        rng = np.random.default_rng(seed)
+        bases, offsets = ragged_reads(rng, 6_000, max_len=200)
+        check_against_oracle(orc, bases, offsets, k, chunks, 80, flags=flags)
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held > 0, "nothing was kept for the next context"
+    sa.release_cached_memory()
+    assert free0 - torch.cuda.mem_get_info()[0] < held // 4
