@@ -2090,8 +2090,23 @@ int shk_pack_reads(const uint8_t *bases, uint64_t n_bases, uint8_t *packed, uint
   if (n_words < 4096) T = 1;
   T = (uint32_t)std::min<uint64_t>(T, n_words);
   std::vector<uint64_t> bad(T, ~0ull);  // first offender of each share: position << 8 | byte
+  const bool avx2 = have_avx2();
   auto work = [&](uint32_t t) {
-    const uint64_t w0 = n_words * t / T, w1 = n_words * (t + 1) / T;
+    uint64_t w0 = n_words * t / T;
+    const uint64_t w1 = n_words * (t + 1) / T;
+    if (avx2) {  // whole 32-base words by the front-end's converter (32 bases per step); a last, partial word below
+      const uint64_t wf = std::min(w1, n_bases / 32);
+      for (; w0 < wf; ++w0) {
+        const Conv32 c = conv32_avx2(bases + w0 * 32, 32);
+        if (c.bad && bad[t] == ~0ull) {
+          const uint32_t i = (uint32_t)__builtin_ctz(c.bad);
+          bad[t] = ((w0 * 32 + i) << 8) | bases[w0 * 32 + i];
+        }
+        const uint64_t be = __builtin_bswap64(c.be);
+        memcpy(packed + w0 * 8, &be, 8);
+        nmask[w0] = c.nbits;
+      }
+    }
     for (uint64_t w = w0; w < w1; ++w) {
       const uint64_t p0 = w * 32;
       const uint32_t n = (uint32_t)std::min<uint64_t>(32, n_bases - p0);
