@@ -274,6 +274,7 @@ struct shk_ctx {
   DevBuf in_bases, in_offsets, st_bases[NST], st_offsets[NST], startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
   DevBuf pk_stage[NST], nm_stage[NST], nz_dev[NST], pk_ascii;
   DevBuf xw_kmers, xw_lanes, xw_count;  // the wide exchange round's output (shk_xchg_wide_scatter_device)
+  HostBuf hp_pk[NST], hp_nm[NST];  // ASCII host batches packed on the host (ingest_host): a slice's 2-bit stream and N mask, pinned
   HostBuf nz_host[NST];             // … and the non-zero words of a slice's N mask, when they are few (index, word)  // packed input: the staged streams of a slice; a whole batch unpacked (device-resident packed ingest)
   DevBuf xbuf, xspill;            // owner layout: the level-1 records of a launch by [owner][lane][super-page]; the foreign spill list
   DevBuf xbuf_alt, part_meta_alt;  // the OTHER exchange buffer and cursor block: shk_xchg_scatter_device takes the two in turn
@@ -1855,7 +1856,7 @@ void shk_destroy(shk_ctx *c) {
   c->xbuf_alt.release();
   c->part_meta_alt.release();
   c->xspill.release();
-  for (int i = 0; i < shk_ctx::NST; ++i) c->pk_stage[i].release(), c->nm_stage[i].release(), c->nz_dev[i].release(), c->nz_host[i].release();
+  for (int i = 0; i < shk_ctx::NST; ++i) c->pk_stage[i].release(), c->nm_stage[i].release(), c->nz_dev[i].release(), c->nz_host[i].release(), c->hp_pk[i].release(), c->hp_nm[i].release();
   c->pk_ascii.release();
   lap("scratch given back");
   if (c->stream) stream_give(c->stream);  // (synchronised at the top)
@@ -1974,13 +1975,31 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   // at 512 M).  A packed batch moves 0.3 B per base: the counting is the bottleneck, every slice costs a host round
   // trip, and 256 M bases per slice are fastest (5.3 ms per call; 128 M: 5.6-6.0, 512 M: 6.6) — the first slice a
   // quarter of that.
+  // An ASCII batch in PAGEABLE memory is packed on the host, slice by slice, when the host has the cores for it (2-bit
+  // stream + N mask by shk_pack_reads' AVX2 converter into pinned staging; slice i + 2 is packed while slice i + 1 is
+  // on the link and slice i is counted): a pageable source crosses PCIe through the runtime's own staging copy at
+  // 40-41 GB/s, packed by 16 cores it arrives at 47-50 Gbases/s — and an invalid byte is found, and reported with the
+  // same text, before anything of its slice is copied.  From PINNED memory the link alone does 52 GB/s and packing in
+  // line is no faster (52.9; config 3's stream 35 against 41: the packing threads and the engine's host thread share
+  // the cores), so pinned batches travel as they are.  SHK_HOST_PACK=0 / 1 pins the choice.
+  const int hp_env = env_int("SHK_HOST_PACK", -1);
+  bool hp = false;
+  if (!packed && bases && n_bases_all) {
+    if (hp_env >= 0) {
+      hp = hp_env != 0;
+    } else if (shk::usable_cpus() >= 12 && n_bases_all >= (8u << 20)) {
+      hipPointerAttribute_t at{};
+      if (hipPointerGetAttributes(&at, bases) == hipSuccess) hp = at.type != hipMemoryTypeHost && at.type != hipMemoryTypeManaged && at.type != hipMemoryTypeDevice;
+      else (void)hipGetLastError(), hp = true;  // (ordinary host memory: not an error)
+    }
+  }
   const uint64_t slice_kb = (uint64_t)env_int("SHK_SLICE_KB", packed ? 256 << 10 : 128 << 10);  // test hook: tiny slices
   const uint64_t slice_bases = slice_kb << 10;
   // slice boundaries at read boundaries, ≈ slice_bases each
   std::vector<uint64_t> cut{0};
   while (cut.back() < n_seqs) {
     uint64_t lo = cut.back(), hi = n_seqs;
-    const uint64_t limit = offsets[lo] + (lo == 0 && packed ? std::max<uint64_t>(slice_bases / 4, 1) : slice_bases);
+    const uint64_t limit = offsets[lo] + (lo == 0 && (packed || hp) ? std::max<uint64_t>(slice_bases / 4, 1) : slice_bases);
     if (offsets[n_seqs] > limit) {  // largest hi with offsets[hi] ≤ limit, at least one read
       hi = (uint64_t)(std::upper_bound(offsets + lo, offsets + n_seqs + 1, limit) - offsets) - 1;
       if (hi <= lo) hi = lo + 1;
@@ -2005,7 +2024,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   // A call of few slices takes few sets (at least two: one may still be read by the previous call's last launch):
   // a stream of one-slice calls — shk_run_files' 64 M-base batches — allocates two sets, not six (and frees two:
   // tearing the context down was 14 ms of an 80 ms job with all six in use).
-  const int NST = (int)std::min<size_t>(shk_ctx::NST, std::max<size_t>(n_slices + 1, 2));
+  const int NST = hp ? 3 : (int)std::min<size_t>(shk_ctx::NST, std::max<size_t>(n_slices + 1, 2));  // (host packing: two slices ahead — one being packed, one on the link — packing is the host's own time)
   const uint32_t s0 = c->stage_last >= 0 ? (uint32_t)(c->stage_last + 1) % (uint32_t)NST : 0u;
   auto set_of = [&](size_t i) { return (int)((s0 + i) % (uint32_t)NST); };
   auto bases_of = [&](int sel) -> DevBuf & { return c->st_bases[sel]; };
@@ -2018,18 +2037,34 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     DevBuf &dof = offs_of(bsel);
     HIPC(c, db.ensure(nb + 64));
     HIPC(c, dof.ensure((ns + 1) * 8));
-    if (nb && packed) {  // the slice's bytes of the 2-bit stream and words of the N mask (+ pad: k_unpack reads a few bytes on)
-      const uint64_t b0 = o0 >> 2, b1 = (o0 + nb + 3) >> 2, w0 = o0 >> 5, w1 = (o0 + nb + 31) >> 5;
+    const uint8_t *pk_src = packed;
+    const uint32_t *nm_src = nmask;
+    uint64_t o_rel = o0;  // the slice's first base in the packed streams
+    if (nb && hp) {
+      HIPC(c, c->hp_pk[bsel].ensure(nb / 4 + 64));   // (free: the copies that read them last have completed, like h_rebased)
+      HIPC(c, c->hp_nm[bsel].ensure((nb / 32 + 2) * 4));
+      const int prc = shk_pack_reads(bases + o0, nb, (uint8_t *)c->hp_pk[bsel].p, (uint32_t *)c->hp_nm[bsel].p, 0);
+      if (prc != SHK_OK) {  // encoding.rs:353-356: the run is over
+        c->poisoned = true;
+        c->poison_code = prc;
+        return fail(c, prc, "%s", shk_run_error());
+      }
+      pk_src = (const uint8_t *)c->hp_pk[bsel].p;
+      nm_src = (const uint32_t *)c->hp_nm[bsel].p;
+      o_rel = 0;
+    }
+    if (nb && pk_src) {  // the slice's bytes of the 2-bit stream and words of the N mask (+ pad: k_unpack reads a few bytes on)
+      const uint64_t b0 = o_rel >> 2, b1 = (o_rel + nb + 3) >> 2, w0 = o_rel >> 5, w1 = (o_rel + nb + 31) >> 5;
       HIPC(c, c->pk_stage[bsel].ensure(b1 - b0 + 16));
       HIPC(c, c->nm_stage[bsel].ensure((w1 - w0 + 2) * 4));
-      HIPC(c, hipMemcpyAsync(c->pk_stage[bsel].p, packed + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream));
+      HIPC(c, hipMemcpyAsync(c->pk_stage[bsel].p, pk_src + b0, b1 - b0, hipMemcpyHostToDevice, c->copy_stream));
       // the N mask: a bit per base, a third of the slice's bytes — and nearly all zeros on most data.  When at
       // most 1/16 of its words are non-zero they cross the link as a list and the rest is cleared on the device.
       const size_t nw = (size_t)(w1 - w0), list_cap = nw / 16 + 64;
       size_t nz = ~(size_t)0;
       if (nw >= (1u << 16) && env_int("SHK_NMASK_SPARSE", 1)) {
         HIPC(c, c->nz_host[bsel].ensure(list_cap * 8));
-        nz = nmask_nonzero(nmask + w0, nw, (uint32_t *)c->nz_host[bsel].p, list_cap);
+        nz = nmask_nonzero(nm_src + w0, nw, (uint32_t *)c->nz_host[bsel].p, list_cap);
       }
       if (nz != ~(size_t)0) {
         HIPC(c, hipMemsetAsync(c->nm_stage[bsel].p, 0, nw * 4, c->copy_stream));
@@ -2040,7 +2075,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
                              (uint32_t *)c->nm_stage[bsel].p, (const uint2 *)c->nz_dev[bsel].p, (uint32_t)nz);
         }
       } else {
-        HIPC(c, hipMemcpyAsync(c->nm_stage[bsel].p, nmask + w0, nw * 4, hipMemcpyHostToDevice, c->copy_stream));
+        HIPC(c, hipMemcpyAsync(c->nm_stage[bsel].p, nm_src + w0, nw * 4, hipMemcpyHostToDevice, c->copy_stream));
       }
     } else if (nb)
       HIPC(c, hipMemcpyAsync(db.p, bases + o0, nb, hipMemcpyHostToDevice, c->copy_stream));
@@ -2080,7 +2115,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     }
     HIPC(c, hipStreamSynchronize(c->stream));
     if (trace) fprintf(stderr, " count(i-1) done at %.0f\n", now_us());
-    if (i + NST - 1 < n_slices) {
+    if (!hp && i + NST - 1 < n_slices) {
       rc = issue_copy(i + NST - 1);
       if (rc != SHK_OK) {
         (void)hipStreamSynchronize(c->copy_stream);
@@ -2090,8 +2125,8 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
     DevBuf &db = bases_of(bsel);
     DevBuf &dof = offs_of(bsel);
-    if (packed && offsets[r1] > offsets[r0]) {  // 2-bit stream + N mask → the slice's ASCII bytes, in HBM
-      const uint64_t o0 = offsets[r0], nb = offsets[r1] - o0;
+    if ((packed || hp) && offsets[r1] > offsets[r0]) {  // 2-bit stream + N mask → the slice's ASCII bytes, in HBM
+      const uint64_t o0 = hp ? 0 : offsets[r0], nb = offsets[r1] - offsets[r0];
       // (the staged copies start at byte o0/4 resp. word o0/32 of the streams; what k_unpack reads past their
       // end only ever feeds positions ≥ nb, which it does not write)
       hipLaunchKernelGGL(k_unpack, dim3((uint32_t)((nb + 16ull * WG - 1) / (16ull * WG))), dim3(WG), 0, c->stream,
@@ -2104,6 +2139,13 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
       (void)hipStreamSynchronize(c->copy_stream);  // do not leave a copy reading `rebased` behind
       return rc;
     }
+    if (hp && i + 2 < n_slices) {  // the next slice but one is packed (the host's own time) under this slice's count and the next one's copy
+      rc = issue_copy(i + 2);
+      if (rc != SHK_OK) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        return rc;
+      }
+    }
   }
   c->stage_last = set_of(n_slices - 1);
   // A host-buffer ingest reports its errors (an invalid byte) before returning — unless the caller asked for
@@ -2113,7 +2155,7 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   // A packed batch cannot hold an invalid byte (two bits per base + the N mask: every value is a base), and its
   // copies have all completed (each slice's was waited for above): nothing the caller has to hear about before the
   // next call, so the last slice's count stays in flight (config 3 packed: 5.3 → 4.0 ms per 4 M-read call).
-  if (packed) return SHK_OK;
+  if (packed || hp) return SHK_OK;  // (hp: every byte was looked at when it was packed)
   return settle_light(c);  // host-buffer ingest reports its errors (an invalid byte) before returning
 }
 

@@ -383,15 +383,45 @@ def test_config2_full_size(orc, flags):
 
 # ---- BASELINE.json config 3 semantics: host input streamed in slices, copy/compute overlap ------------
 
+@pytest.mark.parametrize("host_pack", ["0", "1"])
 @pytest.mark.parametrize("k,chunks", [(31, 1), (21, 4)])
-def test_streamed_slices_match_oracle(orc, monkeypatch, k, chunks):
-    """A large host batch crosses PCIe in slices of whole reads (double-buffered, the next slice
-    copying while the current one is counted); forcing 64 KiB slices exercises many slice
-    boundaries, including ones inside a 1000-read block."""
+def test_streamed_slices_match_oracle(orc, monkeypatch, k, chunks, host_pack):
+    """A large host batch crosses PCIe in slices of whole reads (the next slices copying while the current one is
+    counted); forcing 64 KiB slices exercises many slice boundaries, including ones inside a 1000-read block.
+    host_pack: the slices as ASCII (0), or packed 2-bit on the host first — what a batch of some size gets on a host
+    with the cores for it (SHK_HOST_PACK pins either)."""
     monkeypatch.setenv("SHK_SLICE_KB", "64")
+    monkeypatch.setenv("SHK_HOST_PACK", host_pack)
     rng = np.random.default_rng(99)
-    bases, offsets = ragged_reads(rng, 20_000, max_len=160)
+    bases, offsets = ragged_reads(rng, 20_000, max_len=160, p_n=0.01)
     check_against_oracle(orc, bases, offsets, k, chunks, 60, check_table=False)
+
+
+def test_host_packed_ascii_batch_reports_the_first_invalid_byte(orc, monkeypatch):
+    """Host packing looks at every byte before anything of its slice is copied: the first offender in input order,
+    the reference's text (encoding.rs:353-356), the context poisoned as by the device-side check — and several calls
+    in a row (one and many slices each) give the oracle's histogram."""
+    monkeypatch.setenv("SHK_SLICE_KB", "64")
+    monkeypatch.setenv("SHK_HOST_PACK", "1")
+    rng = np.random.default_rng(12)
+    bases, offsets = ragged_reads(rng, 9_000, max_len=160)
+    ref = orc.run_batch(bases, offsets, 21, 3, 60)
+    with sa.KmerEngine(21, 3, 60) as eng:
+        for a, b in ((0, 2_500), (2_500, 2_600), (2_600, 7_000), (7_000, 9_000)):
+            eng.ingest_reads(bases, offsets[a:b + 1])
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms())
+        c = eng.counters()
+        for f in ("n_reads_ingested", "n_bases_read", "n_bases_ingested", "n_kmers_ingested", "n_unique_kmers"):
+            assert c[f] == ref.stats[f], f
+        eng.reset()
+        bad = bases.copy()
+        bad[int(offsets[4_000]) + 3] = ord("y")
+        bad[int(offsets[3_000]) + 5] = 0xE9
+        with pytest.raises(sa.ShkError, match="Invalid character 'é' in sequence. Only ACGTN allowed."):
+            eng.ingest_reads(bad, offsets)
+        with pytest.raises(sa.ShkError, match="Invalid character 'é'"):   # poisoned: the run is over
+            eng.ingest_reads(bases, offsets[:11])
 
 
 def test_deferred_errors_overlap_calls_and_still_report(orc, monkeypatch):
