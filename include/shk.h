@@ -444,6 +444,14 @@ int shk_synth_reads_device(shk_ctx *ctx, const shk_synth *spec, uint64_t first_r
 typedef struct shk_fastq shk_fastq;
 int shk_fastq_open(const char *const *paths, uint32_t n_paths, uint64_t max_reads,
                    uint64_t validate_every, shk_fastq **out);
+/* The same with flags.  SHK_FASTQ_GZIP_ALL_MEMBERS: NOT what the reference does — its flate2::read::GzDecoder
+ * (io.rs:606-617) reads a gzip file's FIRST member and stops, which is what shk_fastq_open does too; a bgzip'd FASTQ
+ * or `cat a.fastq.gz b.fastq.gz` then counts as its first member (64 KB of a bgzip file).  With the flag every member
+ * is read, the way flate2::read::MultiGzDecoder would: what follows a member's trailer is the next member's header,
+ * every member's CRC-32 and length are checked, an error in any of them is the stream's (same texts). */
+#define SHK_FASTQ_GZIP_ALL_MEMBERS 1u
+int shk_fastq_open_ex(const char *const *paths, uint32_t n_paths, uint64_t max_reads,
+                      uint64_t validate_every, uint32_t flags, shk_fastq **out);
 void shk_fastq_close(shk_fastq *r);
 const char *shk_fastq_error(const shk_fastq *r);
 /* Up to max_seqs sequences / bases_cap bytes, in input order; offsets[0] = 0.  A sequence that
@@ -511,7 +519,7 @@ typedef struct shk_run_config {
   uint64_t batch_reads;     /* reads per device super-batch; 0 = 1,000,000 */
   uint64_t batch_bases;     /* pinned buffer bytes; 0 = 256 MiB */
   uint32_t n_devices;       /* > 1: one multi-device context over device_ids (shk_config.n_devices); else `device` */
-  uint32_t reserved32;
+  uint32_t fastq_flags;     /* SHK_FASTQ_* (shk_fastq_open_ex); 0 = the reference's reader */
   const int32_t *device_ids;
 } shk_run_config;
 int shk_run_files(const shk_run_config *cfg, shk_run_stats *out_stats);

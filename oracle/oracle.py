@@ -175,6 +175,8 @@ def lib():
     L.orc_run_bad_char.restype = C.c_uint8
     L.orc_run_read_fastq.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
     L.orc_run_read_fastq.restype = C.c_int
+    L.orc_set_gzip_all_members.argtypes = [C.c_int]
+    L.orc_set_gzip_all_members.restype = None
     L.orc_run_write_histo.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
     L.orc_run_write_histo.restype = C.c_int
     L.orc_run_write_final_histo.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
@@ -424,10 +426,15 @@ class Run:
         self._check(lib().orc_run_push_batch(self._p, bases.ctypes.data, offsets.ctypes.data,
                                              len(offsets) - 1))
 
-    def read_fastq(self, path: str, max_reads: int = 0, validate_every: int = 0) -> bool:
+    def read_fastq(self, path: str, max_reads: int = 0, validate_every: int = 0, gzip_all_members: bool = False) -> bool:
+        """gzip_all_members: NOT the reference (which reads a gzip file's first member only) — the product's opt-in."""
         reached = C.c_int(0)
-        self._check(lib().orc_run_read_fastq(self._p, path.encode(), max_reads, validate_every,
-                                             C.byref(reached)))
+        lib().orc_set_gzip_all_members(1 if gzip_all_members else 0)
+        try:
+            self._check(lib().orc_run_read_fastq(self._p, path.encode(), max_reads, validate_every,
+                                                 C.byref(reached)))
+        finally:
+            lib().orc_set_gzip_all_members(0)
         return bool(reached.value)
 
     def finish(self):

@@ -863,6 +863,7 @@ typedef struct {
   unsigned char inbuf[1 << 15];
   uint32_t crc;
   uint64_t amount;
+  int all_members; /* NOT the reference: flate2::read::MultiGzDecoder's behaviour, on request (orc_run_set_gzip_all_members) */
 } byte_source;
 
 /* the compressed input, with what inflate has not consumed yet served first */
@@ -1010,6 +1011,17 @@ static long source_read(byte_source *s, unsigned char *dst, size_t cap, io_err *
       io_set(err, IOK_INVALID_INPUT, "corrupt gzip stream does not have a matching checksum");
       return -1;
     }
+    if (s->all_members) { /* MultiGzDecoder: bytes behind a member are the next member's header */
+      int c = src_getc(s);
+      if (c < 0) return 0;
+      s->zs.next_in--; /* (src_getc served it out of inbuf: back it goes) */
+      s->zs.avail_in++;
+      inflateReset(&s->zs);
+      s->crc = 0;
+      s->amount = 0;
+      gz_parse_header(s); /* → body, or an error pending */
+      continue;
+    }
     return 0;
   }
 }
@@ -1135,6 +1147,11 @@ static char *keep_line(char **copy, size_t *cap, const char *line, size_t len) {
   return *copy;
 }
 
+/* test-only switch for the product's opt-in (shk_fastq_open_ex, SHK_FASTQ_GZIP_ALL_MEMBERS): every member of a gzip
+ * file, as flate2::read::MultiGzDecoder would read it.  The reference itself reads the first member only. */
+static int g_gzip_all_members = 0;
+void orc_set_gzip_all_members(int on) { g_gzip_all_members = on; }
+
 int orc_run_read_fastq(orc_run *r, const char *path, uint64_t max_reads,
                        uint64_t validate_every, int *reached_max) {
   if (reached_max) *reached_max = 0;
@@ -1161,6 +1178,7 @@ int orc_run_read_fastq(orc_run *r, const char *path, uint64_t max_reads,
     lr->src.zs.avail_in = (uInt)n;
   }
   lr->src.use_gzip = use_gzip;
+  lr->src.all_members = g_gzip_all_members;
   if (use_gzip) {
     unsigned char *keep_in = lr->src.zs.next_in;
     uInt keep_n = lr->src.zs.avail_in;

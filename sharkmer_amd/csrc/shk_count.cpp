@@ -20,6 +20,7 @@ static bool parse_u64(const char *s, unsigned long long *out) {
 }
 
 int main(int argc, char **argv) {
+  bool gzip_all = false;
   unsigned long long k = 19, chunks = 0, histo_max = 10000, max_reads = 0, validate_every = 0, threads = 1,
                      device = 0, hint = 0;
   const char *sample = nullptr, *outdir = "./";
@@ -59,6 +60,7 @@ int main(int argc, char **argv) {
     else if (key == "--histo-max") num(&histo_max);
     else if (key == "-m" || key == "--max-reads") num(&max_reads);
     else if (key == "--validate-every") num(&validate_every);
+    else if (key == "--gzip-all-members") gzip_all = true;  // (not a sharkmer flag: sharkmer reads a gzip file's first member)
     else if (key == "-t" || key == "--threads") num(&threads);
     else if (key == "--device") num(&device);
     else if (key == "--capacity-hint") num(&hint);
@@ -78,7 +80,7 @@ int main(int argc, char **argv) {
     else if (key == "-o" || key == "--outdir") outdir = val ? argv[i] + eq + 1 : need(i, key.c_str());
     else if (key == "-h" || key == "--help") {
       printf("Usage: shk_count [-k K] [--chunks N] [--histo-max M] [-m READS] -s SAMPLE [-o OUTDIR] "
-             "[--validate-every N] [FASTQ[.gz] ...]\n");
+             "[--validate-every N] [--gzip-all-members] [FASTQ[.gz] ...]\n");
       return 0;
     } else if (a.size() > 1 && a[0] == '-' && a != "-") {
       fprintf(stderr, "error: unexpected argument '%s' found\n", a.c_str());
@@ -96,6 +98,7 @@ int main(int argc, char **argv) {
   rc.histo_max = histo_max;
   rc.max_reads = max_reads;
   rc.validate_every = validate_every;
+  rc.fastq_flags = gzip_all ? SHK_FASTQ_GZIP_ALL_MEMBERS : 0;
   rc.sample = sample;
   rc.outdir = outdir;
   rc.command = command.c_str();

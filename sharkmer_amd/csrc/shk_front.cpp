@@ -454,6 +454,12 @@ struct GzSource final : Source {
   std::deque<Window> q;
   bool done = false, stop = false, started = false;
   InflateStatus final_status = INF_TRUNCATED;
+  // NOT the reference (flate2::read::GzDecoder reads ONE member, and so does this reader unless asked otherwise): on
+  // request — shk_fastq_open_ex, SHK_FASTQ_GZIP_ALL_MEMBERS — every member, as flate2::read::MultiGzDecoder would:
+  // what follows a member's trailer is the next member's header; each member's CRC-32 and ISIZE are checked where it
+  // ends (by this thread: wants_crc() is then false), its error is the stream's.
+  bool all_members = false;
+  IoError members_err;
   static constexpr size_t DEPTH = 3;
   GzSource(const uint8_t *p, const uint8_t *e, std::shared_ptr<void> own) : owner(std::move(own)) {
     window = 16u << 20;
@@ -470,7 +476,7 @@ struct GzSource final : Source {
     }
     cv.notify_all();
   }
-  bool wants_crc() const override { return true; }
+  bool wants_crc() const override { return !all_members; }
   void emit(Window &&w) {
     std::unique_lock<std::mutex> lk(m);
     cv.wait(lk, [&] { return stop || q.size() < DEPTH; });
@@ -914,6 +920,13 @@ struct GzSource final : Source {
       cv.notify_all();
       return;
     }
+    if (all_members) {
+      run_members();
+      std::lock_guard<std::mutex> lk(m);
+      done = true;
+      cv.notify_all();
+      return;
+    }
     {
       // several threads on the one member when it is large enough to pay (test hooks: SHK_PGZ_*)
       const char *e_min = getenv("SHK_PGZ_MIN_KB"), *e_chunk = getenv("SHK_PGZ_CHUNK_KB"), *e_thr = getenv("SHK_PGZ_THREADS");
@@ -965,6 +978,62 @@ struct GzSource final : Source {
     done = true;
     cv.notify_all();
   }
+  // every member, one after the other, by this thread (a bgzip file's 64 KB members, `cat a.gz b.gz`)
+  void run_members() {
+    const size_t cap = window + 32768 + Inflater::OUT_SLACK;
+    auto b = std::make_shared<Buf>();
+    b->v.resize(cap);
+    size_t pos = 0, line0 = 0, crc_from = 0;  // decoded so far in this buffer; first byte not handed out; first byte not in the CRC yet
+    uint32_t crc = 0;
+    uint64_t member_out = 0;
+    for (;;) {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (stop) break;
+      }
+      const InflateStatus st = gz.inf.run(b->v.data(), &pos, b->v.size());
+      crc = crc32_update(crc, b->v.data() + crc_from, pos - crc_from);
+      member_out += pos - crc_from;
+      crc_from = pos;
+      if (st == INF_STREAM_END) {
+        members_err = gz.finish(st, crc, member_out);
+        const uint8_t *nxt = gz.inf.input_after_stream() + 8, *fe = gz.file_end;
+        if (members_err.kind == IO_NONE && nxt < fe) {  // another member: its header, its own history and checks
+          gz = GzMember();
+          gz.open(nxt, fe);
+          members_err = gz.header_error;
+          crc = 0;
+          member_out = 0;
+          if (members_err.kind == IO_NONE) continue;
+        }
+        emit(Window{b, (const char *)b->v.data() + line0, pos - line0, true});
+        break;
+      }
+      if (st != INF_OUTPUT_FULL) {  // a short or corrupt body
+        members_err = gz.finish(st, crc, member_out);
+        emit(Window{b, (const char *)b->v.data() + line0, pos - line0, true});
+        break;
+      }
+      const void *nl = memrchr(b->v.data() + line0, '\n', pos - line0);
+      if (!nl) {  // a line longer than the window: a bigger buffer, everything moves along
+        auto nb = std::make_shared<Buf>();
+        nb->v.resize(b->v.size() * 2);
+        memcpy(nb->v.data(), b->v.data(), pos);
+        b = std::move(nb);
+        continue;
+      }
+      const size_t cut = (size_t)((const uint8_t *)nl - b->v.data()) + 1;
+      const size_t keep = std::min(pos, std::max<size_t>(32768, pos - cut));
+      auto nb = std::make_shared<Buf>();
+      nb->v.resize(std::max(cap, keep + window + Inflater::OUT_SLACK));
+      memcpy(nb->v.data(), b->v.data() + pos - keep, keep);
+      emit(Window{b, (const char *)b->v.data() + line0, cut - line0, false});
+      line0 = keep - (pos - cut);
+      pos = keep;
+      crc_from = keep;
+      b = std::move(nb);
+    }
+  }
   bool next(Window *w) override {
     std::unique_lock<std::mutex> lk(m);
     if (!started) {
@@ -978,7 +1047,7 @@ struct GzSource final : Source {
     cv.notify_all();
     return true;
   }
-  IoError finish(uint32_t crc, uint64_t total) override { return gz.finish(final_status, crc, total); }
+  IoError finish(uint32_t crc, uint64_t total) override { return all_members ? members_err : gz.finish(final_status, crc, total); }
 };
 
 // ---- chunks ------------------------------------------------------------------------------------------------------
@@ -1103,6 +1172,7 @@ struct Producer {
   bool finished = false, cancel = false;
   FileEnd end;
   static constexpr size_t Q_MAX = 256u << 20;  // bytes buffered ahead per file
+  bool gz_all_members = false;  // (shk_fastq_open_ex: not the reference's behaviour)
   const char *map = nullptr;  // plain files: the mapping the chunks point into (released with the producer)
   size_t map_size = 0;
   std::unique_ptr<Source> src;
@@ -1179,7 +1249,11 @@ struct Producer {
           map_size = size;
         }
         const bool magic = size >= 2 && (uint8_t)data[0] == 0x1f && (uint8_t)data[1] == 0x8b;
-        if (gz_ext || magic) return with_window(new GzSource((const uint8_t *)data, (const uint8_t *)data + size, nullptr));
+        if (gz_ext || magic) {
+          auto *g = new GzSource((const uint8_t *)data, (const uint8_t *)data + size, nullptr);
+          g->all_members = gz_all_members;
+          return with_window(g);
+        }
         return with_window(new MappedSource(data, size));
       }
     }
@@ -1208,7 +1282,9 @@ struct Producer {
       if (r <= 0) break;
     }
     ::close(fd);
-    return with_window(new GzSource(all->data(), all->data() + all->size(), all));
+    auto *g = new GzSource(all->data(), all->data() + all->size(), all);
+    g->all_members = gz_all_members;
+    return with_window(g);
   }
 
   // ---- the parse ---------------------------------------------------------------------------------------------------
@@ -1547,6 +1623,7 @@ struct shk_fastq {
   std::unique_ptr<Pool> pool, cpool;            // the producers' pool (window parse) and the consumer's (copy-out): they overlap
   uint32_t T = 1;
   uint64_t max_reads = 0, validate_every = 0;
+  bool gz_all_members = false;
   // -- the scout: what is known about the input ahead of what has been handed out
   struct Held {
     SeqChunk c;
@@ -1597,6 +1674,7 @@ struct shk_fastq {
       p->name = p->path == "-" ? "stdin" : p->path;
       p->pool = pool.get();
       p->T = T;
+      p->gz_all_members = gz_all_members;
       Producer *pp = p.get();
       pp->th = std::thread([pp] { pp->run(); });
       prod.emplace_back(std::move(p));
@@ -1725,8 +1803,14 @@ extern "C" {
 
 int shk_fastq_open(const char *const *paths, uint32_t n_paths, uint64_t max_reads, uint64_t validate_every,
                    shk_fastq **out) {
+  return shk_fastq_open_ex(paths, n_paths, max_reads, validate_every, 0, out);
+}
+
+int shk_fastq_open_ex(const char *const *paths, uint32_t n_paths, uint64_t max_reads, uint64_t validate_every, uint32_t flags,
+                      shk_fastq **out) {
   if (!out) return SHK_ERR_BAD_ARG;
   auto *r = new shk_fastq();
+  r->gz_all_members = (flags & SHK_FASTQ_GZIP_ALL_MEMBERS) != 0;
   for (uint32_t i = 0; i < n_paths; ++i) r->paths.emplace_back(paths[i]);
   if (n_paths == 0) r->paths.emplace_back("-");  // stdin, io.rs:517-537
   r->max_reads = max_reads;

@@ -56,7 +56,7 @@ int shk_run_files(const shk_run_config *rc, shk_run_stats *out_stats) {
     }
   }
   shk_fastq *rd = nullptr;
-  v = shk_fastq_open(rc->inputs, rc->n_inputs, rc->max_reads, rc->validate_every, &rd);
+  v = shk_fastq_open_ex(rc->inputs, rc->n_inputs, rc->max_reads, rc->validate_every, rc->fastq_flags, &rd);
   if (v != SHK_OK) return v;
   shk_config cfg{};
   cfg.k = rc->k;

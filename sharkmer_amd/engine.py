@@ -23,6 +23,7 @@ FLAG_TIMING = 1
 FLAG_FORCE_DIRECT = 2
 FLAG_FORCE_PAGED = 4
 FLAG_TIMING_SAMPLED = 16  # with FLAG_TIMING: only every 4th job's launches are bracketed (include/shk.h)
+FASTQ_GZIP_ALL_MEMBERS = 1  # shk_fastq_open_ex / shk_run_config.fastq_flags (include/shk.h)
 FLAG_DEFER_ERRORS = 8  # host-buffer ingests return once queued; errors surface at the next call (include/shk.h)
 
 KERNEL_NAMES = ["mark", "scan", "direct", "scatter", "pages", "histo", "grow", "insert",
@@ -86,7 +87,7 @@ class _RunConfig(C.Structure):
                 ("max_reads", C.c_uint64), ("validate_every", C.c_uint64), ("sample", C.c_char_p),
                 ("outdir", C.c_char_p), ("command", C.c_char_p), ("version", C.c_char_p),
                 ("table_capacity_hint", C.c_uint64), ("batch_reads", C.c_uint64),
-                ("batch_bases", C.c_uint64), ("n_devices", C.c_uint32), ("reserved32", C.c_uint32),
+                ("batch_bases", C.c_uint64), ("n_devices", C.c_uint32), ("fastq_flags", C.c_uint32),
                 ("device_ids", C.POINTER(C.c_int32))]
 
 
@@ -105,7 +106,7 @@ ABI_SYMBOLS = [
     "shk_merge_entries",
     "shk_table_device_ptrs", "shk_merge_pages", "shk_set_owned_pages", "shk_alloc_pinned",
     "shk_free_pinned", "shk_alloc_device", "shk_free_device", "shk_release_cached_memory", "shk_synth_reads_device",
-    "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_next_batch_packed", "shk_fastq_stats",
+    "shk_fastq_open", "shk_fastq_open_ex", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_next_batch_packed", "shk_fastq_stats",
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
     "shk_run_error", "shk_run_files",
     "shk_xchg_scatter_device", "shk_xchg_absorb", "shk_xchg_spill", "shk_xchg_spill_clear", "shk_insert_device",
@@ -143,7 +144,7 @@ def _share_hip_runtime_with_torch():
 
 
 FRONT_SYMBOLS = [
-    "shk_fastq_open", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_next_batch_packed", "shk_fastq_stats",
+    "shk_fastq_open", "shk_fastq_open_ex", "shk_fastq_close", "shk_fastq_error", "shk_fastq_next_batch", "shk_fastq_next_batch_packed", "shk_fastq_stats",
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args", "shk_run_error",
     "shk_packed_sizes", "shk_pack_reads",
 ]
@@ -156,6 +157,7 @@ def _type_front(L):
     L.shk_packed_sizes.restype = None
     L.shk_pack_reads.argtypes = [vp, u64, vp, vp, u32]
     L.shk_fastq_open.argtypes = [C.POINTER(C.c_char_p), u32, u64, u64, C.POINTER(vp)]
+    L.shk_fastq_open_ex.argtypes = [C.POINTER(C.c_char_p), u32, u64, u64, u32, C.POINTER(vp)]
     L.shk_fastq_close.argtypes = [vp]
     L.shk_fastq_close.restype = None
     L.shk_fastq_error.argtypes = [vp]
@@ -822,11 +824,13 @@ class FastqReader:
     """read_fastq / open_fastq_reader (io.rs:271-352, 598-625) through libshk's C++ host.
     Parses only (no GPU needed)."""
 
-    def __init__(self, paths, max_reads: int = 0, validate_every: int = 0):
+    def __init__(self, paths, max_reads: int = 0, validate_every: int = 0, gzip_all_members: bool = False):
+        """gzip_all_members: NOT the reference (a gzip file is read up to the end of its first member, io.rs:606-617) —
+        every member (bgzip, concatenated files), shk_fastq_open_ex's SHK_FASTQ_GZIP_ALL_MEMBERS."""
         self._L = load_front_library()
         arr = (C.c_char_p * max(len(paths), 1))(*[os.fsencode(p) for p in paths])
         h = C.c_void_p()
-        rc = self._L.shk_fastq_open(arr, len(paths), max_reads, validate_every, C.byref(h))
+        rc = self._L.shk_fastq_open_ex(arr, len(paths), max_reads, validate_every, FASTQ_GZIP_ALL_MEMBERS if gzip_all_members else 0, C.byref(h))
         if rc != 0:
             raise ShkError(rc, "shk_fastq_open failed")
         self._h = h
@@ -911,16 +915,16 @@ def validate_args(k: int, histo_max: int, sample):
 
 def run_files(inputs, k: int, chunks: int, sample: str, outdir: str = "./", histo_max: int = 10000,
               max_reads: int = 0, validate_every: int = 0, device: int = 0, capacity_hint: int = 0,
-              command: str = "", batch_reads: int = 0, batch_bases: int = 0, device_ids=None) -> dict:
+              command: str = "", batch_reads: int = 0, batch_bases: int = 0, device_ids=None, gzip_all_members: bool = False) -> dict:
     """main.rs:112-197 without sPCR: FASTQ files → counts → .histo/.final.histo/.stats.yaml.
-    device_ids: run on one multi-device context (shk_run_config.n_devices)."""
+    device_ids: run on one multi-device context (shk_run_config.n_devices).  gzip_all_members: see FastqReader."""
     L = load_library()
     arr = (C.c_char_p * max(len(inputs), 1))(*[os.fsencode(p) for p in inputs])
     cfg = _RunConfig(inputs=arr, n_inputs=len(inputs), k=k, chunks=chunks, device=device,
                      histo_max=histo_max, max_reads=max_reads, validate_every=validate_every,
                      sample=None if sample is None else sample.encode(), outdir=os.fsencode(outdir),
                      command=command.encode(), version=None, table_capacity_hint=capacity_hint,
-                     batch_reads=batch_reads, batch_bases=batch_bases)
+                     batch_reads=batch_reads, batch_bases=batch_bases, fastq_flags=FASTQ_GZIP_ALL_MEMBERS if gzip_all_members else 0)
     if device_ids is not None:
         ids = (C.c_int32 * len(device_ids))(*device_ids)
         cfg.n_devices = len(device_ids)

@@ -33,10 +33,10 @@ def _built():
     g.build()
 
 
-def product_run(orc, paths, k=11, chunks=2, histo_max=50, max_reads=0, validate_every=0, batch=(777, 1 << 16)):
+def product_run(orc, paths, k=11, chunks=2, histo_max=50, max_reads=0, validate_every=0, batch=(777, 1 << 16), all_members=False):
     """libshk's reader feeding the oracle's counting: what shk_run_files does, with the oracle in the engine's place."""
     run = orc.Run(k, chunks, histo_max)
-    r = sa.FastqReader(paths, max_reads=max_reads, validate_every=validate_every)
+    r = sa.FastqReader(paths, max_reads=max_reads, validate_every=validate_every, gzip_all_members=all_members)
     try:
         while True:
             b, o = r.next_batch(max_seqs=batch[0], max_bases=batch[1])
@@ -52,10 +52,10 @@ def product_run(orc, paths, k=11, chunks=2, histo_max=50, max_reads=0, validate_
     return res
 
 
-def oracle_run(orc, paths, k=11, chunks=2, histo_max=50, max_reads=0, validate_every=0, batch=None):
+def oracle_run(orc, paths, k=11, chunks=2, histo_max=50, max_reads=0, validate_every=0, batch=None, all_members=False):
     run = orc.Run(k, chunks, histo_max)
     for p in paths:
-        if run.read_fastq(p, max_reads=max_reads, validate_every=validate_every):
+        if run.read_fastq(p, max_reads=max_reads, validate_every=validate_every, gzip_all_members=all_members):
             break
     return run.finish()
 
@@ -115,6 +115,38 @@ def test_two_member_gzip_reads_the_first_member_only(orc, tmp_path):
     # the same bytes under a name without the extension: the magic decides (io.rs:611-616)
     q = write(tmp_path, "two_members.bin", raw)
     assert both(orc, [q], k=5) == res
+
+
+def test_all_members_on_request(orc, tmp_path):
+    """The opt-in that is NOT the reference's behaviour (shk_fastq_open_ex, SHK_FASTQ_GZIP_ALL_MEMBERS): every member, the
+    way flate2::read::MultiGzDecoder reads — the fixture's 12 reads; a bgzip-like file of many small members with an
+    empty one at the end; what is not a member behind a member is a header error; a bad CRC in a LATER member is that
+    member's error, after everything before it has been read; a member cut short is the stream ending early."""
+    p = os.path.join(G, "reads_two_members.fastq.gz")
+    res = both(orc, [p], k=5, all_members=True)
+    assert res[0] == "ok" and res[2][0] == 12
+    recs = records(3000, 7)
+    blocks = [text_of(recs[i:i + 37]) for i in range(0, len(recs), 37)]          # members end on record boundaries …
+    text = text_of(recs)
+    ragged = [text[i:i + 3001] for i in range(0, len(text), 3001)]               # … or anywhere
+    for name, parts in (("blocks", blocks), ("ragged", ragged)):
+        q = write(tmp_path, f"{name}.fastq.gz", b"".join(gz_bytes(x, 1) for x in parts) + gz_bytes(b""))
+        res = both(orc, [q], all_members=True)
+        assert res[0] == "ok" and res[2][0] == 3000, name
+        first = both(orc, [q])                                                    # (the default: the first member — 37 reads, or a cut record)
+        assert first[2][0] == 37 if name == "blocks" else first[0] == "error", first[:2]
+    a, b = text_of(records(1200, 1)), text_of(records(900, 2))
+    q = write(tmp_path, "junk.fastq.gz", gz_bytes(a) + b"not a gzip member at all")
+    res = both(orc, [q], all_members=True)
+    assert res == ("error", f"Failed to read header line of record 1201 in {q}: invalid gzip header (kind InvalidInput)")
+    second = bytearray(gz_bytes(b))
+    second[-6] ^= 0x40                                                            # the second member's CRC-32
+    q = write(tmp_path, "badcrc.fastq.gz", gz_bytes(a) + bytes(second))
+    res = both(orc, [q], all_members=True)
+    assert res[0] == "error" and "record 2101" in res[1] and "matching checksum" in res[1], res
+    q = write(tmp_path, "short.fastq.gz", gz_bytes(a) + gz_bytes(b)[:-300])
+    res = both(orc, [q], all_members=True)
+    assert res[0] == "error" and "Local read stream ended unexpectedly" in res[1], res
 
 
 def test_member_followed_by_garbage_and_members_across_files(orc, tmp_path):
