@@ -596,7 +596,7 @@ def test_skewed_low_complexity_input(orc, flags):
 
 # ---- two-level partition (tables with more pages than one LDS sort fans out to) -------------------------
 
-@pytest.mark.parametrize("k,chunks,lvl1", [(21, 1, 2), (31, 3, 3), (13, 2, 0)])
+@pytest.mark.parametrize("k,chunks,lvl1", [(21, 1, 2), (31, 3, 3), (13, 2, 0), (23, 2, 2), (25, 3, 3), (24, 1, 1)])
 def test_two_level_partition_small(orc, monkeypatch, k, chunks, lvl1):
     """Force the super-page + re-scatter path on a small table: 8+ pages, level 1 fans out to
     2^lvl1 super-pages, level 2 to the pages inside each."""
@@ -875,10 +875,11 @@ def test_deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget):
 
 
 @pytest.mark.parametrize("k,chunks,hint,budget,lvl1", [(31, 2, 1_100_000, 0, 3), (29, 3, 1_100_000, 300_000, 5),
-                                                       (21, 2, 4_200_000, 500_000, 4)])
+                                                       (21, 2, 4_200_000, 500_000, 4), (23, 2, 1_100_000, 0, 3),
+                                                       (25, 3, 1_100_000, 300_000, 4), (23, 1, 2_200_000, 250_000, 2)])
 def test_deferred_page_passes_two_level(orc, monkeypatch, k, chunks, hint, budget, lvl1):
     """The same with the super-page + re-scatter partition forced: the level-2 pass appends to the
-    waiting page regions (8-byte records for k = 31 / 29, 4-byte ones for k = 21)."""
+    waiting page regions (8-byte records for k = 31 / 29 / 25 / 23, 4-byte ones for k = 21)."""
     monkeypatch.setenv("SHK_TWO_LEVEL_MIN_PAGES", "4")
     monkeypatch.setenv("SHK_LEVEL1_LOG", str(lvl1))
     _deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget)
@@ -989,6 +990,34 @@ def test_sampled_kernel_timing():
             eng.ingest_reads(bases, offsets)
             eng.finalize()
         assert eng.timings()["histo"][1] == 3
+
+
+# ---- BASELINE configs[2]'s table geometry against the oracle -----------------------------------------------------------
+
+def test_config3_geometry_against_the_oracle(orc):
+    """k = 31 with a hint of 300 M: 2^17 pages, two full partition levels of 8-byte records, deferred page passes — on
+    600 k reads: the final histogram, counters and a sample of point lookups against the oracle.  (Narrow records
+    behind level 2 — 45 bits of the mixed key as a u32 and a u16 array, 6 bytes instead of 8 — were built, tested here in
+    both forms and measured on the full config: re-scatter 39.6 against 39.1 ms, pages 31.9 against 31.9; the two
+    kernels are not bound by the bytes they move.  Not kept.)"""
+    spec = sa.SynthSpec(genome_len=2_000_000, sub_per_64k=200, n_per_64k=40)
+    n_reads, step = 600_000, 150_000
+    bases, offsets = sa.synth_reads(spec, 0, n_reads)
+    ref = orc.run_batch(bases, offsets, 31, 2, 300)
+    with sa.KmerEngine(31, 2, 300, capacity_hint=300_000_000, flags=sa.FLAG_TIMING) as eng:
+        assert eng.table_geometry()[0] == 1 << 17
+        for a in range(0, n_reads, step):
+            eng.ingest_reads(bases, offsets[a:a + step + 1])
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms())
+        c = eng.counters()
+        assert "pscan" in eng.timings() and "pages" in eng.timings()
+        rk, rc = ref.merged().export()
+        probe = rk[:: max(len(rk) // 2000, 1)]
+        want = rc[:: max(len(rk) // 2000, 1)]
+        assert np.array_equal(eng.lookup(probe), want)
+    for f in ("n_kmers_ingested", "n_unique_kmers", "n_hashed_kmers", "n_bases_ingested", "n_reads_ingested"):
+        assert c[f] == ref.stats[f], f
 
 
 # ---- the process-wide block cache (shk_release_cached_memory) -------------------------------------------------------
