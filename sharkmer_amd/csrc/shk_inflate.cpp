@@ -5,6 +5,8 @@
 // choice (a code set that is neither complete nor a single code is refused), since that is the reference's decoder.
 #include "shk_inflate.h"
 
+#include <immintrin.h>
+
 #include <cstring>
 
 namespace shk {
@@ -733,9 +735,94 @@ const CrcTables &crc_tables() {
 }
 }  // namespace
 
+// The same CRC by carry-less multiplication (PCLMULQDQ), four 16-byte lanes folded per step — the scheme of Intel's
+// "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ Instruction" with the published constants for the
+// reflected gzip polynomial (x^(4·128+32), x^(4·128−32), x^(128+32), x^(128−32), x^64, x^32 mod P; P and its Barrett
+// quotient).  `c` is the running register (the complement of the CRC so far); n ≥ 64 and a multiple of 16.
+// Slicing-by-8 does ≈ 2 GB/s a core, this ≈ 10: every decoded byte of a gzip member goes through it once.
+__attribute__((target("pclmul,sse4.1"))) static uint32_t crc32_clmul(uint32_t c, const uint8_t *p, size_t n) {
+  alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+  alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+  alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};
+  alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};
+  __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+  x1 = _mm_loadu_si128((const __m128i *)(p + 0x00));
+  x2 = _mm_loadu_si128((const __m128i *)(p + 0x10));
+  x3 = _mm_loadu_si128((const __m128i *)(p + 0x20));
+  x4 = _mm_loadu_si128((const __m128i *)(p + 0x30));
+  x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)c));
+  x0 = _mm_load_si128((const __m128i *)k1k2);
+  p += 64;
+  n -= 64;
+  while (n >= 64) {  // four lanes, each folded across 64 bytes
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
+    x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+    x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
+    x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+    y5 = _mm_loadu_si128((const __m128i *)(p + 0x00));
+    y6 = _mm_loadu_si128((const __m128i *)(p + 0x10));
+    y7 = _mm_loadu_si128((const __m128i *)(p + 0x20));
+    y8 = _mm_loadu_si128((const __m128i *)(p + 0x30));
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5);
+    x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+    x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7);
+    x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+    p += 64;
+    n -= 64;
+  }
+  x0 = _mm_load_si128((const __m128i *)k3k4);  // the four lanes into one
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+  while (n >= 16) {  // what is left, 16 bytes at a time
+    x2 = _mm_loadu_si128((const __m128i *)p);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    p += 16;
+    n -= 16;
+  }
+  x2 = _mm_clmulepi64_si128(x1, x0, 0x10);  // 128 → 64 bits
+  x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+  x1 = _mm_srli_si128(x1, 8);
+  x1 = _mm_xor_si128(x1, x2);
+  x0 = _mm_loadl_epi64((const __m128i *)k5k0);
+  x2 = _mm_srli_si128(x1, 4);
+  x1 = _mm_and_si128(x1, x3);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  x0 = _mm_load_si128((const __m128i *)poly);  // Barrett reduction, 64 → 32 bits
+  x2 = _mm_and_si128(x1, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+  x2 = _mm_and_si128(x2, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+static bool have_clmul() {
+  static const bool on = getenv("SHK_NO_AVX2") == nullptr && __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+  return on;
+}
+
 uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {
   const CrcTables &T = crc_tables();
   uint32_t c = ~crc;
+  if (n >= 256 && have_clmul()) {
+    const size_t m = n & ~(size_t)15;
+    c = crc32_clmul(c, p, m);
+    p += m;
+    n -= m;
+  }
   while (n && ((uintptr_t)p & 7)) {
     c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xFF];
     --n;

@@ -549,3 +549,26 @@ def test_parallel_member_decode_is_the_sequential_decode(orc, tmp_path, monkeypa
         if name in ("level1", "level6", "level9", "fixed", "stored", "flushes", "two_members"):
             assert got[0] == "ok" and len(got[1]) == 6_000, name
         assert both(orc, [p])[0] == got[0], name   # (and the oracle's own reader agrees on the kind of outcome)
+
+
+def test_member_checksum_at_every_small_size(orc, tmp_path):
+    """The member's CRC-32 is checked over everything written (flate2: "corrupt gzip stream does not have a matching
+    checksum" otherwise); the product computes it by carry-less multiplication from 256 bytes on, 16 bytes at a time
+    with a table-driven tail — every output size from 207 to 1007 bytes, against trailers zlib wrote; and one flipped
+    trailer bit is still caught."""
+    for L in range(100, 501):
+        seq = "ACGT" * (L // 4) + "ACGT"[:L % 4]
+        data = f"@r\n{seq}\n+\n{'I' * L}\n".encode()
+        p = write(tmp_path, "one.fastq.gz", gz_bytes(data, 1))
+        r = sa.FastqReader([p])
+        try:
+            b, o = r.next_batch(max_seqs=10, max_bases=1 << 16)
+            assert len(o) == 2 and bytes(b) == seq.encode(), L
+            assert r.stats()["done"]
+        finally:
+            r.close()
+    raw = bytearray(gz_bytes(data, 1))
+    raw[-7] ^= 0x10
+    p = write(tmp_path, "bad.fastq.gz", bytes(raw))
+    res = both(orc, [p])
+    assert res[0] == "error" and "matching checksum" in res[1]
