@@ -445,8 +445,69 @@ struct FdSource final : Source {  // a pipe, stdin, anything that cannot be mapp
 // One gzip member inflated into buffers by a thread of its own, running ahead of the parse by a few windows.  A
 // buffer starts with the last 32 KiB (at least) of the one before — the decoder's history — which is also where an
 // unfinished last line is carried over, so that every window is whole lines.
+// One member at a time gets the many-thread decoder.  The reader starts the producers of up to LOOKAHEAD files ahead, so
+// that slow (one-thread) streams run side by side; eight large .gz files would otherwise each bring their own sixteen
+// workers — 128 threads on 16 CPUs, all files crawling, the one the consumer is waiting for among them.  Tickets are
+// drawn in file order when the sources are made and served in that order: file i + 1's decode begins the moment file
+// i's ends (file i's windows are still being parsed and handed out then).  A source that does not use the parallel
+// decoder hands its ticket back.
+struct PgzGate {
+  std::mutex m;
+  std::condition_variable cv;
+  uint64_t next = 0, serving = 0;
+  std::vector<uint64_t> returned;  // tickets given back before their turn
+  uint64_t draw() {
+    std::lock_guard<std::mutex> lk(m);
+    return next++;
+  }
+  void skip_returned() {  // (m held)
+    for (bool again = true; again;) {
+      again = false;
+      for (size_t i = 0; i < returned.size(); ++i)
+        if (returned[i] == serving) {
+          returned.erase(returned.begin() + (long)i);
+          ++serving;
+          again = true;
+          break;
+        }
+    }
+  }
+  bool enter(uint64_t t, const std::atomic<bool> &abort) {  // false: the caller was cancelled while it waited
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return serving == t || abort.load(); });
+    return serving == t;
+  }
+  void poke() {
+    std::lock_guard<std::mutex> lk(m);
+    cv.notify_all();
+  }
+  void leave(uint64_t t) {  // after enter(t), or instead of it
+    std::lock_guard<std::mutex> lk(m);
+    if (serving == t) {
+      ++serving;
+    } else {
+      returned.push_back(t);
+    }
+    skip_returned();
+    cv.notify_all();
+  }
+};
+static PgzGate &pgz_gate() {
+  static PgzGate g;
+  return g;
+}
+
 struct GzSource final : Source {
   GzMember gz;
+  uint64_t ticket;          // this source's turn at the many-thread decoder
+  bool ticket_done = false;
+  std::atomic<bool> gate_abort{false};  // cancel(): stop waiting for the turn
+  void ticket_leave() {
+    if (!ticket_done) {
+      ticket_done = true;
+      pgz_gate().leave(ticket);
+    }
+  }
   std::shared_ptr<void> owner;  // the compressed bytes (a mapping or a vector)
   std::thread th;
   std::mutex m;
@@ -461,13 +522,14 @@ struct GzSource final : Source {
   bool all_members = false;
   IoError members_err;
   static constexpr size_t DEPTH = 3;
-  GzSource(const uint8_t *p, const uint8_t *e, std::shared_ptr<void> own) : owner(std::move(own)) {
+  GzSource(const uint8_t *p, const uint8_t *e, std::shared_ptr<void> own, uint64_t turn) : ticket(turn), owner(std::move(own)) {
     window = 16u << 20;
     gz.open(p, e);
   }
   ~GzSource() override {
     cancel();
     if (th.joinable()) th.join();
+    ticket_leave();  // (never started, or stopped early)
   }
   void cancel() override {
     {
@@ -475,6 +537,8 @@ struct GzSource final : Source {
       stop = true;
     }
     cv.notify_all();
+    gate_abort.store(true);
+    pgz_gate().poke();
   }
   bool wants_crc() const override { return !all_members; }
   void emit(Window &&w) {
@@ -914,6 +978,7 @@ struct GzSource final : Source {
 
   void run() {
     if (gz.header_error.kind != IO_NONE) {  // nothing can be read: an empty last window, the error follows it
+      ticket_leave();
       emit(Window{nullptr, "", 0, true});
       std::lock_guard<std::mutex> lk(m);
       done = true;
@@ -921,6 +986,7 @@ struct GzSource final : Source {
       return;
     }
     if (all_members) {
+      ticket_leave();
       run_members();
       std::lock_guard<std::mutex> lk(m);
       done = true;
@@ -934,13 +1000,15 @@ struct GzSource final : Source {
       const size_t chunk = std::max<size_t>(e_chunk ? (size_t)atoll(e_chunk) << 10 : (size_t)1 << 20, 512);
       const uint32_t thr = e_thr ? (uint32_t)atoi(e_thr) : std::min(32u, usable_cpus());
       if (thr > 1 && (size_t)(gz.inf.in_end - gz.inf.in) >= min_bytes) {
-        run_parallel(thr, chunk);
+        if (pgz_gate().enter(ticket, gate_abort)) run_parallel(thr, chunk);
+        ticket_leave();
         std::lock_guard<std::mutex> lk(m);
         done = true;
         cv.notify_all();
         return;
       }
     }
+    ticket_leave();  // (one thread is all this member gets: no turn needed)
     size_t cap = window + 32768 + Inflater::OUT_SLACK;
     auto b = std::make_shared<Buf>();
     b->v.resize(cap);
@@ -1173,6 +1241,8 @@ struct Producer {
   FileEnd end;
   static constexpr size_t Q_MAX = 256u << 20;  // bytes buffered ahead per file
   bool gz_all_members = false;  // (shk_fastq_open_ex: not the reference's behaviour)
+  uint64_t pgz_ticket = 0;      // this file's turn at the many-thread gzip decoder (drawn in file order by the reader)
+  bool ticket_given = false;    // … handed to a GzSource; otherwise given back as soon as the source is known
   const char *map = nullptr;  // plain files: the mapping the chunks point into (released with the producer)
   size_t map_size = 0;
   std::unique_ptr<Source> src;
@@ -1250,7 +1320,8 @@ struct Producer {
         }
         const bool magic = size >= 2 && (uint8_t)data[0] == 0x1f && (uint8_t)data[1] == 0x8b;
         if (gz_ext || magic) {
-          auto *g = new GzSource((const uint8_t *)data, (const uint8_t *)data + size, nullptr);
+          auto *g = new GzSource((const uint8_t *)data, (const uint8_t *)data + size, nullptr, pgz_ticket);
+          ticket_given = true;
           g->all_members = gz_all_members;
           return with_window(g);
         }
@@ -1282,7 +1353,8 @@ struct Producer {
       if (r <= 0) break;
     }
     ::close(fd);
-    auto *g = new GzSource(all->data(), all->data() + all->size(), all);
+    auto *g = new GzSource(all->data(), all->data() + all->size(), all, pgz_ticket);
+    ticket_given = true;
     g->all_members = gz_all_members;
     return with_window(g);
   }
@@ -1458,7 +1530,9 @@ struct Producer {
   }
 
   void run() {
-    if (!open_source()) return finish(end);
+    const bool opened = open_source();
+    if (!ticket_given) pgz_gate().leave(pgz_ticket);  // (not a gzip file, or it could not be opened)
+    if (!opened) return finish(end);
     Window w;
     bool saw_last = false;
     while (!cancelled() && src->next(&w)) {
@@ -1675,6 +1749,7 @@ struct shk_fastq {
       p->pool = pool.get();
       p->T = T;
       p->gz_all_members = gz_all_members;
+      p->pgz_ticket = pgz_gate().draw();
       Producer *pp = p.get();
       pp->th = std::thread([pp] { pp->run(); });
       prod.emplace_back(std::move(p));

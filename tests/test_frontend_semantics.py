@@ -572,3 +572,29 @@ def test_member_checksum_at_every_small_size(orc, tmp_path):
     p = write(tmp_path, "bad.fastq.gz", bytes(raw))
     res = both(orc, [p])
     assert res[0] == "error" and "matching checksum" in res[1]
+
+
+def test_many_gzip_files_take_the_parallel_decoder_in_turn(orc, tmp_path, monkeypatch):
+    """Eight inputs whose producers all start at once — large members (the many-thread decoder, forced here by
+    SHK_PGZ_MIN_KB=0), a plain file, a member too damaged to start, stdin-like small ones — decode one after the other
+    in FILE order (a ticket per file, drawn by the reader): the outcome is the oracle's, also when --max-reads ends
+    the run while later files are still waiting for their turn, and when an early file fails."""
+    monkeypatch.setenv("SHK_PGZ_MIN_KB", "0")
+    monkeypatch.setenv("SHK_PGZ_CHUNK_KB", "16")
+    monkeypatch.setenv("SHK_PGZ_THREADS", "4")
+    paths = []
+    for i in range(8):
+        data = text_of(records(1500 + 100 * i, 40 + i, length=(60, 120)))
+        if i == 3:
+            paths.append(write(tmp_path, f"f{i}.fastq", data))
+        else:
+            paths.append(write(tmp_path, f"f{i}.fastq.gz", gz_bytes(data, 1 + i % 9)))
+    res = both(orc, paths)
+    assert res[0] == "ok" and res[2][0] == sum(1500 + 100 * i for i in range(8))
+    cut = both(orc, paths, max_reads=3300)
+    assert cut[0] == "ok" and cut[2][0] == 3300
+    bad = bytearray(open(paths[2], "rb").read())
+    bad[len(bad) // 2] ^= 0x55
+    paths[2] = write(tmp_path, "f2bad.fastq.gz", bytes(bad))
+    res = both(orc, paths)
+    assert res[0] == "error"
