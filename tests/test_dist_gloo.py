@@ -421,3 +421,21 @@ def test_two_rank_owner_partitioned_ingest_matches_single_oracle(orc, tmp_path, 
                             st["n_kmers_ingested"], st["n_unique_kmers"]]
     if poly and 2 * k - log_p1 <= 32:
         assert t0[5] > 0, "the low-complexity reads were meant to overflow a region"
+
+
+@pytest.mark.parametrize("k,chunks,log_p1", [(21, 3, 10), (27, 2, 10)])
+def test_four_rank_owner_partitioned_ingest(orc, tmp_path, k, chunks, log_p1):
+    """World 4 (two owner bits): the pipelined rounds — round r's segments exchanged while round r − 1 is absorbed —
+    with ranks that run out of reads at different rounds, 4-byte records (k = 21) and the wide round (k = 27)."""
+    import sharkmer_amd as sa
+    histo_max, n_reads = 40, 4300
+    port = _free_port()
+    mp.spawn(_owner_worker, args=(4, port, k, chunks, histo_max, n_reads, log_p1, 1024, False, str(tmp_path)), nprocs=4, join=True)
+    bases, offsets = _owner_input(sa, n_reads, False)
+    ref = orc.run_batch(bases, offsets, k, chunks, histo_max)
+    hs = [np.load(tmp_path / f"hist_{r}.npy") for r in range(4)]
+    assert all(np.array_equal(hs[0], h) for h in hs[1:])
+    assert np.array_equal(hs[0], ref.histograms())
+    t0 = np.load(tmp_path / "tot_0.npy")
+    st = ref.stats
+    assert list(t0[:5]) == [st["n_reads_ingested"], st["n_bases_read"], st["n_bases_ingested"], st["n_kmers_ingested"], st["n_unique_kmers"]]
