@@ -1,9 +1,9 @@
 #!/bin/bash
-# one large .fastq.gz through the front-end alone, with the decoder's own timing lines; thread-count sweep
+# one large .fastq.gz through the front-end alone, with the decoder's own timing lines
 cd "$GRAFT_REPO_ROOT"
 g++ -O2 -o /tmp/reader_bench tools/reader_bench.cpp -Lsharkmer_amd/csrc -lshk -Wl,-rpath,$PWD/sharkmer_amd/csrc || exit 1
-python3 tools/gen_fastq.py /tmp/big.fastq 4000000 > /dev/null 2>&1 || python3 - <<'PY'
-import numpy as np
+python3 - <<'PY'
+import numpy as np, gzip, shutil
 n, L = 4_000_000, 150
 rng = np.random.default_rng(1)
 rec = np.empty((n, 2 * L + 7), dtype=np.uint8)
@@ -13,14 +13,9 @@ rec[:, 3 + L:6 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
 rec[:, 6 + L:6 + 2 * L] = ord("I")
 rec[:, 6 + 2 * L] = ord("\n")
 rec.tofile("/tmp/big.fastq")
+with open('/tmp/big.fastq','rb') as f, gzip.open('/tmp/big.fastq.gz','wb',compresslevel=1) as g: shutil.copyfileobj(f,g,1<<24)
 PY
-ls -la /tmp/big.fastq
-python3 -c "
-import gzip, shutil
-with open('/tmp/big.fastq','rb') as f, gzip.open('/tmp/big.fastq.gz','wb',compresslevel=1) as g: shutil.copyfileobj(f,g,1<<24)"
-ls -la /tmp/big.fastq.gz
-for thr in 8 12 16 24; do
-  echo "== SHK_PGZ_THREADS=$thr"
-  SHK_PGZ_THREADS=$thr /tmp/reader_bench --packed /tmp/big.fastq.gz | tail -2
-done
-echo "== debug"; SHK_FASTQ_DEBUG=1 /tmp/reader_bench --packed /tmp/big.fastq.gz 2>&1 | grep -i "pgz\|member\|decode" | tail -8
+ls -la /tmp/big.fastq /tmp/big.fastq.gz
+/tmp/reader_bench --packed /tmp/big.fastq.gz | tail -3
+SHK_FASTQ_DEBUG=1 /tmp/reader_bench --packed /tmp/big.fastq.gz 2>&1 | grep -i "gzip member\|workers" | tail -4
+echo "== plain"; /tmp/reader_bench --packed /tmp/big.fastq | tail -2
