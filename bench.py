@@ -154,7 +154,7 @@ def extras(sa, torch, dev):
                 ascii_wire = hp == "0" or (hp is None and kind == "pinned")
                 res[kind] = {"Gbases_per_s": round(n * L / best / 1e9, 2),
                              "bound": "PCIe H2D, 1 B/base ASCII" if ascii_wire else
-                                      "the library packs every slice 2-bit on the host's cores (a pageable batch, 12 or more cores: the default), 0.3 B/base on the link"}
+                                      "the library's packer thread: every slice 2-bit on the host's cores (a pageable batch on 12 or more cores: the default), 0.3 B/base on the link"}
                 if ascii_wire:
                     res[kind]["pcie_GB_per_s"] = round(n * L / best / 1e9, 2)
             del pageable

@@ -1975,19 +1975,21 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   // at 512 M).  A packed batch moves 0.3 B per base: the counting is the bottleneck, every slice costs a host round
   // trip, and 256 M bases per slice are fastest (5.3 ms per call; 128 M: 5.6-6.0, 512 M: 6.6) — the first slice a
   // quarter of that.
-  // An ASCII batch in PAGEABLE memory is packed on the host, slice by slice, when the host has the cores for it (2-bit
-  // stream + N mask by shk_pack_reads' AVX2 converter into pinned staging; slice i + 2 is packed while slice i + 1 is
-  // on the link and slice i is counted): a pageable source crosses PCIe through the runtime's own staging copy at
-  // 40-41 GB/s, packed by 16 cores it arrives at 47-50 Gbases/s — and an invalid byte is found, and reported with the
-  // same text, before anything of its slice is copied.  From PINNED memory the link alone does 52 GB/s and packing in
-  // line is no faster (52.9; config 3's stream 35 against 41: the packing threads and the engine's host thread share
-  // the cores), so pinned batches travel as they are.  SHK_HOST_PACK=0 / 1 pins the choice.
+  // An ASCII batch is PACKED ON THE HOST, slice by slice, when the host has the cores for it (2-bit stream + N mask by
+  // shk_pack_reads' AVX2 converter, ≈ 77 Gbases/s on 16 cores, into pinned staging, by a thread of its own that runs
+  // ahead of the copies and the counting): the link moves 52 GB/s = 52 Gbases/s of ASCII out of pinned memory and 41
+  // out of pageable memory, and 0.3 B per base of a packed slice — and an invalid byte is found, and reported with the
+  // same text, before anything of its slice is copied.  SHK_HOST_PACK=0 / 1 pins the choice.
   const int hp_env = env_int("SHK_HOST_PACK", -1);
   bool hp = false;
   if (!packed && bases && n_bases_all) {
     if (hp_env >= 0) {
       hp = hp_env != 0;
-    } else if (shk::usable_cpus() >= 12 && n_bases_all >= (8u << 20)) {
+    } else if (shk::usable_cpus() >= 12 && n_bases_all >= (8u << 20) && n_bases_all <= (1ull << 31)) {
+      // (up to 2^31 bases a call: the call's packed staging is pinned memory, 3/8 of a byte per base.)  By default only
+      // for a batch in PAGEABLE memory — 41 → 50-52 Gbases/s; out of pinned memory the gain over the link's 52 is small
+      // (55; config 3's stream 43.6 against 41.7: in line the packing runs at ≈ 55, not 77 — it shares the host's
+      // memory bus with the copies) and a busy host would turn it into a loss
       hipPointerAttribute_t at{};
       if (hipPointerGetAttributes(&at, bases) == hipSuccess) hp = at.type != hipMemoryTypeHost && at.type != hipMemoryTypeManaged && at.type != hipMemoryTypeDevice;
       else (void)hipGetLastError(), hp = true;  // (ordinary host memory: not an error)
@@ -2024,11 +2026,73 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   // A call of few slices takes few sets (at least two: one may still be read by the previous call's last launch):
   // a stream of one-slice calls — shk_run_files' 64 M-base batches — allocates two sets, not six (and frees two:
   // tearing the context down was 14 ms of an 80 ms job with all six in use).
-  const int NST = hp ? 3 : (int)std::min<size_t>(shk_ctx::NST, std::max<size_t>(n_slices + 1, 2));  // (host packing: two slices ahead — one being packed, one on the link — packing is the host's own time)
+  const int NST = (int)std::min<size_t>(shk_ctx::NST, std::max<size_t>(n_slices + 1, 2));
   const uint32_t s0 = c->stage_last >= 0 ? (uint32_t)(c->stage_last + 1) % (uint32_t)NST : 0u;
   auto set_of = [&](size_t i) { return (int)((s0 + i) % (uint32_t)NST); };
   auto bases_of = [&](int sel) -> DevBuf & { return c->st_bases[sel]; };
   auto offs_of = [&](int sel) -> DevBuf & { return c->st_offsets[sel]; };
+  // Host packing: ONE thread of its own packs the call's slices, in order, each into its own stretch of the call's
+  // pinned staging (shk_pack_reads: all the host's cores per slice), and says how far it has come; this thread sends
+  // what is packed and counts what has arrived — a deferred page pass that holds it up does not hold the packing up.
+  std::vector<size_t> hp_pk_off, hp_nm_off;
+  std::mutex hp_m;
+  std::condition_variable hp_cv;
+  size_t hp_done = 0;      // slices packed so far
+  int hp_rc = SHK_OK;      // … or the packer's error (an invalid byte: the run is over)
+  std::string hp_err;
+  bool hp_quit = false;
+  std::thread hp_thread;
+  struct HpJoin {  // (every way out of this function goes past the packer)
+    std::thread &t;
+    std::mutex &m;
+    bool &quit;
+    ~HpJoin() {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        quit = true;
+      }
+      if (t.joinable()) t.join();
+    }
+  } hp_join{hp_thread, hp_m, hp_quit};
+  if (hp) {
+    size_t pk_total = 0, nm_total = 0;
+    for (size_t j = 0; j < n_slices; ++j) {
+      const uint64_t nb = offsets[cut[j + 1]] - offsets[cut[j]];
+      hp_pk_off.push_back(pk_total);
+      hp_nm_off.push_back(nm_total);
+      pk_total += (size_t)((nb / 4 + 64 + 63) & ~63ull);
+      nm_total += (size_t)(((nb / 32 + 2) * 4 + 63) & ~63ull);
+    }
+    HIPC(c, c->hp_pk[0].ensure(pk_total));  // (free: every copy out of them was waited for before the call that made it returned)
+    HIPC(c, c->hp_nm[0].ensure(nm_total));
+    hp_thread = std::thread([&] {
+      for (size_t j = 0; j < n_slices; ++j) {
+        {
+          std::lock_guard<std::mutex> lk(hp_m);
+          if (hp_quit) return;
+        }
+        const uint64_t o0 = offsets[cut[j]], nb = offsets[cut[j + 1]] - o0;
+        int prc = SHK_OK;
+        if (nb) prc = shk_pack_reads(bases + o0, nb, (uint8_t *)c->hp_pk[0].p + hp_pk_off[j], (uint32_t *)((uint8_t *)c->hp_nm[0].p + hp_nm_off[j]), 0);
+        std::lock_guard<std::mutex> lk(hp_m);
+        if (prc != SHK_OK) {
+          hp_rc = prc;
+          hp_err = shk_run_error();  // (this thread's own message buffer)
+          hp_cv.notify_all();
+          return;
+        }
+        hp_done = j + 1;
+        hp_cv.notify_all();
+      }
+    });
+  }
+  // slices [0, n) packed?  block: wait for slice n − 1 (or the packer's error, which is this call's)
+  auto hp_packed = [&](bool block, size_t need) -> size_t {
+    std::unique_lock<std::mutex> lk(hp_m);
+    if (block) hp_cv.wait(lk, [&] { return hp_done >= need || hp_rc != SHK_OK; });
+    return hp_done;
+  };
+  size_t hp_issued = 0;  // slices whose copies have been queued (host packing)
   auto issue_copy = [&](size_t i) -> int {
     const int bsel = set_of(i);
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
@@ -2040,17 +2104,9 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     const uint8_t *pk_src = packed;
     const uint32_t *nm_src = nmask;
     uint64_t o_rel = o0;  // the slice's first base in the packed streams
-    if (nb && hp) {
-      HIPC(c, c->hp_pk[bsel].ensure(nb / 4 + 64));   // (free: the copies that read them last have completed, like h_rebased)
-      HIPC(c, c->hp_nm[bsel].ensure((nb / 32 + 2) * 4));
-      const int prc = shk_pack_reads(bases + o0, nb, (uint8_t *)c->hp_pk[bsel].p, (uint32_t *)c->hp_nm[bsel].p, 0);
-      if (prc != SHK_OK) {  // encoding.rs:353-356: the run is over
-        c->poisoned = true;
-        c->poison_code = prc;
-        return fail(c, prc, "%s", shk_run_error());
-      }
-      pk_src = (const uint8_t *)c->hp_pk[bsel].p;
-      nm_src = (const uint32_t *)c->hp_nm[bsel].p;
+    if (nb && hp) {  // (the packer thread has finished this slice: the caller checked)
+      pk_src = (const uint8_t *)c->hp_pk[0].p + hp_pk_off[i];
+      nm_src = (const uint32_t *)((const uint8_t *)c->hp_nm[0].p + hp_nm_off[i]);
       o_rel = 0;
     }
     if (nb && pk_src) {  // the slice's bytes of the 2-bit stream and words of the N mask (+ pad: k_unpack reads a few bytes on)
@@ -2094,7 +2150,23 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   };
   // (sets s0 … s0+NST−2 were last read by launches that a later launch of the previous call has waited for)
   int rc = SHK_OK;
-  for (size_t i = 0; i < std::min<size_t>(n_slices, (size_t)NST - 1) && rc == SHK_OK; ++i) rc = issue_copy(i);
+  // host packing: queue the copies of the slices that are packed, in order, up to slice max_j (what the staging sets
+  // allow at this point); need > 0: wait until `need` slices are packed first
+  auto hp_issue = [&](size_t max_j, size_t need) -> int {
+    const size_t have = hp_packed(need > 0, need);
+    if (have < need) {  // the packer gave up: encoding.rs:353-356, the run is over
+      c->poisoned = true;
+      c->poison_code = hp_rc;
+      return fail(c, hp_rc, "%s", hp_err.c_str());
+    }
+    while (hp_issued < have && hp_issued < n_slices && hp_issued <= max_j) {
+      const int r = issue_copy(hp_issued);
+      if (r != SHK_OK) return r;
+      ++hp_issued;
+    }
+    return SHK_OK;
+  };
+  for (size_t i = 0; !hp && i < std::min<size_t>(n_slices, (size_t)NST - 1) && rc == SHK_OK; ++i) rc = issue_copy(i);
   if (rc != SHK_OK) {
     (void)hipStreamSynchronize(c->copy_stream);
     return rc;
@@ -2104,6 +2176,13 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
   auto now_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
   for (size_t i = 0; i < n_slices; ++i) {
     const int bsel = set_of(i);
+    if (hp) {  // slice i must be on its way; slice i − 1's count may still be reading set (i − 1) % NST = slice i + NST − 1's
+      rc = hp_issue(i + (size_t)NST - 2, i + 1);
+      if (rc != SHK_OK) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        return rc;
+      }
+    }
     const double ta = now_us();
     HIPC(c, hipEventSynchronize(c->copy_done[bsel]));  // `rebased[bsel]` consumed; data resident
     if (trace) fprintf(stderr, "[slice %zu] copy waited %.0f us (at %.0f)", i, now_us() - ta, now_us());
@@ -2115,12 +2194,14 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
     }
     HIPC(c, hipStreamSynchronize(c->stream));
     if (trace) fprintf(stderr, " count(i-1) done at %.0f\n", now_us());
-    if (!hp && i + NST - 1 < n_slices) {
+    if (hp) {
+      rc = hp_issue(i + (size_t)NST - 1, 0);  // (whatever else is packed by now)
+    } else if (i + NST - 1 < n_slices) {
       rc = issue_copy(i + NST - 1);
-      if (rc != SHK_OK) {
-        (void)hipStreamSynchronize(c->copy_stream);
-        return rc;
-      }
+    }
+    if (rc != SHK_OK) {
+      (void)hipStreamSynchronize(c->copy_stream);
+      return rc;
     }
     const uint64_t r0 = cut[i], r1 = cut[i + 1];
     DevBuf &db = bases_of(bsel);
@@ -2139,8 +2220,8 @@ static int ingest_host(shk_ctx *c, const uint8_t *bases, const uint64_t *offsets
       (void)hipStreamSynchronize(c->copy_stream);  // do not leave a copy reading `rebased` behind
       return rc;
     }
-    if (hp && i + 2 < n_slices) {  // the next slice but one is packed (the host's own time) under this slice's count and the next one's copy
-      rc = issue_copy(i + 2);
+    if (hp) {  // (and what has been packed while this slice was launched)
+      rc = hp_issue(i + (size_t)NST - 1, 0);
       if (rc != SHK_OK) {
         (void)hipStreamSynchronize(c->copy_stream);
         return rc;
