@@ -204,8 +204,13 @@ class OwnerCounter:
         # What the engine counts while this round's flags and segments travel: the round BEFORE — its exchange ran
         # under this round's scatter — and then the next round's scatter (the engine hands its exchange buffers out
         # in turn: include/shk.h, shk_xchg_scatter_device).  Launched first, so the host's wait for the flags below
-        # costs the GPU nothing.
-        self._absorb_pending()
+        # costs the GPU nothing.  (A rank whose scatter — or this absorb — failed still takes part in the flags below:
+        # the others must not be left waiting in a collective.)
+        if err is None:
+            try:
+                self._absorb_pending()
+            except Exception as e:  # noqa: BLE001
+                err = e
         r2 = self.n_rounds & 1
         with self._on_comm_stream():
             st = self._dev(torch.tensor([1 if err is not None else 0, n_foreign], dtype=torch.int64))

@@ -439,3 +439,43 @@ def test_four_rank_owner_partitioned_ingest(orc, tmp_path, k, chunks, log_p1):
     t0 = np.load(tmp_path / "tot_0.npy")
     st = ref.stats
     assert list(t0[:5]) == [st["n_reads_ingested"], st["n_bases_read"], st["n_bases_ingested"], st["n_kmers_ingested"], st["n_unique_kmers"]]
+
+
+def _owner_error_worker(rank, world, port, k, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import sharkmer_amd as sa
+    from sharkmer_amd.dist import OwnerCounter, shard_batches
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_reads = 6000
+    bases, offsets = _owner_input(sa, n_reads, False)
+    bases = bases.copy()
+    bases[int(offsets[3100]) + 2] = ord("x")   # read 3100: rank 1's second batch (batches of 1000 go round robin)
+    eng = NumpyOwnerEngine(k, 2, 40, world, rank, 10 if k <= 21 else 10, 1024)
+    oc = OwnerCounter(eng, dist, round_bases=1000 * 160)
+    mine = shard_batches(n_reads, rank, world)
+    outcome = "finished"
+    try:
+        for first, n in mine:
+            oc.round((bases, offsets[first:first + n + 1], n, int(offsets[first + n] - offsets[first]), first))
+        oc.finalize_histograms()
+    except Exception as e:  # noqa: BLE001
+        outcome = f"{type(e).__name__}: {e}"
+    open(os.path.join(out_dir, f"outcome_{rank}.txt"), "w").write(outcome)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [21, 27])
+def test_a_failing_rank_takes_every_rank_out_of_the_pipelined_rounds(tmp_path, k):
+    """An invalid byte in ONE rank's batch of a later round — when an earlier round's segments are still waiting to be
+    absorbed — ends the round for everybody: the failing rank with the reference's text, its peer with "a peer rank
+    failed"; nobody is left waiting in a collective (the test would hang).  4-byte rounds and the wide ones."""
+    port = _free_port()
+    mp.spawn(_owner_error_worker, args=(2, port, k, str(tmp_path)), nprocs=2, join=True)
+    o0 = (tmp_path / "outcome_0.txt").read_text()
+    o1 = (tmp_path / "outcome_1.txt").read_text()
+    assert "Invalid character 'x' in sequence. Only ACGTN allowed." in o1, o1
+    assert "a peer rank failed" in o0, o0
