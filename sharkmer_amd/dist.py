@@ -340,7 +340,6 @@ class OwnerCounter:
 
     def finalize_histograms(self):
         dist = self.dist
-        self._absorb_pending()
         if self._trace is not None and self._trace[3]:
             import sys
             a, b, c, n = self._trace
@@ -349,6 +348,7 @@ class OwnerCounter:
             self._trace = [0.0, 0.0, 0.0, 0]
         err = None
         try:
+            self._absorb_pending()   # (the last round's segments)
             self.eng.finalize()
             h = self.eng.histograms()
             c = self.eng.counters()
