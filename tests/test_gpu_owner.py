@@ -210,13 +210,14 @@ def test_config5_owner_share_on_one_card(orc):
     """BASELINE.json configs[4] — 10 cumulative subsets (chunk lanes) of reads over a 3 Gb genome on 8 GPUs —
     as ONE owner's share on one card: owner 5 of 8, 10 lanes, a 2^30-slot table × (8 + 10·4) B = 51 GB (the
     whole key space would need 412 GB per rank).  Every read is offered, the seven other owners' records are
-    dropped in the level-1 pass (the same kernels the 8-GPU exchange runs).  SHK_SHARE_READS reads (default
-    125 M = one rank's share of the 1 B; set 1000000000 for all of them: every record this owner would receive).
+    dropped in the level-1 pass (the same kernels the 8-GPU exchange runs).  SHK_SHARE_READS reads: by default ALL
+    of the config's 10^9 — every record this owner would receive in the 8-GPU run (80 s on the box, most of it the
+    oracle's extractor over 150 Gbases on 16 CPUs); 125000000 = one rank's share, for a quick look.
     Checks: an EXACT probe set per chunk lane — 10^5 k-mers of sampled reads counted over all reads by the
     oracle's extractor; owned probes must come back with exactly that merged count, foreign ones with 0 —
     plus the size-independent properties of the incremental histograms."""
     from probe_util import ProbeChecker
-    n = int(os.environ.get("SHK_SHARE_READS", "125000000"))
+    n = int(os.environ.get("SHK_SHARE_READS", "1000000000"))
     L, k, batch, W, owner, chunks = 150, 21, 1_700_000, 8, 5, 10
     n = n // batch * batch
     spec = sa.SynthSpec(genome_len=3_000_000_000, read_len=L)
