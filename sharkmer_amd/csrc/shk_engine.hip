@@ -901,6 +901,7 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
     const uint64_t few_gib = (8ull << 30) / (rec32 ? 4 : 8) / NL;
     const bool hinted = c->cfg.table_capacity_hint && (double)c->cfg.table_capacity_hint <= 0.8 * (double)c->tb.cap;
     uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), hinted && env_int("SHK_WIDE_WINDOW", 1) ? c->tb.cap * 8 : c->tb.cap * 5 / 2);
+    if (env_int("SHK_ACC_MAX_MRECORDS", 0) > 0) bmax = std::min<uint64_t>(bmax, (uint64_t)env_int("SHK_ACC_MAX_MRECORDS", 0) << 20);  // test hook: small windows (several contexts on one card)
     bmax = std::max<uint64_t>(std::min(bmax, mem_records), kmers_ub);
     // a lane's regions take a lane's share of the window (+ 50 %: blocks of uneven read lengths), but at
     // least what one launch can put into a single lane

@@ -267,3 +267,68 @@ def test_config5_owner_share_on_one_card(orc):
         assert (h[j][:1002] >= bins[:1002].astype(np.uint64)).all()
     expect = 3e9 * (1 - np.exp(-total / 3e9)) / W
     assert abs(c["n_unique_kmers"] - expect) < 0.01 * expect
+
+
+# ---- BASELINE configs[3] as a WHOLE JOB on one card: eight owner shares, the real exchange, all 10^9 reads ------------
+
+def test_config4_whole_job_on_one_card(monkeypatch):
+    """What the 8-GPU run of configs[3] does, rank for rank, with the eight ranks as eight contexts (and threads) on ONE
+    card: every rank an owner share on a 2^30-slot table (8 × 12.9 GB), 125 M reads per rank generated round by round
+    (1.7 M reads = one exchange round), OwnerCounter's pipelined rounds with the real segment sizes (137 MB per owner
+    and round) over the in-process transport — only the links are missing.  SHK_JOB_READS: the job's reads (default
+    10^9; the deferred windows are capped at 1 G records per context so that eight of them fit one card).  Exact:
+    130 k-mers per read over all ranks, Σ freq·count = k-mer occurrences, every rank the same histogram; the distinct
+    count against the random-placement expectation."""
+    monkeypatch.setenv("SHK_ACC_MAX_MRECORDS", "1024")
+    W, L, k, round_reads = 8, 150, 21, 1_700_000
+    n_total = int(os.environ.get("SHK_JOB_READS", "1000000000"))
+    per_rank = n_total // W
+    n_rounds = -(-per_rank // round_reads)
+    spec = sa.SynthSpec(genome_len=3_000_000_000, read_len=L)
+    shared = ThreadGroup.Shared(W)
+    results, errors = [None] * W, []
+
+    def run(rank):
+        try:
+            eng = sa.KmerEngine(k, 1, 1000, capacity_hint=3_000_000_000 // W, n_owners=W, owner_id=rank)
+            assert eng.table_geometry()[0] * eng.table_geometry()[1] == 1 << 30
+            oc = OwnerCounter(eng, ThreadGroup(shared, rank), device=0, round_bases=round_reads * L)
+            d_bases = eng.alloc_device(round_reads * L)
+            d_off = eng.alloc_device((round_reads + 1) * 8)
+            try:
+                for r in range(n_rounds):
+                    n = min(round_reads, per_rank - r * round_reads)
+                    first = rank * per_rank + r * round_reads   # (any assignment of reads to ranks gives the same job)
+                    eng.synth_reads_device(spec, first, n, d_bases, d_off)
+                    lay = oc.round((d_bases, d_off, n, n * L, first))
+                    assert lay.n_owners == W
+                hist = oc.finalize_histograms()
+                results[rank] = (hist, dict(oc.totals), oc.n_foreign_rounds, eng.counters()["n_grows"])
+            finally:
+                eng.sync()
+                eng.free_device(d_bases)
+                eng.free_device(d_off)
+                eng.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    sa.release_cached_memory()
+    assert not errors, errors
+    n = per_rank * W
+    h0, tot, _, _ = results[0]
+    for hist, t, n_foreign, n_grows in results:
+        assert np.array_equal(hist, h0) and t == tot
+        assert n_grows == 0
+    assert tot["n_reads_ingested"] == n and tot["n_bases_ingested"] == n * L
+    assert tot["n_kmers_ingested"] == (L - k + 1) * n == tot["n_hashed_kmers"]
+    col = h0[0].astype(object)
+    assert sum(int(f) * i for i, f in enumerate(col)) == (L - k + 1) * n or int(col[-1]) > 0   # (the last bin clamps counts > histo_max)
+    assert int(h0[0].sum()) == tot["n_unique_kmers"]
+    expect = 3e9 * (1 - np.exp(-(L - k + 1) * n / 3e9))
+    assert abs(tot["n_unique_kmers"] - expect) < 0.01 * expect
