@@ -332,3 +332,30 @@ def test_config4_whole_job_on_one_card(monkeypatch):
     assert int(h0[0].sum()) == tot["n_unique_kmers"]
     expect = 3e9 * (1 - np.exp(-(L - k + 1) * n / 3e9))
     assert abs(tot["n_unique_kmers"] - expect) < 0.01 * expect
+
+
+# ---- a randomized sweep of the exchange rounds ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SHK_FUZZ_SEEDS", "24"))))
+def test_random_exchange_configuration_against_the_oracle(orc, monkeypatch, seed):
+    """World size, k (4-byte rounds or — where a record does not fit — the wide ones), chunk lanes, level-1 fan-out,
+    table size and input drawn from a seed: W contexts on one card as W ranks through OwnerCounter's pipelined rounds,
+    every rank's histogram and totals against the oracle."""
+    rng = np.random.default_rng(77_000 + seed)
+    W = int(rng.choice([1, 2, 2, 4, 8]))
+    k = int(rng.choice([13, 15, 17, 19, 21, 21, 22, 23, 27, 31]))
+    chunks = int(rng.choice([0, 1, 2, 3, 10, 16]))
+    lvl1 = int(rng.choice([6, 8, 10]))
+    hint = int(rng.choice([600_000, 1_000_000, 4_200_000]))
+    monkeypatch.setenv("SHK_LEVEL1_LOG", str(lvl1))
+    if rng.random() < 0.3:
+        monkeypatch.setenv("SHK_DEFER_BUDGET", str(int(rng.choice([30_000, 200_000]))))
+    n_reads = int(rng.integers(1_500, 14_000))
+    spec = sa.SynthSpec(genome_len=int(rng.choice([3_000, 60_000, 400_000])), sub_per_64k=int(rng.choice([0, 250, 2000])),
+                        n_per_64k=int(rng.choice([0, 50, 600])))
+    bases, offsets = sa.synth_reads(spec, int(rng.integers(0, 10_000)), n_reads)
+    if rng.random() < 0.25:   # low-complexity reads: one k-mer's records overflow their region → the foreign spill list
+        bases = bases.copy()
+        for i in range(0, n_reads, 5):
+            bases[int(offsets[i]):int(offsets[i + 1])] = ord("ACGT"[i % 4])
+    _exchange_run(orc, bases, offsets, k, chunks, 200, W, hint=hint)
