@@ -3,6 +3,7 @@ and a thread-based stand-in for torch.distributed moves the tensors between them
 HIP entry points (shk_table_reserve_pages, shk_owner_counts, shk_compact_owners, shk_merge_entries,
 shk_table_device_ptrs, shk_merge_pages, shk_set_owned_pages, owned-range finalize) are checked against the oracle.  The RCCL transport
 itself is exercised by bench.py --gpus N on the 8-GPU node."""
+import os
 import threading
 
 import numpy as np
@@ -190,3 +191,57 @@ def test_fixed_capacity_pieces_from_the_second_job_on(orc, monkeypatch, cap):
             assert n_fixed == 2 and n_rem <= 1  # (job 2 may outgrow the capacity learnt from job 1 — by design)
         else:
             assert n_fixed == 3 and n_rem == 3
+
+
+# ---- a randomized sweep of merge-at-finalize: what bench.py --gpus N runs, rank for rank -----------------------------------
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SHK_FUZZ_SEEDS", "16"))))
+def test_random_merge_at_finalize_jobs_against_the_oracle(orc, monkeypatch, seed):
+    """World size 2 … 8, k, chunk lanes, flags, the dense / packed piece format, and THREE jobs in a row on the same
+    contexts (the first asks for exact counts, the others take fixed-capacity pieces learnt from the job before — job
+    sizes drawn so that a later job may outgrow them), reads dealt to the ranks in 1000-read batches: every rank's
+    histogram and totals of every job against the oracle."""
+    rng = np.random.default_rng(55_000 + seed)
+    world = int(rng.choice([2, 2, 4, 8]))
+    k = int(rng.choice([11, 15, 19, 21, 21, 25, 31]))
+    chunks = int(rng.choice([0, 1, 2, 3, 10]))
+    flags = int(rng.choice([0, 0, sa.FLAG_FORCE_DIRECT, sa.FLAG_FORCE_PAGED]))
+    histo_max = int(rng.choice([5, 300]))
+    monkeypatch.setenv("SHK_DIST_DENSE", str(rng.choice(["0", "0", "1"])))
+    hints = [int(rng.choice([0, 0, 30_000, 400_000])) for _ in range(world)]   # (the ranks must agree on a geometry first)
+    jobs = []
+    for j in range(3):
+        n_reads = int(rng.integers(world * 1000, 16_000))
+        spec = sa.SynthSpec(genome_len=int(rng.choice([8_000, 60_000, 900_000])), sub_per_64k=int(rng.choice([0, 300])),
+                            n_per_64k=int(rng.choice([0, 60])))
+        bases, offsets = sa.synth_reads(spec, int(rng.integers(0, 50_000)), n_reads)
+        jobs.append((bases, offsets, n_reads, orc.run_batch(bases, offsets, k, chunks, histo_max)))
+    shared = ThreadGroup.Shared(world)
+    results, errors = [[] for _ in range(world)], []
+
+    def run(rank):
+        try:
+            eng = sa.KmerEngine(k, chunks, histo_max, capacity_hint=hints[rank], flags=flags)
+            dc = DistCounter(eng, ThreadGroup(shared, rank), device=0)
+            for bases, offsets, n_reads, _ in jobs:
+                eng.reset()
+                for first, n in shard_batches(n_reads, rank, world):
+                    eng.set_read_index(first)
+                    eng.ingest_reads(bases, offsets[first:first + n + 1])
+                results[rank].append((dc.finalize_histograms(), dict(dc.totals)))
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, (errors, dict(seed=seed, world=world, k=k, chunks=chunks, flags=flags))
+    for res in results:
+        for (hist, tot), (_, _, n_reads, ref) in zip(res, jobs):
+            assert np.array_equal(hist, ref.histograms()), dict(seed=seed, world=world, k=k, chunks=chunks, flags=flags)
+            for f in ("n_unique_kmers", "n_kmers_ingested", "n_bases_ingested", "n_reads_ingested", "n_bases_read"):
+                assert tot[f] == ref.stats[f], (f, seed)
