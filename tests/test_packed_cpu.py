@@ -62,6 +62,19 @@ def test_pack_n_vectors(seq, expected):
     assert [p for p in range(len(seq)) if (int(pk.nmask[p >> 5]) >> (p & 31)) & 1] == [i for i, ch in enumerate(seq) if ch == "N"]
 
 
+def test_packed_sizes_are_what_the_packer_writes():
+    """shk_packed_sizes: (n + 3) / 4 bytes of stream, (n + 31) / 32 words of N mask — the arrays pack_reads allocates."""
+    import ctypes as C
+    from sharkmer_amd.engine import load_front_library
+    L = load_front_library()
+    for n in (0, 1, 3, 4, 5, 31, 32, 33, 1000, 12345, (1 << 32) + 7):
+        pb, nw = C.c_uint64(99), C.c_uint64(99)
+        L.shk_packed_sizes(n, C.byref(pb), C.byref(nw))
+        assert (pb.value, nw.value) == ((n + 3) // 4, (n + 31) // 32), n
+    pk = _pack(b"ACGTN" * 7)
+    assert pk.packed.size == (35 + 3) // 4 and pk.nmask.size == (35 + 31) // 32
+
+
 def test_pack_matches_oracle_on_random_reads(orc):
     rng = np.random.default_rng(2)
     for _ in range(40):
