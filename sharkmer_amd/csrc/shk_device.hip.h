@@ -2118,6 +2118,28 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   uint32_t sub = 0;
   StageRegs32<NT, TT> pre;
   if (have) stage32_prefetch<NT, TT>(b, t0, pre);
+  // ALL-LANES mode walks a tile LIST (k_build_tiles): a tile's descriptor is two dependent loads away (how many tiles
+  // there are, then the descriptor), and the prefetch of its bases a third — asked for when the tile before it is
+  // staged, that chain stood in the stage phase of every tile (10 lanes: 169 k cycles per workgroup against 63 k with
+  // one lane).  So the descriptor of the tile AFTER the next one is asked for a whole tile ahead.
+  // (… and through the VECTOR memory path: a scalar load shares its counter with the LDS operations, so the first LDS
+  // wait after it would wait for it as well)
+  const uint64_t n_tiles_all = all_lanes && b.tiles ? (uint64_t)b.stats->n_tiles : 0;
+  auto desc_ahead = [&](uint64_t tt, uint64_t &d0, uint64_t &d1, uint32_t &dl) -> bool {
+    if (!b.tiles) return tile_get(b, tt, d0, d1, dl);
+    if (tt >= b.tile_count || tt + b.tile_first >= n_tiles_all) return false;
+    const TileDesc *p = b.tiles + tt + b.tile_first;
+    asm volatile("" : "+v"(p));  // (the address in vector registers: a global_load, counted by vmcnt)
+    const TileDesc d = *p;
+    d0 = d.begin;
+    d1 = d.end;
+    dl = d.lane;
+    return true;
+  };
+  uint64_t at = t + gridDim.x, a0 = 0, a1 = 0;
+  uint32_t al = 0;
+  bool a_have = false;
+  if (all_lanes && have) a_have = desc_ahead(at, a0, a1, al);
   while (have) {
     const uint64_t s0 = t0 + (uint64_t)sub * TT;
     const uint64_t s1 = s0 + TT < t1 ? s0 + TT : t1;
@@ -2150,9 +2172,15 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
     uint32_t nl = lane, nsub = sub + 1;
     bool hn = true;
     if (t0 + (uint64_t)nsub * TT >= t1) {
-      nt = t + gridDim.x;
-      hn = next_tile(b, nt, !all_lanes, lane_filter, n0, n1, nl);
       nsub = 0;
+      if (all_lanes) {  // the descriptor asked for a tile ago; the one after it is asked for now
+        nt = at, hn = a_have, n0 = a0, n1 = a1, nl = al;
+        at = nt + gridDim.x;
+        if (hn) a_have = desc_ahead(at, a0, a1, al);
+      } else {
+        nt = t + gridDim.x;
+        hn = next_tile(b, nt, !all_lanes, lane_filter, n0, n1, nl);
+      }
     }
     if (hn) stage32_prefetch<NT, TT>(b, n0 + (uint64_t)nsub * TT, pre);  // in flight during the rest of this one
     __syncthreads();
