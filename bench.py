@@ -222,15 +222,16 @@ def extras(sa, torch, dev):
             parts.append(pth)
         res = {"workload": f"{n} reads x {L} bp as FASTQ in the page cache → shk_run_files (parse + count + .histo/.stats.yaml), best of 3 (the first job of a process also maps the device and pinned memory that later ones find in the library's cache)"}
         for name, paths in (("plain", [plain]), ("gzip_8_files", parts), ("gzip_1_file", parts[:1])):
-            best = None
+            best, first = None, None
             for _ in range(3):
                 t0 = time.perf_counter()
                 sa.run_files(paths, k=21, chunks=1, histo_max=10000, sample="s", outdir=tmp, capacity_hint=3_000_000)
                 dt = time.perf_counter() - t0
+                first = dt if first is None else first
                 best = dt if best is None else min(best, dt)
             nn = n if name != "gzip_1_file" else n // NP
-            res[name] = {"Gbases_per_s": round(nn * L / best / 1e9, 3), "file_MB": round(sum(os.path.getsize(p_) for p_ in paths) / 1e6, 1),
-                         "bound": "host: read + inflate + line split"}
+            res[name] = {"Gbases_per_s": round(nn * L / best / 1e9, 3), "first_job_Gbases_per_s": round(nn * L / first / 1e9, 3),
+                         "file_MB": round(sum(os.path.getsize(p_) for p_ in paths) / 1e6, 1), "bound": "host: read + inflate + line split"}
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
         return res
