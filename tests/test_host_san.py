@@ -62,7 +62,8 @@ def _fastq(rng, n, bad=None):
 def test_threaded_reader_clean_under_tsan(san_libs, tmp_path):
     """ThreadSanitizer cannot be preloaded into the interpreter, so a native caller (tests/native/front_driver.cpp) drives
     the same entry points: several files at once — plain, gzip, gzip by magic, one truncated — through small windows and
-    many threads (producers running ahead, the inflate thread, both pools), then the packer.  No report, and the same
+    many threads (producers running ahead, the inflate thread, both pools), then the packer; and again with every gzip
+    member forced through the many-thread decoder (speculating workers, the stitcher, the files' turns).  No report, and the same
     digest as the unsanitized build."""
     import zlib
     import numpy as np
@@ -84,14 +85,20 @@ def test_threaded_reader_clean_under_tsan(san_libs, tmp_path):
     flawed.write_bytes(gz(_fastq(rng, 5000, bad=4000)))
     cut = tmp_path / "cut.fastq.gz"
     cut.write_bytes(gz(_fastq(rng, 5000))[:30000])
-    env = dict(os.environ)
-    env.update(SHK_FASTQ_WINDOW_KB="256", SHK_FASTQ_THREADS="6", SHK_FASTQ_COPY_THREADS="4")
+    env0 = dict(os.environ)
+    env0.update(SHK_FASTQ_WINDOW_KB="256", SHK_FASTQ_THREADS="6", SHK_FASTQ_COPY_THREADS="4")
     log = str(tmp_path / "tsan")
-    env["TSAN_OPTIONS"] = f"halt_on_error=0:exitcode=66:log_path={log}"
-    for args in (["0", "0", "20000", "3000000"] + files,
-                 ["61234", "7", "5000", "1000000"] + files,
-                 ["0", "1000", "100000", "30000000"] + files[:2] + [str(flawed)] + files[2:],
-                 ["0", "0", "100000", "30000000"] + files[:3] + [str(cut)]):
+    env0["TSAN_OPTIONS"] = f"halt_on_error=0:exitcode=66:log_path={log}"
+    pgz = dict(SHK_PGZ_MIN_KB="0", SHK_PGZ_CHUNK_KB="16", SHK_PGZ_THREADS="5")   # every member through the many-thread decoder, files in turn
+    for args, extra in ((["0", "0", "20000", "3000000"] + files, {}),
+                        (["61234", "7", "5000", "1000000"] + files, {}),
+                        (["0", "1000", "100000", "30000000"] + files[:2] + [str(flawed)] + files[2:], {}),
+                        (["0", "0", "100000", "30000000"] + files[:3] + [str(cut)], {}),
+                        (["0", "0", "20000", "3000000"] + files, pgz),
+                        (["9000", "0", "5000", "1000000"] + files, pgz),
+                        (["0", "0", "100000", "30000000"] + files[:3] + [str(cut)] + [str(flawed)], pgz)):
+        env = dict(env0)
+        env.update(extra)
         want = subprocess.run([os.path.join(CSRC, "front_driver_plain"), *args], env=env, capture_output=True, text=True, timeout=300)
         got = subprocess.run([os.path.join(CSRC, "front_driver_tsan"), *args], env=env, capture_output=True, text=True, timeout=600)
         reports = [f for f in os.listdir(tmp_path) if f.startswith("tsan.")]
