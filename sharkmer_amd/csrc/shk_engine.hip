@@ -1857,6 +1857,9 @@ void shk_destroy(shk_ctx *c) {
   c->xbuf_alt.release();
   c->part_meta_alt.release();
   c->xspill.release();
+  c->xw_kmers.release();  // (the wide exchange round's output: 12 B per k-mer of the largest batch)
+  c->xw_lanes.release();
+  c->xw_count.release();
   for (int i = 0; i < shk_ctx::NST; ++i) c->pk_stage[i].release(), c->nm_stage[i].release(), c->nz_dev[i].release(), c->nz_host[i].release(), c->hp_pk[i].release(), c->hp_nm[i].release();
   c->pk_ascii.release();
   lap("scratch given back");

@@ -492,20 +492,21 @@ struct PgzGate {
     cv.notify_all();
   }
 };
-static PgzGate &pgz_gate() {
-  static PgzGate g;
-  return g;
-}
+// (The gate belongs to ONE reader — shk_fastq::gate — not to the process: tickets only mean something inside one
+// reader's file order, and a source holds its turn until its member is decoded, which only advances while THAT reader
+// is consumed.  With a process-wide gate a second reader on a large .gz waited for the first to be drained — one thread
+// taking two readers in lockstep, as read_fastq_paired does with R1 / R2 (io.rs:629-700), never came back.)
 
 struct GzSource final : Source {
   GzMember gz;
+  PgzGate *gate;            // the reader's gate
   uint64_t ticket;          // this source's turn at the many-thread decoder
   bool ticket_done = false;
   std::atomic<bool> gate_abort{false};  // cancel(): stop waiting for the turn
   void ticket_leave() {
     if (!ticket_done) {
       ticket_done = true;
-      pgz_gate().leave(ticket);
+      gate->leave(ticket);
     }
   }
   std::shared_ptr<void> owner;  // the compressed bytes (a mapping or a vector)
@@ -522,7 +523,7 @@ struct GzSource final : Source {
   bool all_members = false;
   IoError members_err;
   static constexpr size_t DEPTH = 3;
-  GzSource(const uint8_t *p, const uint8_t *e, std::shared_ptr<void> own, uint64_t turn) : ticket(turn), owner(std::move(own)) {
+  GzSource(const uint8_t *p, const uint8_t *e, std::shared_ptr<void> own, PgzGate *gt, uint64_t turn) : gate(gt), ticket(turn), owner(std::move(own)) {
     window = 16u << 20;
     gz.open(p, e);
   }
@@ -538,7 +539,7 @@ struct GzSource final : Source {
     }
     cv.notify_all();
     gate_abort.store(true);
-    pgz_gate().poke();
+    gate->poke();
   }
   bool wants_crc() const override { return !all_members; }
   void emit(Window &&w) {
@@ -1002,7 +1003,7 @@ struct GzSource final : Source {
       // file gives 2.5-2.6 Gbases/s with 8 threads, 2.9-3.3 with 12, 2.2-3.0 with 16, 2.1 with 24)
       const uint32_t thr = e_thr ? (uint32_t)atoi(e_thr) : std::max(2u, std::min(32u, usable_cpus() * 3 / 4));
       if (thr > 1 && (size_t)(gz.inf.in_end - gz.inf.in) >= min_bytes) {
-        if (pgz_gate().enter(ticket, gate_abort)) run_parallel(thr, chunk);
+        if (gate->enter(ticket, gate_abort)) run_parallel(thr, chunk);
         ticket_leave();
         std::lock_guard<std::mutex> lk(m);
         done = true;
@@ -1243,6 +1244,7 @@ struct Producer {
   FileEnd end;
   static constexpr size_t Q_MAX = 256u << 20;  // bytes buffered ahead per file
   bool gz_all_members = false;  // (shk_fastq_open_ex: not the reference's behaviour)
+  PgzGate *gate = nullptr;      // the reader's gate (shk_fastq::gate)
   uint64_t pgz_ticket = 0;      // this file's turn at the many-thread gzip decoder (drawn in file order by the reader)
   bool ticket_given = false;    // … handed to a GzSource; otherwise given back as soon as the source is known
   const char *map = nullptr;  // plain files: the mapping the chunks point into (released with the producer)
@@ -1322,7 +1324,7 @@ struct Producer {
         }
         const bool magic = size >= 2 && (uint8_t)data[0] == 0x1f && (uint8_t)data[1] == 0x8b;
         if (gz_ext || magic) {
-          auto *g = new GzSource((const uint8_t *)data, (const uint8_t *)data + size, nullptr, pgz_ticket);
+          auto *g = new GzSource((const uint8_t *)data, (const uint8_t *)data + size, nullptr, gate, pgz_ticket);
           ticket_given = true;
           g->all_members = gz_all_members;
           return with_window(g);
@@ -1355,7 +1357,7 @@ struct Producer {
       if (r <= 0) break;
     }
     ::close(fd);
-    auto *g = new GzSource(all->data(), all->data() + all->size(), all, pgz_ticket);
+    auto *g = new GzSource(all->data(), all->data() + all->size(), all, gate, pgz_ticket);
     ticket_given = true;
     g->all_members = gz_all_members;
     return with_window(g);
@@ -1533,7 +1535,7 @@ struct Producer {
 
   void run() {
     const bool opened = open_source();
-    if (!ticket_given) pgz_gate().leave(pgz_ticket);  // (not a gzip file, or it could not be opened)
+    if (!ticket_given) gate->leave(pgz_ticket);  // (not a gzip file, or it could not be opened)
     if (!opened) return finish(end);
     Window w;
     bool saw_last = false;
@@ -1694,6 +1696,7 @@ struct PackWriter {
 
 struct shk_fastq {
   std::vector<std::string> paths;
+  PgzGate gate;  // this reader's files take the many-thread gzip decoder in turn (declared before `prod`: the sources hand their tickets back when they go)
   std::vector<std::unique_ptr<Producer>> prod;  // one per path; started up to LOOKAHEAD files ahead of the scout
   size_t started = 0;                           // producers started so far
   std::unique_ptr<Pool> pool, cpool;            // the producers' pool (window parse) and the consumer's (copy-out): they overlap
@@ -1751,7 +1754,8 @@ struct shk_fastq {
       p->pool = pool.get();
       p->T = T;
       p->gz_all_members = gz_all_members;
-      p->pgz_ticket = pgz_gate().draw();
+      p->gate = &gate;
+      p->pgz_ticket = gate.draw();
       Producer *pp = p.get();
       pp->th = std::thread([pp] { pp->run(); });
       prod.emplace_back(std::move(p));

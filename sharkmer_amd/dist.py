@@ -52,7 +52,17 @@ def exchange_parts(dist, out: torch.Tensor, inp: torch.Tensor, world: int, rank:
         in_splits = out_splits = [per] * world
     esz = inp.element_size()
     if in_pieces is None:
-        in_pieces = max(max(in_splits), max(out_splits)) * esz > MAX_MESSAGE_BYTES
+        largest = max(max(in_splits), max(out_splits)) * esz
+        if len(set(in_splits)) != 1 or list(in_splits) != list(out_splits):
+            # UNEQUAL parts and nobody has agreed on the route: a rank only sees its own row and column of the W x W
+            # part sizes, and a rank whose parts are all small must not call all_to_all_single while a pair with a
+            # large part waits in send/recv pairs (a hang on gloo, undefined pairing on RCCL).  One small
+            # all_reduce(MAX) makes the choice the same everywhere; callers that already hold a job-wide maximum
+            # pass in_pieces and skip it.
+            t = torch.tensor([largest], dtype=torch.int64, device=inp.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            largest = int(t.item())
+        in_pieces = largest > MAX_MESSAGE_BYTES
     if not in_pieces or not hasattr(dist, "batch_isend_irecv"):
         if in_splits[0] * world == inp.numel() and len(set(in_splits)) == 1 and list(in_splits) == list(out_splits):
             dist.all_to_all_single(out, inp)   # (in-process test transports have nothing else)
@@ -464,13 +474,17 @@ class DistCounter:
         while True:
             counts = np.asarray(self.eng.owner_counts(W), dtype=np.int64)   # what I hold of every owner's range
             counts[self.rank] = 0                                           # … my own range stays where it is
-            msg = np.empty((W, 2), dtype=np.int64)
+            # (third word: the largest part this rank SENDS — every part is sent by somebody, so the maximum over what a
+            # rank receives is the largest part of the whole exchange, the same number on every rank: it picks the
+            # route of the exchange below, which all ranks must take alike)
+            msg = np.empty((W, 3), dtype=np.int64)
             msg[:, 0] = n_pages
             msg[:, 1] = counts
+            msg[:, 2] = int(counts.max()) if W else 0
             send_n = self._dev(torch.from_numpy(msg.reshape(-1)))
             recv_n = torch.empty_like(send_n)
             dist.all_to_all_single(recv_n, send_n)
-            got = recv_n.cpu().numpy().reshape(W, 2)
+            got = recv_n.cpu().numpy().reshape(W, 3)
             P = int(got[:, 0].max())
             if P == n_pages and int(got[:, 0].min()) == n_pages:
                 break
@@ -479,6 +493,7 @@ class DistCounter:
             assert n_pages == P, (n_pages, P)
         recv = [int(x) for x in got[:, 1]]                              # what every peer holds of MY range
         send = [int(x) for x in counts]
+        largest_part = int(got[:, 2].max())                             # entries; the same on every rank
         self._last_max = max(max(send), max(recv))  # (finalize_histograms turns the job-wide maximum into the next capacity)
         if hasattr(self.eng, "compact_owner_packed") and self.device is not None:
             # k-mers and ALL lanes' counts of a peer in ONE collective: every owner's entries are one
@@ -489,7 +504,8 @@ class DistCounter:
                 buf, L = self.eng.compact_owner_packed(counts, self.rank)
                 w = 2 + L
                 rbuf = torch.empty(max(sum(recv) * w, 1), dtype=torch.int32, device=buf.device)[:sum(recv) * w]
-                exchange_parts(dist, rbuf, buf, W, self.rank, in_splits=[x * w for x in send], out_splits=[r * w for r in recv])
+                exchange_parts(dist, rbuf, buf, W, self.rank, in_splits=[x * w for x in send], out_splits=[r * w for r in recv],
+                               in_pieces=largest_part * w * buf.element_size() > MAX_MESSAGE_BYTES)
                 at = 0
                 for src in range(W):
                     self.eng.merge_packed_piece(rbuf[at:at + recv[src] * w], recv[src], L)
@@ -500,9 +516,11 @@ class DistCounter:
         n_recv = sum(recv)
         rk = keys.new_empty(n_recv)
         rv = vals.new_empty((n_lanes, n_recv))
-        exchange_parts(dist, rk, keys, W, self.rank, in_splits=send, out_splits=recv)
+        exchange_parts(dist, rk, keys, W, self.rank, in_splits=send, out_splits=recv,
+                       in_pieces=largest_part * keys.element_size() > MAX_MESSAGE_BYTES)
         for l in range(n_lanes):
-            exchange_parts(dist, rv[l], vals[l].contiguous(), W, self.rank, in_splits=send, out_splits=recv)
+            exchange_parts(dist, rv[l], vals[l].contiguous(), W, self.rank, in_splits=send, out_splits=recv,
+                           in_pieces=largest_part * vals.element_size() > MAX_MESSAGE_BYTES)
         if rk.is_cuda:
             # RCCL enqueues on torch's stream; the merge below runs on the engine's own HIP
             # stream, so the received entries must have landed before it is launched

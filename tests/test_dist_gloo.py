@@ -207,6 +207,55 @@ def test_two_rank_merge_matches_single_oracle(orc, tmp_path, monkeypatch, k, chu
                         st["n_kmers_ingested"], st["n_unique_kmers"]]
 
 
+def _skewed_merge_worker(rank, world, port, out_dir):
+    """Rank 0 holds many keys of owner 1's range; everything else anybody holds is a handful of keys."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["SHK_DIST_MAX_MESSAGE"] = "4096"   # bytes: 512 keys
+    os.environ["SHK_DIST_DENSE"] = "0"
+    from sharkmer_amd.dist import DistCounter
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    eng = NumpyPagedEngine(21, 1, 40)
+    eng.log_pages = 6   # 64 pages of 64 slots, 16 pages per owner
+    rng = np.random.default_rng(1234)   # the same stream on every rank: every rank can name every key
+    pool = rng.integers(1, 1 << 42, size=6000, dtype=np.int64)
+    owner = (_hash32(pool.astype(np.uint64)) >> np.uint64(32 - 6)).astype(np.int64) // 16
+    big = pool[owner == 1][:700]                      # 700 keys x 8 B = 5600 B > the limit: only the part 0 -> 1
+    small = [pool[owner == o][700:700 + 5] for o in range(world)]
+    mine = {int(x): 1 for o in range(world) for x in small[o]}
+    if rank == 0:
+        mine.update({int(x): 2 for x in big})
+    for key, c in mine.items():
+        eng.counts[key] = np.array([c], dtype=np.int64)
+    dc = DistCounter(eng, dist)
+    hist = dc.finalize_histograms()
+    np.save(os.path.join(out_dir, f"hist_{rank}.npy"), hist)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_four_rank_merge_with_one_oversized_part_takes_one_route_everywhere(tmp_path):
+    """Only the part rank 0 -> rank 1 is above the message limit; ranks 2 and 3 see nothing but small parts.  All four
+    must still take the same route through exchange_parts (send/recv pairs): a rank that chose all_to_all_single on
+    its own view left the others waiting (a hang under gloo, mispaired messages under RCCL).  The largest part of the
+    whole exchange rides in the (page count, counts) all_to_all that every rank already makes."""
+    world = 4
+    port = _free_port()
+    mp.spawn(_skewed_merge_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    hs = [np.load(tmp_path / f"hist_{r}.npy") for r in range(world)]
+    for h in hs[1:]:
+        assert np.array_equal(h, hs[0])
+    # 20 small keys held by all four ranks with count 1 each -> merged count 4; 700 keys with count 2 on rank 0 only
+    want = np.zeros_like(hs[0])
+    want[0, 4] = 20
+    want[0, 2] = 700
+    assert np.array_equal(hs[0], want)
+
+
 def test_shard_batches_cover_every_read_once():
     from sharkmer_amd.dist import shard_batches
     for n, w in [(0, 2), (999, 2), (1000, 2), (2500, 2), (10_001, 8), (123_456, 4)]:

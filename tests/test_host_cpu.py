@@ -310,3 +310,42 @@ def test_histo_files_load_the_way_the_viewer_loads_them(orc, tmp_path):
     # genomescopemovie.sh: the numeric rows, one column at a time, as "count<space>frequency" pairs
     rows = [ln.split("\t") for ln in (tmp_path / "v.histo").read_text().splitlines() if ln and ln[0].isdigit()]
     assert len(rows) == 51 and [int(r[0]) for r in rows] == list(range(1, 52)) and [int(r[2]) for r in rows] == list(h[1, 1:])
+
+
+@pytest.mark.timeout(120)
+def test_two_readers_on_large_gzip_files_in_lockstep(tmp_path, monkeypatch):
+    """Two readers open at once, each on a gzip member that takes the many-thread decoder, consumed in lockstep by one
+    thread — what read_fastq_paired does with R1 / R2 (io.rs:629-700).  The decoder's turn-taking is per READER (a
+    reader's files take the decoder in file order): with one process-wide gate the second reader's first batch waited
+    for the first reader to be drained, which a lockstep consumer never does.  Small windows and chunks so that the
+    decoder of a ~1 MB member really waits on its consumer (three windows ahead at most)."""
+    monkeypatch.setenv("SHK_FASTQ_WINDOW_KB", "32")
+    monkeypatch.setenv("SHK_PGZ_MIN_KB", "1")
+    monkeypatch.setenv("SHK_PGZ_CHUNK_KB", "16")
+    monkeypatch.setenv("SHK_PGZ_THREADS", "3")
+    rng = np.random.default_rng(11)
+    ta, sa_ = _ragged_fastq(rng, 7_000)
+    tb, sb = _ragged_fastq(rng, 7_000)
+    pa, pb = _tmp(tmp_path, "r1.fastq.gz", ta, gz=True), _tmp(tmp_path, "r2.fastq.gz", tb, gz=True)
+    ra, rb = sa.FastqReader([pa]), sa.FastqReader([pb])
+    got_a, got_b = [], []
+
+    def take(r, out):
+        b, o = r.next_batch(max_seqs=100, max_bases=1 << 16)
+        out += [b[int(o[i]):int(o[i + 1])].tobytes().decode() for i in range(len(o) - 1)]
+        return r.stats()["done"]
+    done_a = done_b = False
+    while not (done_a and done_b):
+        if not done_a:
+            done_a = take(ra, got_a)
+        if not done_b:
+            done_b = take(rb, got_b)   # (used to block here until reader A had been drained)
+    ra.close()
+    rb.close()
+    assert got_a == sa_ and got_b == sb
+    # … and a reader left open and undrained does not stall a later one
+    rc_ = sa.FastqReader([pa])
+    take(rc_, [])
+    bases, offs, st = read_all([pb])
+    assert st["n_reads_read"] == len(sb)
+    rc_.close()
