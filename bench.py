@@ -352,7 +352,41 @@ def extras(sa, torch, dev):
 
 def owner_config(args, real_stdout):
     """--config 4 / 5: one rank's share of BASELINE.json configs[3] / configs[4] per GPU, key-space-partitioned ingest
-    (reference semantics: io.rs:340-361 striping by global read index, io.rs:1023-1028 per-chunk histograms)."""
+    (reference semantics: io.rs:340-361 striping by global read index, io.rs:1023-1028 per-chunk histograms).
+
+    --config 5 on ONE card (the whole key space — 48 B x 2^33 slots — does not fit it) has two ways to load the card:
+      * exchange (the line's `value`): a world of one that is loaded the way a RANK OF THE 8-GPU JOB is — its own 125 M
+        reads scattered, as many records absorbed as it scatters (in the job: an eighth of eight ranks' records), into
+        the rank's real table: 2^30 slots x 48 B, filled by the 375 Mb eighth of the genome its share of the key space
+        amounts to.  Everything a rank does per step except waiting for the links.
+      * drop (`extras.drop_mode`): owner 0 of 8 of the 3 Gb genome — every read offered, 7/8 of the records dropped in
+        the level-1 pass, 1/8 absorbed.  The scatter sees the job's real key distribution; the passes behind it see an
+        eighth of a rank's load — an upper bound, not a configs[4] rate."""
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    mode = args.mode
+    if mode == "auto":
+        mode = "exchange"
+    if args.config == 5 and world in (2, 3) and mode != "drop":
+        raise SystemExit("--config 5 needs 1 GPU (one rank's load, or --mode drop) or >= 4 GPUs (the key space must fit)")
+    out = owner_run(args, args.config, mode, dist_ready=False)
+    if args.config == 5 and world == 1 and mode == "exchange" and not args.no_extras:
+        try:
+            d = owner_run(args, 5, "drop", dist_ready=True)
+            out["extras"] = {"drop_mode": {key: d[key] for key in ("value", "ms_per_step", "config", "kernels_ms_per_step", "table", "roofline")}}
+        except Exception as e:  # noqa: BLE001 — an extra must not take the line down
+            out["extras"] = {"drop_mode": {"error": f"{type(e).__name__}: {e}"[:300]}}
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def owner_run(args, config, mode, dist_ready):
+    """One measurement of --config 4 / 5 (see owner_config); returns the line as a dict on rank 0 (None elsewhere)."""
     import torch
     import sharkmer_amd as sa
     from sharkmer_amd.dist import OwnerCounter
@@ -361,20 +395,19 @@ def owner_config(args, real_stdout):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     L, k, histo_max = 150, 21, args.histo_max
-    lanes = 1 if args.config == 4 else 10
-    genome = 3_000_000_000
+    lanes = 1 if config == 4 else 10
     JOB_GPUS = 8                                  # BASELINE.json: "8×MI355X"
+    drop_mode = mode == "drop"
+    # the genome a rank's table sees: the job's 3 Gb — or, where ONE rank stands in for a rank of the 8-GPU job (config
+    # 5, a world of one, exchange mode), the eighth of it that a rank's share of the key space amounts to
+    rank_load = config == 5 and world == 1 and not drop_mode
+    genome = 3_000_000_000 // JOB_GPUS if rank_load else 3_000_000_000
     rpr = args.reads or 10**9 // JOB_GPUS         # reads per rank: its share of the job as stated
     steps, warmup = args.steps if args.steps != 100 else 3, args.warmup if args.warmup != 50 else 1
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
-    # how the rank takes part: exchange rounds over RCCL among `world` owners — or, where the whole key space does not
-    # fit the ranks there are (config 5 on one card: 48 B × 2^33 slots), as owner 0 of 8, dropping the others' records
-    drop_mode = args.config == 5 and world < 4
-    if drop_mode and world > 1:
-        raise SystemExit("--config 5 needs 1 GPU (one owner's share, no exchange) or >= 4 GPUs (the key space must fit)")
     import torch.distributed as dist
-    if not drop_mode:
+    if not drop_mode and not dist.is_initialized():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29532")
@@ -490,12 +523,15 @@ def owner_config(args, real_stdout):
             cpu = {"value": round(ns * L / cdt / 1e9, 5), "unit": "Gbases/s", "cores": 1, "kind": "port",
                    "sample": f"the first {ns} reads of the job ({lanes} chunk lane(s)), single-threaded C restatement of sharkmer's counting path",
                    "cpu_model": cpu_model()}
-        which = "configs[3]" if args.config == 4 else "configs[4]"
+        which = "configs[3]" if config == 4 else "configs[4]"
         how = (f"owner 0 of {n_owners}: every read of the share offered, the other owners' records dropped in the level-1 pass (no exchange)"
                if drop_mode else f"exchange rounds among {world} owner share(s) over RCCL (OwnerCounter)")
+        if rank_load:
+            how += (f" — ONE card loaded like a rank of the {JOB_GPUS}-GPU job: its {rpr} reads scattered, as many records absorbed as scattered, "
+                    f"the rank's table ({genome} bp of distinct k-mers, {lanes} lanes); no link time")
         out = {
             "metric": "Gbases/sec k-mer counted (k=21, 150bp reads); histogram bit-exact vs CPU",
-            "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "value": round(value, 4), "unit": "Gbases/s", "n_gpus": (dist.get_world_size() if dist.is_initialized() else 1), "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"BASELINE.json {which}: one rank's share per GPU — {rpr} synthetic {L}bp reads of a {genome} bp genome, k={k}, "
@@ -510,14 +546,75 @@ def owner_config(args, real_stdout):
             "histogram_rows_sum_to_distinct": bool(int(hist[-1, 1:].sum()) == int(tot["n_unique_kmers"])),
             "table": {"capacity": cap, "n_grows": cnt["n_grows"], "n_spilled": cnt["n_spilled"]},
         }
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    else:
+        out = None
     eng.close()
-    if not drop_mode:
-        dist.destroy_process_group()
+    del d_all, d_off
+    torch.cuda.empty_cache()
+    return out
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """`python3 bench.py --gpus N` without a launcher in front: start N fresh rank processes — one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* set the way torch.distributed.run sets them — wait for them and hand rank 0's
+    ONE JSON line on.  Called before this process has imported torch or touched HIP (a process that holds the GPU must
+    not exec or fork into another GPU program on this pool); the children are ordinary child processes, never an exec
+    of this one.  A rank that fails takes the others down with it and the parent exits non-zero.
+    SHK_BENCH_CHILD: the child's command (a test hook: a stub that records its environment)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    child = os.environ.get("SHK_BENCH_CHILD")
+    cmd = child.split() if child else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: what RCCL needs between processes on this pool)
+        procs.append(subprocess.Popen(cmd + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        pending = list(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.remove(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the others", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    lines = [ln for ln in out0.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
 
 
 def main():
+    # `--gpus N` with no launcher in front (WORLD_SIZE unset): this process becomes the launcher — BEFORE torch or HIP
+    # are touched — and the N ranks are its children
+    if "WORLD_SIZE" not in os.environ:
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--gpus", type=int, default=1)
+        n_req = pre.parse_known_args()[0].gpus
+        if n_req > 1:
+            sys.exit(launch_ranks(n_req, sys.argv[1:]))
     # ONE line on stdout, whatever libraries print on theirs (RCCL announces its version there when a communicator
     # is created): the process's stdout goes to stderr until the JSON line is written to the real one
     sys.stdout.flush()
@@ -531,6 +628,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", type=int, choices=[2, 4, 5], default=2,
                     help="2: BASELINE configs[1] (the metric's configuration); 4 / 5: configs[3] / configs[4], a rank's share per GPU")
+    ap.add_argument("--mode", choices=["auto", "exchange", "drop"], default="auto",
+                    help="--config 4 / 5: exchange rounds over RCCL (auto) or one owner's share with the others' records dropped")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: 1 M for --config 2, 125 M for 4 / 5)")
     ap.add_argument("--batches", type=int, default=4, help="--config 2: distinct resident batches the steps rotate over")
     ap.add_argument("--k", type=int, default=21)
@@ -567,7 +666,7 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world
+    n_gpus = dist.get_world_size() if dist is not None else 1   # (as the communicator saw it)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -670,7 +769,7 @@ def main():
         rec_bytes = 4 if 2 * args.k - 10 <= 32 else 8
         def alg_bytes(name, lps):
             return {
-                "scatter": (n_bases * 1 + n_kmers * 8) / lps,      # bases read + one record per k-mer written (8 B; the kernel moves rec_bytes)
+                "scatter": (n_bases * 1 + n_kmers * rec_bytes) / lps,   # bases read + one record per k-mer written, at the width in use (what the kernel must move by design; §8d's 8-byte figure: achieved_sec8d_GBps)
                 "pages": n_kmers * rec_bytes / lps + cap * (8 + 4 * lanes),   # records read at the width in use + every page written out once
                 "histo": cap * (8 + 4 * lanes),                    # one table scan per histogram emit
                 "direct": (n_bases * 1 + n_kmers * 16 + nd * 8) / lps,
@@ -695,9 +794,12 @@ def main():
                 avg = ms / launches
                 ab = alg_bytes(name, lps)
                 phys = traffic_kernels.get(name, {}).get("hbm_bytes_per_launch")
+                # (SURVEY.md §8d prices a k-mer record at 8 bytes whatever travels: the same time against that figure)
+                ab8 = (n_bases * 1 + n_kmers * 8) / lps if name == "scatter" else (n_kmers * 8 / lps + cap * (8 + 4 * lanes) if name == "pages" else ab)
                 per_kernel[name] = {"avg_launch_ms": round(avg, 4), "launches_per_step": lps,
                                     "alg_bytes_per_launch": int(ab),
-                                    "achieved_GBps": round(ab / (avg * 1e-3) / 1e9, 1),           # algorithmic bytes ÷ time
+                                    "achieved_GBps": round(ab / (avg * 1e-3) / 1e9, 1),           # bytes the kernel must move by design ÷ time
+                                    "achieved_sec8d_GBps": round(ab8 / (avg * 1e-3) / 1e9, 1),    # §8d's 8-byte-record bytes ÷ the same time
                                     "hbm_bytes_per_launch": phys,
                                     "physical_GBps": round(phys / (avg * 1e-3) / 1e9, 1) if phys else None}  # PMC bytes ÷ time
         hot = [k_ for k_ in ("direct", "scatter", "pages") if k_ in per_kernel]
@@ -709,7 +811,9 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(d["achieved_GBps"] / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "traffic_source": traffic_src if traffic else None, "alg_bytes_per_launch": d["alg_bytes_per_launch"],
-                    "avg_launch_ms": d["avg_launch_ms"], "physical_GBps": d["physical_GBps"]}
+                    "avg_launch_ms": d["avg_launch_ms"], "physical_GBps": d["physical_GBps"], "achieved_sec8d_GBps": d["achieved_sec8d_GBps"],
+                    "what": "bytes the dominant kernel must move by design (records at the width in use) ÷ its average launch time; "
+                            "achieved_sec8d_GBps prices a record at SURVEY §8d's 8 bytes; roofline_path is the whole step against §8d"}
         # the whole counting path against SURVEY.md §8d's B_alg (1 B/base + 16 B/k-mer + 8 B/distinct
         # + one table scan per emit), over the summed device time of its kernels
         path_ms = sum(ms for name, (ms, _) in tim.items()
@@ -770,6 +874,23 @@ def main():
             del d_offsets
             torch.cuda.empty_cache()
             out["extras"] = extras(sa, torch, dev)
+    else:
+        out = None
+    if world > 1 and not args.no_extras:
+        # N > 1: the same ranks then run one rank's share each of BASELINE configs[3] (1 B reads of a 3 Gb genome over
+        # 8 GPUs; key-space-partitioned ingest, the records exchanged by owner every round) — the multi-GPU
+        # configuration the north star names, on record beside the metric's own configuration
+        eng.close()
+        d_bases.clear()
+        torch.cuda.empty_cache()
+        import copy
+        a4 = copy.copy(args)
+        a4.steps, a4.warmup, a4.reads, a4.no_cpu_baseline = min(args.steps, 3), 1, 0, True
+        c4 = owner_run(a4, 4, "exchange", dist_ready=True)
+        if rank == 0:
+            out["extras"] = {"config4": {key: c4[key] for key in ("value", "ms_per_step", "n_gpus", "config", "kernels_ms_per_step", "exchange",
+                                                                     "kmers_as_expected", "histogram_rows_sum_to_distinct", "table")}}
+    if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     eng.close()

@@ -269,6 +269,96 @@ def test_config5_owner_share_on_one_card(orc):
     assert abs(c["n_unique_kmers"] - expect) < 0.01 * expect
 
 
+# ---- BASELINE configs[4] as a WHOLE JOB on one card: the eight owner shares one after the other ------------------------
+
+def test_config5_whole_job_eight_shares_in_sequence(orc):
+    """BASELINE.json configs[4] — 10 cumulative subsets of 10^9 reads over a 3 Gb genome on 8 GPUs (io.rs:340-361: read i
+    belongs to subset (i / 1000) % 10; io.rs:1023-1028: column j of the histogram is taken after subsets 0..j) — as a JOB:
+    the eight owner shares (10 lanes, 2^30 slots x 48 B = 51 GB each; all eight at once would be 412 GB) counted ONE AFTER
+    THE OTHER on one card, each offered every read of the job with the other owners' records dropped in the level-1 pass
+    (the kernels the 8-GPU exchange runs), and the eight 10-column histograms SUMMED — bins are additive over disjoint
+    key sets (counting.rs:157-166), which is what the 8-GPU run's final all-reduce does.  SHK_JOB5_READS: the job's reads
+    (default 10^9).  Exact checks on the job's result:
+      * column j: sum of freq x count = the k-mer occurrences of subsets 0..j = (j + 1) x n / 10 x 130, for every j;
+      * columns only ever gain k-mers; the last column's distinct count against the random-placement expectation;
+      * a probe set over ALL owners — 10^5 k-mers of sampled reads counted per subset over all reads by the oracle's
+        extractor in ONE sweep of the reads (during the first share's pass): every probe is found in exactly one share,
+        with exactly the merged count, and the summed histogram's columns hold at least the probes' bins."""
+    from probe_util import ProbeChecker
+    n = int(os.environ.get("SHK_JOB5_READS", "1000000000"))
+    L, k, batch, W, chunks, hmax = 150, 21, 1_700_000, 8, 10, 1000
+    n = n // 10_000 * 10_000                     # (whole rounds of the ten subsets: every subset gets n / 10 reads)
+    n_batches = -(-n // batch)
+    spec = sa.SynthSpec(genome_len=3_000_000_000, read_len=L)
+    pc = ProbeChecker(orc, k, chunks, L, n_probes=100_000)
+    hist_sum = np.zeros((chunks, hmax + 2), dtype=object)
+    tot = {"n_kmers_ingested": 0, "n_unique_kmers": 0, "n_hashed_kmers": 0}
+    found = None
+    probes = None
+    for owner in range(W):
+        with sa.KmerEngine(k, chunks, hmax, capacity_hint=3_000_000_000 // W, n_owners=W, owner_id=owner) as eng:
+            n_pages, page_slots, n_lanes = eng.table_geometry()
+            assert n_pages * page_slots == 1 << 30 and n_lanes == chunks
+            d_bases = eng.alloc_device(batch * L)
+            d_off = eng.alloc_device((batch + 1) * 8)
+            try:
+                if owner == 0:
+                    for s_batch in (0, n_batches // 2, n_batches - 1):
+                        eng.synth_reads_device(spec, min(s_batch * batch + 4321, n - 320), 320, d_bases, d_off)
+                        eng.sync()
+                        pc.add_sample(pc._fetch(eng, d_bases, 320), 320)
+                    probes = pc.freeze()
+                    found = np.zeros(len(probes), dtype=np.int64)
+                    merged_got = np.zeros(len(probes), dtype=np.uint64)
+                for b in range(n_batches):
+                    nb = min(batch, n - b * batch)
+                    eng.synth_reads_device(spec, b * batch, nb, d_bases, d_off)
+                    eng.ingest_reads_device(d_bases, d_off, nb, nb * L)
+                    if owner == 0:               # the oracle's one sweep of the reads
+                        pc.count_async(pc._fetch(eng, d_bases, nb), nb, b * batch)
+                eng.finalize()
+                h = eng.histograms()
+                c = eng.counters()
+                got = eng.lookup(probes)
+            finally:
+                eng.sync()
+                eng.free_device(d_bases)
+                eng.free_device(d_off)
+        assert c["n_reads_ingested"] == n and c["n_hashed_kmers"] == c["n_kmers_ingested"] and c["n_grows"] == 0
+        assert int(h[-1].sum()) == c["n_unique_kmers"]
+        hist_sum += h.astype(object)
+        for f in tot:
+            tot[f] += c[f]
+        found += (got > 0)
+        merged_got += got.astype(np.uint64)
+        own = _owner_of(probes, k, W) == owner
+        assert not (got[~own] > 0).any()                                   # a share holds nothing of the other owners
+        sa.release_cached_memory()
+    per_lane = pc.result()
+    pc.close()
+    # ---- the job's result --------------------------------------------------------------------------------------
+    occ = (L - k + 1) * n
+    assert tot["n_kmers_ingested"] == occ == tot["n_hashed_kmers"]         # every occurrence counted by exactly one share
+    per_subset = (L - k + 1) * (n // chunks)
+    for j in range(chunks):
+        col = hist_sum[j]
+        assert int(col[-1]) == 0                                           # (50x coverage: nothing near histo_max, so the sums below are exact)
+        assert sum(int(f) * i for i, f in enumerate(col)) == (j + 1) * per_subset, j
+        if j:
+            assert int(col.sum()) >= int(hist_sum[j - 1].sum())
+    assert int(hist_sum[-1].sum()) == tot["n_unique_kmers"]
+    expect = 3e9 * (1 - np.exp(-occ / 3e9))
+    assert abs(tot["n_unique_kmers"] - expect) < 0.01 * expect
+    # every probe in exactly one share, with exactly the merged count
+    assert (found == 1).all()
+    want = np.minimum(per_lane.sum(axis=0), 0xFFFFFFFF).astype(np.uint64)
+    assert np.array_equal(merged_got, want)
+    cum = np.minimum(np.cumsum(per_lane, axis=0), 0xFFFFFFFF)
+    for j in (0, chunks // 2, chunks - 1):
+        bins = np.bincount(np.minimum(cum[j][cum[j] > 0], hmax + 1).astype(np.int64), minlength=hmax + 2)
+        assert all(int(hist_sum[j][i]) >= int(bins[i]) for i in range(hmax + 2))
+
+
 # ---- BASELINE configs[3] as a WHOLE JOB on one card: eight owner shares, the real exchange, all 10^9 reads ------------
 
 def test_config4_whole_job_on_one_card(monkeypatch):
