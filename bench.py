@@ -303,6 +303,8 @@ def extras(sa, torch, dev):
     def shapes():
         res = {}
         for name, genome, n, chunks, steps in (("config2_10_lanes", 3_000_000, 1_000_000, 10, 30),
+                                               ("config2_40_lanes", 3_000_000, 1_000_000, 40, 10),
+                                               ("config2_100_lanes", 3_000_000, 1_000_000, 100, 5),   # the reference's own historical runs: n = 100 (sharkmer_viewer/tests/data/Cordagalma.stats)
                                                ("genome_30Mb_1_lane", 30_000_000, 1_700_000, 1, 10),
                                                ("genome_30Mb_10_lanes", 30_000_000, 1_700_000, 10, 10)):
             spec = sa.SynthSpec(genome_len=genome, read_len=L)

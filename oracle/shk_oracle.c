@@ -973,16 +973,14 @@ static long source_read(byte_source *s, unsigned char *dst, size_t cap, io_err *
       int rc = inflate(&s->zs, Z_NO_FLUSH);
       size_t got = cap - s->zs.avail_out;
       if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
-        /* (what this call had written is NOT handed out by flate2 either: the read fails) — but
-         * everything a decoder can say before the damage is kept here, as in the product; see
-         * DESIGN.md on which record a corrupt stream is blamed on */
-        if (got) {
-          s->crc = (uint32_t)crc32(s->crc, dst, (uInt)got);
-          s->amount += got;
-          s->gz_state = 0;
-          io_set(&s->gz_err, IOK_INVALID_INPUT, "corrupt deflate stream");
-          return (long)got;
-        }
+        /* flate2's zio::read: `Err(..) => return Err(io::Error::new(InvalidInput, "corrupt deflate
+         * stream"))` — the bytes this very call had already written into the caller's buffer (`got`:
+         * up to the 8 KiB of BufReader's fill_buf; the call began where the one before it ended, i.e.
+         * at the last point where the output buffer was full or the 32 KiB of compressed input ran
+         * out) are NOT handed out: the read fails, BufReader's buffer stays empty, read_until returns
+         * the error.  Round 4: restated here as it is (rounds 2-3 kept those bytes, as the product does
+         * — see DESIGN.md §2 on which record a corrupt stream is blamed on). */
+        (void)got;
         io_set(err, IOK_INVALID_INPUT, "corrupt deflate stream");
         s->gz_state = 3;
         return -1;

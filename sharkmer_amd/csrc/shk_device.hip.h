@@ -2055,6 +2055,7 @@ __device__ __forceinline__ void place_entries(uint32_t *__restrict__ sorted, con
 // records' worth of regions and their cursor words — is ONE contiguous piece of each array (what crosses
 // the link in a multi-GPU run).  keep = an owner id: records of every other owner are dropped in the walk
 // and there is a single segment (seg_recs = 0); keep = ~0: all owners' records are kept.
+constexpr uint32_t SC32_MAX_LANES = 128;  // chunk lanes one all-lanes pass of k_scatter32 takes (its per-lane base counts: 1 KiB of static LDS)
 struct OwnerCfg {
   uint32_t log_w;     // owner bits (≤ log_parts)
   uint32_t keep;      // owner id to keep, or ~0 = all
@@ -2071,11 +2072,11 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[NT / 64];
   __shared__ uint32_t red[NT / 64];
-  __shared__ unsigned long long lane_nn[64];  // ALL-LANES mode: non-N bases per chunk lane (n_lanes ≤ 64 here)
+  __shared__ unsigned long long lane_nn[SC32_MAX_LANES];  // ALL-LANES mode: non-N bases per chunk lane
   // lane_filter = ~0: ALL-LANES mode — one pass over the tiles of every chunk lane; region and cursor
   // index = lane · P + page (n_region_lanes · P regions, block-interleaved together)
   constexpr bool all_lanes = ALL;  // (the host picks the variant from lane_filter == ~0)
-  if (all_lanes && threadIdx.x < 64) lane_nn[threadIdx.x] = 0;
+  if (all_lanes && threadIdx.x < SC32_MAX_LANES) lane_nn[threadIdx.x] = 0;
   static_assert(TILE_T % TT == 0 && TT % (8 * NT) == 0 && 4 * TT >= TT + HALO + 4 * ((TT + HALO) / 16), "tile shape");
   constexpr int SPAN = TT / NT;
   constexpr int GROUPS = (TT + HALO) / 16;
@@ -2444,7 +2445,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
   }
   __syncthreads();
   if (all_lanes) {
-    if (threadIdx.x < 64 && threadIdx.x < n_region_lanes && lane_nn[threadIdx.x])
+    if (threadIdx.x < SC32_MAX_LANES && threadIdx.x < n_region_lanes && lane_nn[threadIdx.x])
       atomicAdd(&lane_bases[threadIdx.x], lane_nn[threadIdx.x]);
   } else {
     uint32_t tot = wg_sum<NT>(n_non_n, red);

@@ -705,7 +705,10 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
 // touched page is read and written once per pass.
 static bool paged_feasible(const shk_ctx *c) {
   // one level up to MAX_PARTS pages, two levels (super-pages of ≤ MAX_PARTS pages) beyond
-  return c->tb.log_pages + c->owner_bits <= 20 && c->n_lanes <= 16;
+  // (Chunk lanes: 16 until round 4 — "the lane rounds stay few".  Nothing in the paged passes depends on it: with
+  // 40 lanes config 2's batch runs at 118 Gbases/s paged against 19.5 through the global atomics, with 100 — what
+  // the reference's own historical runs used, sharkmer_viewer/tests/data/Cordagalma.stats — see DESIGN.md §8.)
+  return c->tb.log_pages + c->owner_bits <= 20 && c->n_lanes <= (uint32_t)env_int("SHK_PAGED_MAX_LANES", (int)shk::SC32_MAX_LANES);
 }
 static bool paged_pays(const shk_ctx *c, uint64_t sub_kmers_ub) {
   return c->tb.log_pages >= 8 && sub_kmers_ub >= c->tb.cap / 2;
@@ -764,7 +767,7 @@ static bool use_rec32(const shk_ctx *c, const PartGeom &g) {
 #define SHK_SC32_WGS 1
 #endif
 constexpr int SC32_NT = SHK_SC32_NT, SC32_TT = 16 * SHK_SC32_NT;  // k_scatter32: 64 KiB of records + 64 KiB of entries in LDS,
-constexpr size_t SC32_LDS_MAX = 160 * 1024 - 1024;  // one workgroup per CU (its static LDS is < 1 KiB)
+constexpr size_t SC32_LDS_MAX = 160 * 1024 - 2048;  // one workgroup per CU (its static LDS is < 2 KiB: per-lane base counts of up to 128 chunk lanes)
 static size_t scatter32_lds(uint32_t P1) {
   return (size_t)SC32_TT * 8 + (size_t)P1 * 12 + 32;  // entries (+ P1/2 holes at most) + records + three words per partition (+ the walk's 8 spare counters when P1 < 8)
 }
@@ -776,14 +779,14 @@ static bool use_scatter32(const shk_ctx *c, const PartGeom &g) {
 // and cursors per (lane, page)) and counted by ONE k_pages32 launch that keeps a page in LDS for all
 // its lanes — instead of one scatter + one page pass per lane.  One level, k_scatter32 only.
 static bool use_all_lanes(const shk_ctx *c, const PartGeom &g, bool multi) {
-  return multi && !g.two_level && use_scatter32(c, g) && c->n_lanes <= 64 && env_int("SHK_ALL_LANES", 1) != 0;
+  return multi && !g.two_level && use_scatter32(c, g) && c->n_lanes <= shk::SC32_MAX_LANES && env_int("SHK_ALL_LANES", 1) != 0;
 }
 // The OWNER LAYOUT route (xl_count): ONE level-1 scatter for the tiles of every chunk lane into regions
 // ordered [owner][lane][super-page], then ONE level-2 pass per owner segment into the waiting (lane, page)
 // regions.  It is what an owner share always takes, and what a whole-key-space context takes for a
 // deferred two-level pass over several lanes (instead of a scatter + re-scatter per lane).
 static bool xl_feasible(const shk_ctx *c, const PartGeom &g) {
-  return g.two_level && use_scatter32(c, g) && (1u << g.log_sub) <= (uint32_t)MAX_PARTS && c->n_lanes <= 64 &&
+  return g.two_level && use_scatter32(c, g) && (1u << g.log_sub) <= (uint32_t)MAX_PARTS && c->n_lanes <= shk::SC32_MAX_LANES &&
          g.lpg <= MAX_LOG_PAGES;
 }
 static bool xl_route(const shk_ctx *c, const PartGeom &g, bool multi, bool defer) {

@@ -523,9 +523,46 @@ struct GzSource final : Source {
   bool all_members = false;
   IoError members_err;
   static constexpr size_t DEPTH = 3;
-  GzSource(const uint8_t *p, const uint8_t *e, std::shared_ptr<void> own, PgzGate *gt, uint64_t turn) : gate(gt), ticket(turn), owner(std::move(own)) {
+  const uint8_t *file_base;  // the file's first byte (file offsets decide where flate2's reads begin)
+  GzSource(const uint8_t *p, const uint8_t *e, std::shared_ptr<void> own, PgzGate *gt, uint64_t turn) : gate(gt), ticket(turn), owner(std::move(own)), file_base(p) {
     window = 16u << 20;
     gz.open(p, e);
+  }
+  // ---- what the reference has SEEN of a stream when its decoder reports damage --------------------------------------
+  // flate2's zio::read (GzDecoder over its own 32 KiB BufReader, under std's 8 KiB BufReader, io.rs:606-617) returns
+  // `Err("corrupt deflate stream")` for the whole call in which the decoder met the damage: what that call had already
+  // written into the caller's 8 KiB buffer is lost with it.  A call begins where the one before it ended — when the
+  // 8 KiB were full, when the 32 KiB of compressed input ran out, or at a member's end — so of the `n_ok` bytes in
+  // front of the damage the reference's line reader gets
+  //     seen = o + 8192 · ⌊(n_ok − o) / 8192⌋,   o = the output in front of the last such input (or member) boundary.
+  // HOLD_BACK: no window is handed on while fewer than this many decoded bytes lie behind its end, so that the cut
+  // never has to take back anything (the reader parses, and hands out, what the windows hold).
+  static constexpr size_t HOLD_BACK = 8192;
+  // bytes a decoder gets out of [from, to) alone (a stream cut short at `to`: everything whose bits lie in front of it)
+  static uint64_t output_of_prefix(const uint8_t *from, const uint8_t *to) {
+    Inflater inf;
+    inf.seek(from, to, 0);
+    std::vector<uint8_t> buf((1u << 20) + 32768 + Inflater::OUT_SLACK);
+    uint64_t total = 0;
+    size_t pos = 0;
+    for (;;) {
+      const size_t before = pos;
+      const InflateStatus st = inf.run(buf.data(), &pos, buf.size());
+      total += pos - before;
+      if (st != INF_OUTPUT_FULL) return total;
+      const size_t keep = std::min<size_t>(pos, 32768);
+      memmove(buf.data(), buf.data() + pos - keep, keep);
+      pos = keep;
+    }
+  }
+  // n_ok: the stream's bytes in front of the damage; member_out0: the stream's bytes in front of the damaged member;
+  // deflate0: where that member's DEFLATE data begins; fail: the input byte the decoder stood at
+  uint64_t reference_has_seen(uint64_t n_ok, uint64_t member_out0, const uint8_t *deflate0, const uint8_t *fail) const {
+    const uint64_t fail_off = (uint64_t)(fail - file_base), b_off = fail_off & ~(uint64_t)32767;
+    uint64_t o = member_out0;
+    if (b_off > (uint64_t)(deflate0 - file_base)) o += output_of_prefix(deflate0, file_base + b_off);
+    if (o > n_ok) o = n_ok;  // (cannot be: the prefix decodes like the whole)
+    return o + (n_ok - o) / 8192 * 8192;
   }
   ~GzSource() override {
     cancel();
@@ -726,6 +763,7 @@ struct GzSource final : Source {
     uint64_t verified = 0;        // bit position everything in front of which has been decoded and checked
     InflateStatus status = INF_OUTPUT_FULL;
     const uint8_t *after = nullptr;
+    uint64_t emitted_out = 0;  // bytes of the pieces that have left out_q
     bool cancelled = false;
     size_t n_spec_used = 0, n_here = 0;  // chunks taken from the workers / stretches decoded by this thread
     uint64_t bytes_spec = 0, bytes_here = 0;
@@ -891,10 +929,25 @@ struct GzSource final : Source {
       }
       out_q.emplace_back(std::move(pc));
     };
+    // (a piece goes out only while HOLD_BACK decoded bytes lie behind it: see reference_has_seen)
     auto drain = [&](size_t keep_n) {
-      while (out_q.size() > keep_n && !cancelled) emit_front(false);
+      while (out_q.size() > keep_n && !cancelled) {
+        size_t behind = 0;
+        for (size_t i = 1; i < out_q.size() && behind < HOLD_BACK; ++i) behind += out_q[i].n;
+        if (behind < HOLD_BACK) break;
+        emitted_out += out_q.front().n;
+        emit_front(false);
+      }
     };
 
+    // A chunk whose speculation is passed over gives its symbol buffer back at once (12 MB or more each, touched by
+    // the worker): a member where the finder keeps missing — stored or fixed blocks, false block starts — would
+    // otherwise hold one per chunk until its end, memory growing with the file.
+    auto drop_symbols = [](SpecResult &x) {
+      UBuf<uint16_t> none;
+      std::swap(x.sym, none);
+      x.n = 0;
+    };
     // chunk 0, then chunk after chunk
     decode_here((uint64_t)chunk_bytes * 8);
     size_t next = 1;
@@ -942,16 +995,21 @@ struct GzSource final : Source {
           continue;
         }
         decode_here((uint64_t)(next + 1) * chunk_bytes * 8);  // (the ordinary decoder says what is wrong with it)
+        drop_symbols(r);
         ++next;
         continue;
       }
       if (r.found && r.start_bit > verified) {  // something the finder does not look for lies in between
         decode_here(r.start_bit);
-        if (verified != r.start_bit) ++next;  // (it was no block boundary after all: that chunk's result is void)
+        if (verified != r.start_bit) {  // (it was no block boundary after all: that chunk's result is void)
+          drop_symbols(r);
+          ++next;
+        }
         continue;
       }
       // no entry point found in this chunk, or one in front of where the stream really stands: the ordinary way
       if ((uint64_t)(next + 1) * chunk_bytes * 8 > verified) decode_here((uint64_t)(next + 1) * chunk_bytes * 8);
+      drop_symbols(r);
       ++next;
     }
     if (!cancelled) {
@@ -961,8 +1019,25 @@ struct GzSource final : Source {
         pc.buf->v.resize(64);
         out_q.emplace_back(std::move(pc));
       }
-      while (out_q.size() > 1) emit_front(false);
       final_status = status == INF_OUTPUT_FULL ? INF_TRUNCATED : status;
+      if (final_status == INF_CORRUPT) {  // the reference's reader has not seen all of what lies in front of the damage
+        uint64_t n_ok = emitted_out;
+        for (const Piece &pc : out_q) n_ok += pc.n;
+        uint64_t cut = n_ok - reference_has_seen(n_ok, 0, origin, origin + (verified >> 3));
+        while (cut && !out_q.empty()) {  // (off the tail: resolved pieces first — their bytes are being written by workers)
+          Piece &pc = out_q.back();
+          const size_t t = (size_t)std::min<uint64_t>(cut, pc.n);
+          pc.n -= t;
+          cut -= t;
+          if (pc.n == 0 && out_q.size() > 1) {
+            while (pc.pending && pc.pending->load(std::memory_order_acquire) > 0) std::this_thread::yield();
+            out_q.pop_back();
+          } else if (pc.n == 0) {
+            break;
+          }
+        }
+      }
+      while (out_q.size() > 1) emit_front(false);
       if (final_status == INF_STREAM_END && after) {  // where the trailer lies (GzMember::finish)
         gz.inf.in = after;
         gz.inf.bitcnt = 0;
@@ -1016,6 +1091,8 @@ struct GzSource final : Source {
     auto b = std::make_shared<Buf>();
     b->v.resize(cap);
     size_t pos = 0, line0 = 0;  // decoded so far in this buffer; start of the bytes not handed out yet
+    uint64_t gone = 0;          // bytes of the stream that have left the buffer's front
+    const uint8_t *const deflate0 = gz.inf.in;
     for (;;) {
       {
         std::lock_guard<std::mutex> lk(m);
@@ -1024,10 +1101,16 @@ struct GzSource final : Source {
       const InflateStatus st = gz.inf.run(b->v.data(), &pos, b->v.size());
       if (st != INF_OUTPUT_FULL) {
         final_status = st;
-        emit(Window{b, (const char *)b->v.data() + line0, pos - line0, true});
+        size_t end = pos;
+        if (st == INF_CORRUPT) {  // the reference's reader has not seen all of what lies in front of the damage
+          const uint64_t seen = reference_has_seen(gone + pos, 0, deflate0, gz.inf.in - (gz.inf.bitcnt >> 3));
+          end = (size_t)(seen - gone);  // (≥ line0: the last HOLD_BACK bytes were never handed on)
+        }
+        emit(Window{b, (const char *)b->v.data() + line0, end - line0, true});
         break;
       }
-      const void *nl = memrchr(b->v.data() + line0, '\n', pos - line0);
+      const size_t held = std::min(pos - line0, HOLD_BACK);
+      const void *nl = memrchr(b->v.data() + line0, '\n', pos - held - line0);
       if (!nl) {  // a line longer than the window: a bigger buffer, everything moves along
         auto nb = std::make_shared<Buf>();
         nb->v.resize(b->v.size() * 2);
@@ -1042,6 +1125,7 @@ struct GzSource final : Source {
       memcpy(nb->v.data(), b->v.data() + pos - keep, keep);
       emit(Window{b, (const char *)b->v.data() + line0, cut - line0, false});
       line0 = keep - (pos - cut);
+      gone += pos - keep;
       pos = keep;
       b = std::move(nb);
     }
@@ -1057,11 +1141,14 @@ struct GzSource final : Source {
     size_t pos = 0, line0 = 0, crc_from = 0;  // decoded so far in this buffer; first byte not handed out; first byte not in the CRC yet
     uint32_t crc = 0;
     uint64_t member_out = 0;
+    uint64_t gone = 0;                        // bytes of the stream that have left the buffer's front
+    const uint8_t *deflate0 = gz.inf.in;      // where the member being decoded begins
     for (;;) {
       {
         std::lock_guard<std::mutex> lk(m);
         if (stop) break;
       }
+      gz.inf.history_bytes = member_out;  // (a member's matches reach back into that member only)
       const InflateStatus st = gz.inf.run(b->v.data(), &pos, b->v.size());
       crc = crc32_update(crc, b->v.data() + crc_from, pos - crc_from);
       member_out += pos - crc_from;
@@ -1075,6 +1162,7 @@ struct GzSource final : Source {
           members_err = gz.header_error;
           crc = 0;
           member_out = 0;
+          deflate0 = gz.inf.in;
           if (members_err.kind == IO_NONE) continue;
         }
         emit(Window{b, (const char *)b->v.data() + line0, pos - line0, true});
@@ -1082,10 +1170,16 @@ struct GzSource final : Source {
       }
       if (st != INF_OUTPUT_FULL) {  // a short or corrupt body
         members_err = gz.finish(st, crc, member_out);
-        emit(Window{b, (const char *)b->v.data() + line0, pos - line0, true});
+        size_t end = pos;
+        if (st == INF_CORRUPT) {  // (see reference_has_seen: a member's end is where a read ends, too)
+          const uint64_t seen = reference_has_seen(gone + pos, gone + pos - member_out, deflate0, gz.inf.in - (gz.inf.bitcnt >> 3));
+          end = (size_t)(seen - gone);
+        }
+        emit(Window{b, (const char *)b->v.data() + line0, end - line0, true});
         break;
       }
-      const void *nl = memrchr(b->v.data() + line0, '\n', pos - line0);
+      const size_t held = std::min(pos - line0, HOLD_BACK);
+      const void *nl = memrchr(b->v.data() + line0, '\n', pos - held - line0);
       if (!nl) {  // a line longer than the window: a bigger buffer, everything moves along
         auto nb = std::make_shared<Buf>();
         nb->v.resize(b->v.size() * 2);
@@ -1100,6 +1194,7 @@ struct GzSource final : Source {
       memcpy(nb->v.data(), b->v.data() + pos - keep, keep);
       emit(Window{b, (const char *)b->v.data() + line0, cut - line0, false});
       line0 = keep - (pos - cut);
+      gone += pos - keep;
       pos = keep;
       crc_from = keep;
       b = std::move(nb);

@@ -3,6 +3,7 @@
 // them for longer codes), up to three literals per refill, wide overshooting match copies.  RFC 1951 is the
 // specification followed; which malformed streams are refused follows miniz_oxide's rules where RFC 1951 leaves a
 // choice (a code set that is neither complete nor a single code is refused), since that is the reference's decoder.
+#include <algorithm>
 #include "shk_inflate.h"
 
 #include <immintrin.h>
@@ -267,6 +268,9 @@ InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) 
   uint8_t *out = out_base + *out_pos;
   uint8_t *const out_end = out_base + out_cap;
   uint8_t *const out_start = out;
+  // how far back a match may reach: never beyond the buffer's start — and never beyond the START OF THE STREAM where
+  // the caller decodes several streams into one buffer (all-members mode: a member starts with empty history)
+  uint8_t *const hist_first = out_start - (size_t)std::min<uint64_t>(history_bytes, (uint64_t)*out_pos);
   const uint8_t *ip = in;
   uint64_t bb = bitbuf;
   uint32_t bc = bitcnt;
@@ -385,7 +389,7 @@ InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) 
           const size_t distance = (d >> 16) + ((uint32_t)bb & ((1u << deb) - 1));
           bb >>= deb;
           bc -= (uint8_t)d + deb;
-          if (distance > (size_t)(out - out_base)) SHK_DONE(INF_CORRUPT);
+          if (distance > (size_t)(out - hist_first)) SHK_DONE(INF_CORRUPT);
           const uint8_t *src = out - distance;
           uint8_t *const end = out + length;
           if (distance >= 16) {
@@ -456,7 +460,7 @@ InflateStatus Inflater::run(uint8_t *out_base, size_t *out_pos, size_t out_cap) 
       const uint32_t deb = (d >> 8) & 15;
       const size_t distance = (d >> 16) + ((uint32_t)b2 & ((1u << deb) - 1));
       if (!drop(deb)) SHK_DONE(INF_TRUNCATED);
-      if (distance > (size_t)(out - out_base)) SHK_DONE(INF_CORRUPT);
+      if (distance > (size_t)(out - hist_first)) SHK_DONE(INF_CORRUPT);
       bb = b2;
       bc = c2;
       const uint8_t *src = out - distance;

@@ -65,6 +65,10 @@ struct Inflater {
   InflateStatus run_symbols(uint16_t *out, size_t *out_pos, size_t out_cap, const uint8_t *origin, uint64_t stop_bit, bool *between_blocks);
   // Decodes into out_base[out_pos, out_cap); bytes [out_pos - min(out_pos, 32768), out_pos) are the history.
   InflateStatus run(uint8_t *out_base, size_t *out_pos, size_t out_cap);
+  // How many of the bytes in front of out_pos belong to THIS stream (the default: all of them).  A caller that decodes
+  // one stream after another into the same buffer sets it before every run(): a match must not reach back into the
+  // stream before (flate2's MultiGzDecoder starts every member with empty history: "corrupt deflate stream").
+  uint64_t history_bytes = ~0ull;
   // After INF_STREAM_END: the first input byte behind the stream (whole unread bytes are given back).
   const uint8_t *input_after_stream() const { return in - (bitcnt >> 3); }
 };

@@ -149,6 +149,25 @@ def test_all_members_on_request(orc, tmp_path):
     assert res[0] == "error" and "Local read stream ended unexpectedly" in res[1], res
 
 
+def test_a_member_has_no_history_but_its_own(orc, tmp_path):
+    """All-members mode decodes member after member into one buffer.  A later member whose FIRST symbol is a match
+    (fixed-Huffman block: length 3, distance 1, end of block) reaches back in front of its own first byte:
+    flate2's MultiGzDecoder starts every member with empty history and reports "corrupt deflate stream" — and so must
+    the reader, instead of copying the previous member's last byte and leaving it to the CRC."""
+    bits = [1, 1, 0] + [0, 0, 0, 0, 0, 0, 1] + [0, 0, 0, 0, 0] + [0] * 7     # BFINAL, BTYPE = 01; code 257; distance code 0; code 256
+    raw = bytearray((len(bits) + 7) // 8)
+    for i, b in enumerate(bits):
+        raw[i >> 3] |= b << (i & 7)
+    a = text_of(records(1200, 1))
+    ghost = a[-1:] * 3                                                        # what a decoder without the check would produce
+    member2 = (b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff" + bytes(raw) +
+               zlib.crc32(ghost).to_bytes(4, "little") + len(ghost).to_bytes(4, "little"))
+    q = write(tmp_path, "reach_back.fastq.gz", gz_bytes(a) + member2)
+    res = both(orc, [q], all_members=True)
+    assert res[0] == "error" and "corrupt deflate stream" in res[1] and "kind InvalidInput" in res[1], res
+    assert both(orc, [q])[2][0] == 1200                                       # (the default never looks at a second member)
+
+
 def test_member_followed_by_garbage_and_members_across_files(orc, tmp_path):
     a = text_of(records(1200, 1))
     b = text_of(records(900, 2))

@@ -85,7 +85,7 @@ def draw_reads(rng):
 def test_random_configuration_against_the_oracle(orc, monkeypatch, seed):
     rng = np.random.default_rng(10_000 + seed)
     k = int(rng.choice([1, 2, 5, 9, 11, 13, 15, 16, 17, 19, 21, 21, 21, 22, 23, 25, 27, 29, 31, 31]))
-    chunks = int(rng.choice([0, 1, 1, 2, 3, 7, 10, 16, 17]))
+    chunks = int(rng.choice([0, 1, 1, 2, 3, 7, 10, 16, 17, 40, 100, 129]))   # (up to 128 lanes: the paged passes; beyond: the atomics)
     histo_max = int(rng.choice([1, 5, 50, 300]))
     flags = int(rng.choice([0, 0, 0, sa.FLAG_FORCE_DIRECT, sa.FLAG_FORCE_PAGED, sa.FLAG_DEFER_ERRORS, sa.FLAG_TIMING]))
     hint = int(rng.choice([0, 0, 20_000, 400_000, 1_100_000, 4_200_000]))

@@ -664,11 +664,19 @@ def test_two_level_partition_large_table():
 
 # ---- parameter extremes ------------------------------------------------------------------------------
 
-def test_many_chunks_take_the_direct_path(orc):
-    """More chunk lanes than the paged path handles (16): the atomics path with per-tile lanes."""
+@pytest.mark.parametrize("chunks,paged_max,hint,flags", [(40, 0, 0, 0), (40, 16, 0, 0), (100, 0, 0, 0), (100, 0, 600_000, "paged"), (128, 0, 600_000, "paged"),
+                                                         (130, 0, 0, 0), (64, 0, 9_000_000, 0)])
+def test_many_chunk_lanes(orc, monkeypatch, chunks, paged_max, hint, flags):
+    """Chunk counts well beyond the usual ten — the reference takes any (its own historical runs: n = 100,
+    sharkmer_viewer/tests/data/Cordagalma.stats:1).  Up to 128 lanes the paged passes take them (round 4: the limit was
+    16, and 40 lanes ran through the global atomics at a sixth of the rate); beyond that — or with the limit pinned back
+    to 16 — the atomics path with per-tile lanes; a large table puts 64 lanes through the two-level route."""
+    if paged_max:
+        monkeypatch.setenv("SHK_PAGED_MAX_LANES", str(paged_max))
     spec = sa.SynthSpec(genome_len=20_000, sub_per_64k=328, n_per_64k=66)
-    bases, offsets = sa.synth_reads(spec, 0, 45_500)
-    check_against_oracle(orc, bases, offsets, 21, 40, 300, check_table=False)
+    bases, offsets = sa.synth_reads(spec, 0, 45_500 if chunks <= 40 else 135_500)
+    check_against_oracle(orc, bases, offsets, 21, chunks, 300, check_table=chunks == 100 and not flags,
+                         flags=sa.FLAG_FORCE_PAGED if flags == "paged" else 0, hint=hint)
 
 
 @pytest.mark.parametrize("histo_max", [1, 1_000_000])
