@@ -419,7 +419,7 @@ def owner_run(args, config, mode, dist_ready):
     n_owners = JOB_GPUS if drop_mode else world
     flags = sa.FLAG_TIMING
     eng = sa.KmerEngine(k, lanes, histo_max, device=dev, capacity_hint=genome // n_owners, flags=flags,
-                        n_owners=n_owners, owner_id=0 if drop_mode else rank)
+                        n_owners=n_owners, owner_id=0 if drop_mode else rank, reserve_cus=args.reserve_cus)
     spec = sa.SynthSpec(genome_len=genome, read_len=L)
     # the rank's reads, resident in HBM: rounds of ≤ 2^28 bases
     round_reads = 1_700_000
@@ -500,8 +500,18 @@ def owner_run(args, config, mode, dist_ready):
         if dom:
             d = per_kernel[dom]
             lps = d["launches_per_step"]
+            # HBM bytes per launch from the PMC passes of this round's build over the same command on one card
+            # (tools/profile_owner.sh → profiles/rNN_config{4,5}_traffic.json); only for the mode it was taken in
+            import glob
+            traffic, tsrc = None, None
+            for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_config{config}_traffic.json")), reverse=True):
+                tj = json.load(open(tpath))
+                if world == 1 and not drop_mode and not args.reads:
+                    traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+                    tsrc = os.path.relpath(tpath, ROOT)
+                break
             roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(d["achieved_GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(d["achieved_GBps"] / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc if traffic else None,
                     "alg_bytes_per_launch": int(d["alg_bytes_per_step"] / lps), "avg_launch_ms": round(d["ms_per_step"] / lps, 4)}
         b_alg = n_bases + n_kmers_rank * 16 * own_frac + cnt["n_unique_kmers"] / (1 if drop_mode else world) * 8 + cap * (8 + 4 * lanes)
         path_roof = {"alg_bytes_per_step_per_rank": int(b_alg), "achieved_GBps": round(b_alg / (dt / steps) / 1e9, 1),
@@ -539,7 +549,8 @@ def owner_run(args, config, mode, dist_ready):
             "config": {"workload": f"BASELINE.json {which}: one rank's share per GPU — {rpr} synthetic {L}bp reads of a {genome} bp genome, k={k}, "
                                    f"{lanes} chunk lane(s), {world}xMI355X; {how}; step = reset + all rounds + histogram emit, input resident in HBM",
                        "reads_per_gpu": rpr, "k": k, "chunks": lanes, "genome": genome, "n_owners": n_owners,
-                       "mode": "drop" if drop_mode else "exchange", "round_reads": round_reads},
+                       "mode": "drop" if drop_mode else "exchange", "round_reads": round_reads,
+                       "reserve_cus": args.reserve_cus if args.reserve_cus else ("library default: 16 for n_owners > 1 (SHK_RESERVE_CUS)" if n_owners > 1 else 0)},
             "roofline": roof, "cpu_baseline": cpu, "roofline_path": path_roof, "kernels": per_kernel,
             "kernels_ms_per_step": {k_: round(v[0] / steps, 3) for k_, v in tim.items() if v[0] > 0},
             "exchange": exchange,
@@ -632,6 +643,8 @@ def main():
                     help="2: BASELINE configs[1] (the metric's configuration); 4 / 5: configs[3] / configs[4], a rank's share per GPU")
     ap.add_argument("--mode", choices=["auto", "exchange", "drop"], default="auto",
                     help="--config 4 / 5: exchange rounds over RCCL (auto) or one owner's share with the others' records dropped")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="--config 4 / 5: compute units the counting leaves to the collectives (shk_config.reserve_cus; 0 = the library's default)")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: 1 M for --config 2, 125 M for 4 / 5)")
     ap.add_argument("--batches", type=int, default=4, help="--config 2: distinct resident batches the steps rotate over")
     ap.add_argument("--k", type=int, default=21)

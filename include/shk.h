@@ -52,6 +52,7 @@ extern "C" {
 #define SHK_FLAG_TIMING_SAMPLED 16u /* with SHK_FLAG_TIMING: only the launches of every 4th job are bracketed (a job =
                                     * what lies between two shk_reset calls; the first after shk_reset_timings is) — the
                                     * event records themselves cost ≈3 % of a 0.6 ms job */
+#define SHK_RESERVE_NONE 0xFFFFFFFFu /* shk_config.reserve_cus: every compute unit, whatever SHK_RESERVE_CUS says */
 #define SHK_FLAG_DEFER_ERRORS 8u  /* host-buffer ingests (shk_ingest_reads/_batch/_packed) return once their last
                                    * slice is queued, like the device-buffer ones: an invalid byte is reported by
                                    * the NEXT call on the context (ingest, sync, finalize), and that call's first
@@ -86,7 +87,15 @@ typedef struct shk_config {
    * to the devices with their global read index (io.rs:340-361), records exchanged by owner between the
    * devices during ingest, one histogram sum at finalize.  `device` is ignored then.  0 or 1: one device. */
   uint32_t n_devices;
-  uint32_t reserved32;
+  /* COMPUTE UNITS LEFT FREE (round 4): the context's PERSISTENT kernel — the 4-byte-record scatter, one 1024-thread
+   * workgroup with 144 of 160 KiB of LDS on every CU for the whole launch — starts this many workgroups fewer (rounded
+   * up to a multiple of 8), so that whoever else works on the card while it counts finds a CU: the collectives of a
+   * multi-GPU job, whose channels are workgroups that need CUs and LDS while a round's segments travel under the next
+   * round's scatter.  (The other kernels are many short workgroups; a collective's get in as those retire.)
+   * 0: the default — none for a whole-key-space context, SHK_RESERVE_CUS (default 16) for an owner share of a
+   * multi-GPU job (n_owners > 1); SHK_RESERVE_NONE (~0): none, whatever the environment says.  What it costs the
+   * counting on one card is in DESIGN.md §6. */
+  uint32_t reserve_cus;
   const int32_t *device_ids;
   uint64_t reserved[1];
 } shk_config;
@@ -385,7 +394,7 @@ int shk_xchg_absorb(shk_ctx *ctx, const void *d_records, const void *d_cursors, 
 int shk_xchg_spill(shk_ctx *ctx, void **d_kmers, void **d_lanes, void **d_counts, uint64_t *n);
 int shk_xchg_spill_clear(shk_ctx *ctx);
 /* The exchange round for k-mers the owner layout cannot take (4-byte records need 2k − layout.log_p1 ≤ 32: k ≤ 21 at
- * the default fan-out; ≤ 16 chunk lanes) — any k, any number of lanes, slower: the batch is validated, its canonical
+ * the default fan-out; ≤ 128 chunk lanes) — any k, any number of lanes, slower: the batch is validated, its canonical
  * k-mers (kmers_from_ascii, encoding.rs:332-371) are extracted as whole 64-bit values and grouped by owner:
  *   *d_kmers u64[Σ counts], owner o's k-mers at [Σ_{o'<o} counts[o'], …) in no particular order;
  *   *d_lanes u32[Σ counts], each k-mer's chunk lane (read i → lane (i / 1000) % n_chunks, io.rs:340-361);

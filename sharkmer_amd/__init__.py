@@ -8,7 +8,7 @@ fallback: importing works anywhere, creating an engine needs a gfx950 GPU.
 """
 from .engine import (  # noqa: F401
     KmerEngine, ShkError, N_READS_PER_BATCH, lib_path, load_library,
-    FLAG_TIMING, FLAG_FORCE_DIRECT, FLAG_FORCE_PAGED, FLAG_DEFER_ERRORS, FLAG_TIMING_SAMPLED, KERNEL_NAMES,
+    FLAG_TIMING, FLAG_FORCE_DIRECT, FLAG_FORCE_PAGED, FLAG_DEFER_ERRORS, FLAG_TIMING_SAMPLED, KERNEL_NAMES, RESERVE_NONE,
     PackedReads, pack_reads, release_cached_memory, FastqReader, write_histo, write_final_histo, write_stats_yaml, validate_args, run_files,
 )
 from .synth import SynthSpec, synth_reads  # noqa: F401

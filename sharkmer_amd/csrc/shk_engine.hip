@@ -238,6 +238,7 @@ struct shk_ctx {
   bool is_share() const { return owner_bits != 0 || share_w1; }
   int64_t xchg_lane_fixed = -1;  // the next shk_xchg_scatter_device sends every read to this chunk lane (multi-device shk_ingest_batch)
   uint32_t n_cus = 256;  // compute units of the device (multiProcessorCount)
+  uint32_t n_cus_scatter = 256;  // … that the persistent scatter takes (n_cus − shk_config.reserve_cus)
   hipStream_t stream = nullptr;
   // table
   TableRef tb{};
@@ -1059,7 +1060,7 @@ static int xl_scatter(shk_ctx *c, const BatchRef &b, const PartGeom &g, const Xl
   own.log_w = g.lw;
   own.keep = keep_all ? 0xFFFFFFFFu : c->owner_id;
   own.seg_recs = keep_all ? (uint32_t)x.seg_recs : 0u;
-  const uint32_t G = std::min<uint32_t>(grid_for(b.tile_count * (TILE_T / SC32_TT), 1, (uint32_t)env_int("SHK_PART_G", 512)), c->n_cus * SHK_SC32_WGS);
+  const uint32_t G = std::min<uint32_t>(grid_for(b.tile_count * (TILE_T / SC32_TT), 1, (uint32_t)env_int("SHK_PART_G", 512)), c->n_cus_scatter * SHK_SC32_WGS);
   const size_t lds = scatter32_lds(g.P1);
   {
     ScopedTimer t(c, SHK_K_SCATTER, /*chain=*/prezeroed && c->chain_from_mark);
@@ -1143,7 +1144,7 @@ static int xchg_check(shk_ctx *c, const PartGeom &g) {
   if (!c->is_share()) return fail(c, SHK_ERR_STATE, "not an owner share (shk_config.n_owners = 0: say 1 for a share that is the whole key space)");
   if (!xl_feasible(c, g) || count_path(c, 0) != PATH_DEFER)
     return fail(c, SHK_ERR_STATE,
-                "the owner exchange needs 4-byte records (2k - %u ≤ 32) and ≤ 16 chunk lanes at this table geometry; "
+                "the owner exchange needs 4-byte records (2k - %u ≤ 32) and ≤ 128 chunk lanes at this table geometry; "
                 "merge the tables at finalize instead", g.log_p1);
   return SHK_OK;
 }
@@ -1341,10 +1342,10 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       if (rec32 && lds32) {
         int rcl;
         if (defer && !two_level)  // straight into the accumulation regions, (lane, page) layout
-          rcl = launch_scatter32(c, acc_wide != 0, std::min<uint32_t>(G, c->n_cus * SHK_SC32_WGS), lds_s32, b, log_p1, 0xFFFFFFFFu,
+          rcl = launch_scatter32(c, acc_wide != 0, std::min<uint32_t>(G, c->n_cus_scatter * SHK_SC32_WGS), lds_s32, b, log_p1, 0xFFFFFFFFu,
                                  (unsigned int *)c->acc_cur.p, c->acc_cap, (uint32_t *)c->acc_buf.p, sp, dbg, NL);
         else
-          rcl = launch_scatter32(c, false, std::min<uint32_t>(G, c->n_cus * SHK_SC32_WGS), lds_s32, b, log_p1,
+          rcl = launch_scatter32(c, false, std::min<uint32_t>(G, c->n_cus_scatter * SHK_SC32_WGS), lds_s32, b, log_p1,
                                  all_lanes ? 0xFFFFFFFFu : lane, cursor1, cap1, (uint32_t *)c->part.p, sp, dbg, NL);
         if (rcl != SHK_OK) return rcl;
       } else if (rec32)
@@ -1770,7 +1771,18 @@ int shk_create(const shk_config *cfg, shk_ctx **out) {
       return bail(e__ == hipErrorOutOfMemory ? SHK_ERR_NOMEM : SHK_ERR_HIP);                 \
     }                                                                                        \
   } while (0)
-  HIPB(stream_take(&c->stream));
+  {
+    // compute units left to others (shk_config.reserve_cus): the PERSISTENT kernel of the context — k_scatter32, one
+    // 1024-thread workgroup with 144 KiB of LDS per CU for the whole launch — starts that many workgroups fewer.  (A CU
+    // mask on the context's stream — hipExtStreamCreateWithCUMask; bit i = CU i / 8 of XCD i % 8, tools/cumask_probe.hip
+    // — was built and measured first: it also holds the many-workgroup kernels off the reserved CUs, and it costs the
+    // config-4 share 17 to 32 % at a world of one — 126 Gbases/s unmasked, 86 / 87 / 105 / 92 with 8 / 16 / 32 / 64 CUs
+    // masked off: the masked queue dispatches slowly, the level-2 pass loses 30 % to 3 % fewer CUs.  Not kept.)
+    uint32_t r = cfg->reserve_cus == SHK_RESERVE_NONE ? 0u : cfg->reserve_cus;
+    if (cfg->reserve_cus == 0 && cfg->n_owners > 1) r = (uint32_t)std::max(0, env_int("SHK_RESERVE_CUS", 16));
+    c->n_cus_scatter = c->n_cus - std::min((r + 7u) & ~7u, c->n_cus > 64 ? c->n_cus - 64 : 0u);
+    HIPB(stream_take(&c->stream));
+  }
   HIPB(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
   const size_t hist_n = (size_t)std::max<uint32_t>(cfg->chunks, 1) * (cfg->histo_max + 2);
   {

@@ -47,6 +47,13 @@ struct shk_group {
   // per-device staging
   std::vector<DevBuf> in_bases, in_offsets, recv_rec, recv_cur, recv_spill;
   std::vector<HostBuf> rebased;
+  // k-mers that do not fit the owner layout's 4-byte records (k > 21 at the default fan-out): the WIDE round — whole
+  // 64-bit k-mers and their chunk lanes grouped by owner (shk_xchg_wide_scatter_device), every device pulls its piece
+  // of every peer's arrays and inserts it (shk_insert_device).  Round 4: such a context used to be refused.
+  bool wide = false;
+  std::vector<void *> wk_ptr, wl_ptr;
+  std::vector<std::vector<uint64_t>> wcounts;  // [sender][owner]
+  std::vector<DevBuf> recv_wk, recv_wl;
   // what the workers publish in a round
   std::vector<void *> rec_ptr, cur_ptr;
   std::vector<shk_xchg_layout> lay;
@@ -158,11 +165,11 @@ int group_create(const shk_config *cfg, shk_ctx **out) {
     c1.owner_id = d;
     c1.table_capacity_hint = cfg->table_capacity_hint ? (cfg->table_capacity_hint + D - 1) / D : 0;
     int rc = shk_create(&c1, &g->ctx[d]);
-    if (rc == SHK_OK) {  // the exchange needs 4-byte records at this geometry: say so now, not at the first batch
+    if (rc == SHK_OK) {  // 4-byte records at this geometry, or the wide round for the whole context (every device alike)
       const PartGeom pg = part_geom(g->ctx[d]);
       if (xchg_check(g->ctx[d], pg) != SHK_OK) {
-        rc = SHK_ERR_BAD_ARG;
-        g_create_error = "a multi-device context needs k ≤ 21 and ≤ 16 chunk lanes (4-byte exchange records): " + g->ctx[d]->err;
+        g->wide = true;
+        g->ctx[d]->err.clear();
       }
     }
     if (rc != SHK_OK) {
@@ -190,6 +197,11 @@ int group_create(const shk_config *cfg, shk_ctx **out) {
   g->recv_cur.resize(D);
   g->recv_spill.resize(D);
   g->rebased.resize(D);
+  g->wk_ptr.assign(D, nullptr);
+  g->wl_ptr.assign(D, nullptr);
+  g->wcounts.assign(D, std::vector<uint64_t>(D, 0));
+  g->recv_wk.resize(D);
+  g->recv_wl.resize(D);
   g->rec_ptr.assign(D, nullptr);
   g->cur_ptr.assign(D, nullptr);
   g->lay.assign(D, shk_xchg_layout{});
@@ -222,6 +234,8 @@ void group_destroy(shk_ctx *top) {
     g->recv_rec[d].release();
     g->recv_cur[d].release();
     g->recv_spill[d].release();
+    g->recv_wk[d].release();
+    g->recv_wl[d].release();
     g->rebased[d].release();
     if (g->ctx[d]) shk_destroy(g->ctx[d]);
   }
@@ -252,6 +266,36 @@ int group_round(shk_ctx *top, const uint8_t *bases, const uint64_t *offsets, con
       if (nb) hipc(hipMemcpyAsync(g->in_bases[d].p, bases + o0, nb, hipMemcpyHostToDevice, c->stream));
       for (uint64_t j = 0; j <= ns; ++j) reb[j] = offsets[r0 + j] - o0;
       hipc(hipMemcpyAsync(g->in_offsets[d].p, reb, (ns + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (g->wide) {  // ---- the wide round: whole k-mers grouped by owner, pulled and inserted by their owners
+      if (g->status[d] == SHK_OK) {
+        if (lane_fixed >= 0) c->xchg_lane_fixed = lane_fixed;
+        else (void)shk_set_read_index(c, first_read + r0);
+        g->status[d] = shk_xchg_wide_scatter_device(c, g->in_bases[d].p, g->in_offsets[d].p, ns, nb, &g->wk_ptr[d], &g->wl_ptr[d],
+                                                    g->wcounts[d].data());
+        c->xchg_lane_fixed = -1;
+      }
+      if (g->barrier()) return g->status[d];
+      for (uint32_t i = 0; i < D && g->status[d] == SHK_OK; ++i) {
+        const uint32_t s = (d + i) % D;  // (my own piece first: no copy)
+        const uint64_t n = g->wcounts[s][d];
+        if (!n) continue;
+        uint64_t off = 0;
+        for (uint32_t o = 0; o < d; ++o) off += g->wcounts[s][o];
+        const char *src_k = (const char *)g->wk_ptr[s] + off * 8, *src_l = (const char *)g->wl_ptr[s] + off * 4;
+        if (s == d) {
+          g->status[d] = shk_insert_device(c, src_k, src_l, nullptr, n);
+        } else {
+          hipc(g->recv_wk[d].ensure(n * 8));
+          hipc(g->recv_wl[d].ensure(n * 4));
+          hipc(hipMemcpyPeerAsync(g->recv_wk[d].p, g->dev_ids[d], src_k, g->dev_ids[s], n * 8, c->stream));
+          hipc(hipMemcpyPeerAsync(g->recv_wl[d].p, g->dev_ids[d], src_l, g->dev_ids[s], n * 4, c->stream));
+          if (g->status[d] == SHK_OK) g->status[d] = shk_insert_device(c, g->recv_wk[d].p, g->recv_wl[d].p, nullptr, n);  // (synchronous)
+        }
+      }
+      hipc(hipStreamSynchronize(c->stream));
+      (void)g->barrier();  // everybody has pulled what it owns: the peers may scatter again
+      return g->status[d];
     }
     if (g->status[d] == SHK_OK) {
       if (lane_fixed >= 0) c->xchg_lane_fixed = lane_fixed;  // drain_batch with an explicit chunk (io.rs:356-358)

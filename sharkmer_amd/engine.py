@@ -23,6 +23,7 @@ FLAG_TIMING = 1
 FLAG_FORCE_DIRECT = 2
 FLAG_FORCE_PAGED = 4
 FLAG_TIMING_SAMPLED = 16  # with FLAG_TIMING: only every 4th job's launches are bracketed (include/shk.h)
+RESERVE_NONE = 0xFFFFFFFF  # shk_config.reserve_cus: every compute unit (include/shk.h)
 FASTQ_GZIP_ALL_MEMBERS = 1  # shk_fastq_open_ex / shk_run_config.fastq_flags (include/shk.h)
 FLAG_DEFER_ERRORS = 8  # host-buffer ingests return once queued; errors surface at the next call (include/shk.h)
 
@@ -48,7 +49,7 @@ class _Config(C.Structure):
     _fields_ = [("k", C.c_uint32), ("chunks", C.c_uint32), ("histo_max", C.c_uint64),
                 ("device", C.c_int32), ("flags", C.c_uint32),
                 ("table_capacity_hint", C.c_uint64), ("n_owners", C.c_uint32), ("owner_id", C.c_uint32),
-                ("n_devices", C.c_uint32), ("reserved32", C.c_uint32), ("device_ids", C.POINTER(C.c_int32)),
+                ("n_devices", C.c_uint32), ("reserve_cus", C.c_uint32), ("device_ids", C.POINTER(C.c_int32)),
                 ("reserved", C.c_uint64 * 1)]
 
 
@@ -288,15 +289,17 @@ class KmerEngine:
 
     def __init__(self, k: int, chunks: int = 0, histo_max: int = 10000, device: int = 0,
                  capacity_hint: int = 0, flags: int = 0, n_owners: int = 0, owner_id: int = 0,
-                 device_ids=None):
+                 device_ids=None, reserve_cus: int = 0):
         """n_owners/owner_id: an OWNER SHARE — the context holds 1/n_owners of the key space
-        (shk_config.n_owners).  device_ids: a multi-device context (shk_config.n_devices)."""
+        (shk_config.n_owners).  device_ids: a multi-device context (shk_config.n_devices).
+        reserve_cus: compute units the context's kernels leave free (shk_config.reserve_cus; 0 = the
+        library's default, RESERVE_NONE = none)."""
         self._L = load_library()
         self.k, self.chunks, self.histo_max = k, chunks, histo_max
         self.n_owners, self.owner_id = max(n_owners, 1), owner_id
         self._tdev = f"cuda:{device}"  # torch tensors over this context's memory live on ITS device, whatever torch's current one is
         cfg = _Config(k=k, chunks=chunks, histo_max=histo_max, device=device, flags=flags,
-                      table_capacity_hint=capacity_hint, n_owners=n_owners, owner_id=owner_id)
+                      table_capacity_hint=capacity_hint, n_owners=n_owners, owner_id=owner_id, reserve_cus=reserve_cus)
         if device_ids is not None:
             ids = (C.c_int32 * len(device_ids))(*device_ids)
             cfg.n_devices = len(device_ids)

@@ -48,8 +48,13 @@ def _check(orc, bases, offsets, k, chunks, histo_max, devs, splits=None, hint=0)
     return c
 
 
-@pytest.mark.parametrize("devs,k,chunks", [([0, 0], 21, 10), ([0, 0, 0, 0], 19, 3), ([0, 0], 15, 0), ([0] * 8, 21, 1)])
+@pytest.mark.parametrize("devs,k,chunks", [([0, 0], 21, 10), ([0, 0, 0, 0], 19, 3), ([0, 0], 15, 0), ([0] * 8, 21, 1),
+                                           ([0, 0], 31, 10), ([0, 0, 0, 0], 27, 3), ([0, 0], 21, 40), ([0, 0, 0, 0], 31, 40), ([0, 0], 23, 0)])
 def test_multi_device_context_matches_oracle(orc, devs, k, chunks):
+    """k > 21 (no 4-byte exchange record holds the rest of the key at the default fan-out): the context takes the WIDE
+    round — whole k-mers grouped by owner, pulled and inserted by their owners — instead of refusing (round 4); 40 chunk
+    lanes: the 4-byte rounds (the paged passes take up to 128 lanes since round 4).  The reference accepts 0 < k < 32 and
+    any number of chunks (cli.rs:659-677)."""
     spec = sa.SynthSpec(genome_len=70_000, sub_per_64k=250, n_per_64k=50)
     bases, offsets = sa.synth_reads(spec, 0, 23_456)
     _check(orc, bases, offsets, k, chunks, 300, devs, splits=[1_700, 9_999, 17_000])
@@ -102,8 +107,9 @@ def test_multi_device_errors_carry_the_reference_messages():
             eng.finalize()
         with pytest.raises(sa.ShkError, match="Invalid character 'x' in sequence. Only ACGTN allowed."):
             eng.ingest_seqs(["ACGTACGTACGTACGTACGTACGTAAAA", "ACGTACGTACGTxACGTACGTACGTACGTACGT"])
-    with pytest.raises(sa.ShkError, match="k ≤ 21"):
-        sa.KmerEngine(31, 1, 100, device_ids=[0, 0])
+    with sa.KmerEngine(31, 1, 100, device_ids=[0, 0]) as eng:   # (refused until round 4: k > 21 takes the wide round now)
+        with pytest.raises(sa.ShkError, match="Invalid character 'x' in sequence. Only ACGTN allowed."):
+            eng.ingest_seqs(["ACGTACGTACGTACGTACGTACGTAAAAACGTACGTACGT", "ACGTACGTACGTxACGTACGTACGTACGTACGTACGTACGTACGT"])
     with pytest.raises(sa.ShkError, match="power of two"):
         sa.KmerEngine(21, 1, 100, device_ids=[0, 0, 0])
 

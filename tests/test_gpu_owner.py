@@ -117,7 +117,7 @@ def test_owner_share_skewed_input_spills_exactly(orc, monkeypatch):
 
 # ---- exchange mode: W contexts on one card as W ranks ------------------------------------------------
 
-def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint):
+def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint, reserve_cus=0):
     """Every rank ingests its own 1000-read batches (round-robin, shard_batches), one batch per round."""
     n_reads = len(offsets) - 1
     ref = orc.run_batch(bases, offsets, k, chunks, histo_max) if orc is not None else None
@@ -128,7 +128,7 @@ def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint):
 
     def run(rank):
         try:
-            eng = sa.KmerEngine(k, chunks, histo_max, capacity_hint=hint, n_owners=W, owner_id=rank)
+            eng = sa.KmerEngine(k, chunks, histo_max, capacity_hint=hint, n_owners=W, owner_id=rank, reserve_cus=reserve_cus)
             oc = OwnerCounter(eng, ThreadGroup(shared, rank), device=0, round_bases=1000 * 160)
             mine = shard_batches(n_reads, rank, W)
             keep = []
@@ -170,6 +170,16 @@ def test_exchange_between_contexts_like_ranks(orc, monkeypatch, W, k, chunks, lv
     spec = sa.SynthSpec(genome_len=80_000, sub_per_64k=250, n_per_64k=50)
     bases, offsets = sa.synth_reads(spec, 0, 20_500)
     _exchange_run(orc, bases, offsets, k, chunks, 300, W, hint=4_200_000 if lvl1 == 10 else 1_000_000)  # (2k - lvl1 ≤ 32: 4-byte records)
+
+
+@pytest.mark.parametrize("reserve", [sa.RESERVE_NONE, 8, 100, 250])
+def test_exchange_with_compute_units_left_to_the_collectives(orc, monkeypatch, reserve):
+    """shk_config.reserve_cus: the persistent scatter of an owner share starts that many workgroups fewer (the default for
+    a share of a multi-GPU job is 16; at most all but 64 of the card's).  The result does not depend on it."""
+    monkeypatch.setenv("SHK_LEVEL1_LOG", "10")
+    spec = sa.SynthSpec(genome_len=90_000, sub_per_64k=250, n_per_64k=50)
+    bases, offsets = sa.synth_reads(spec, 0, 30_500)
+    _exchange_run(orc, bases, offsets, 21, 3, 300, 2, hint=4_200_000, reserve_cus=reserve)
 
 
 def test_exchange_with_skewed_input_goes_through_the_foreign_spill_list(orc, monkeypatch):
