@@ -2458,6 +2458,228 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
 }
 
 // ------------------------------------------------------------------------------------------
+// k_scatter64: the 8-byte-record scatter (k-mers whose mixed-key remainder does not fit 32 bits: every
+// table at k ≥ 22) with k_scatter32's machine — a persistent 1024-thread workgroup per CU, 16 Ki-position
+// tiles, the thread's group staged in registers, the window walk — and the RECORDS (canonical k-mers, what
+// k_part_rescatter and k_pages read) carried in registers from the walk to the place phase:
+//   walk   : windows of the 48 bases in sight → canonical k-mer (two registers per end position, sixteen
+//            positions per thread) + partition off the top of the mixed key + rank (returning LDS add)
+//   scan, reserve : as k_scatter32 (runs are even: the write-out moves aligned PAIRS)
+//   place  : sorted[tstart[partition] + rank] = k-mer — the 8-byte record itself, not an index
+//   write  : one 16-byte LDS read and one 16-byte store per lane and step; the partition of a pair is
+//            re-read off its first k-mer (one 64-bit multiply per PAIR)
+// k_part_scatter_sorted<.., false>, which it replaces for ≤ 1024 partitions and k ≥ 18, kept 16-bit
+// position entries and rebuilt every k-mer from the packed tile in its write phase (three LDS reads, funnel
+// shifts and the multiply per RECORD: 37 % of that kernel on BASELINE configs[2]).
+// LDS: 8·(TT + P) (the sorted records; aliases the staged pairs) + 8·P; same output, same cursors, same
+// padding (EMPTY behind an odd run) as the kernel it replaces.
+// ------------------------------------------------------------------------------------------
+template <int NT, int TT>
+__global__ void __launch_bounds__(NT, 4) k_scatter64(
+    BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
+    uint32_t cap_p, uint64_t *__restrict__ part_buf, DevStats *__restrict__ stats,
+    unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
+  __shared__ uint32_t wsum[NT / 64];
+  __shared__ uint32_t red[NT / 64];
+  __shared__ uint32_t n_ent_sh;
+  static_assert(TILE_T % TT == 0 && TT % (8 * NT) == 0, "tile shape");
+  constexpr int SPAN = TT / NT;
+  constexpr int GROUPS = (TT + HALO) / 16;
+  static_assert(SPAN == 16 && GROUPS == NT + 2, "a thread walks exactly the group it staged");
+  const uint32_t P = 1u << log_parts;                  // ≤ NT
+  uint2 *pg = reinterpret_cast<uint2 *>(sh);           // the stage's (packed word, masks) per group; dead once the walk has read them
+  uint2 *sorted = reinterpret_cast<uint2 *>(sh);       // TT + P records (every run starts at an EVEN index); aliases pg
+  uint32_t *cnt = sh + 2 * (TT + P);                   // P
+  uint32_t *tstart = cnt + P;                          // P  (tstart[0..7] double as the walk's spare counters: written after it)
+  uint32_t *gbase = cnt;                               // P: (this tile's reservation) − tstart, in records — takes cnt's place
+#ifdef SHK_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#endif
+  uint32_t n_non_n = 0;
+  const int k = b.k;                                   // 18 ≤ k ≤ 31 (the host's choice)
+  const uint32_t LS = 64u - 2u * (uint32_t)k;          // left shift of a frame: 2 … 28
+  const uint32_t of0 = 2u * (33u - (uint32_t)k);       // bit offset of the first end position's window in w0:w1:w2 (4 … 30)
+  const uint32_t lo_keep = 0xFFFFFFFFu << LS;          // the k-mer's bits of a left-aligned frame's low word
+  const uint64_t M = 2u * (uint32_t)k <= MIX_NARROW_BITS ? MIX_M32 : MIX_M64;
+  const uint32_t M_lo = (uint32_t)M, M_hi = (uint32_t)(M >> 32);
+  const uint32_t psh = 32u - log_parts;                // log_parts ≥ 1
+
+  uint64_t t = blockIdx.x, t0, t1;
+  uint32_t lane;
+  bool have = next_tile(b, t, true, lane_filter, t0, t1, lane);
+  uint32_t sub = 0;
+  StageRegs32<NT, TT> pre;
+  if (have) stage32_prefetch<NT, TT>(b, t0, pre);
+  while (have) {
+    const uint64_t s0 = t0 + (uint64_t)sub * TT;
+    const uint64_t s1 = s0 + TT < t1 ? s0 + TT : t1;
+    __syncthreads();  // previous sub-tile's write phase is done with sorted/cnt/tstart/gbase
+#ifdef SHK_PHASE_TIMING
+    tprev = __builtin_readcyclecounter();
+#endif
+    for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
+    uint32_t my_pw, my_gm;
+    {
+      uint32_t nn = 0;
+      my_pw = stage32_group_regs(b, s0, s1, (int)threadIdx.x + 2, pre.raw[0], pre.sb0[0], pre.sb1[0], stats, &my_gm, &nn);
+      pg[threadIdx.x + 2] = make_uint2(my_pw, my_gm);
+      if (threadIdx.x < 2) {
+        uint32_t gm1;
+        const uint32_t pw1 = stage32_group_regs(b, s0, s1, (int)threadIdx.x, pre.raw[1], pre.sb0[1], pre.sb1[1], stats, &gm1, &nn);
+        pg[threadIdx.x] = make_uint2(pw1, gm1);
+      }
+      n_non_n += nn;
+    }
+    uint64_t nt = t, n0 = t0, n1 = t1;
+    uint32_t nl = lane, nsub = sub + 1;
+    bool hn = true;
+    if (t0 + (uint64_t)nsub * TT >= t1) {
+      nsub = 0;
+      nt = t + gridDim.x;
+      hn = next_tile(b, nt, true, lane_filter, n0, n1, nl);
+    }
+    if (hn) stage32_prefetch<NT, TT>(b, n0 + (uint64_t)nsub * TT, pre);  // in flight during the rest of this one
+    __syncthreads();
+    STAMP(0);
+    // ---- walk ---------------------------------------------------------------------------------
+    uint32_t pr[SPAN], km_lo[SPAN], km_hi[SPAN];
+    {
+      const int n_end = (int)(s1 - s0);
+      const uint2 gA = pg[threadIdx.x], gB = pg[threadIdx.x + 1];
+      const uint32_t okw = stage32_okbits(gA.y, gB.y, my_gm, k, n_end + HALO - ((int)threadIdx.x + 2) * 16);
+      const uint32_t spare_pc = P + (threadIdx.x & 7u);
+      // the 48 bases in sight (the two groups before mine and mine, first base on top), shifted up so that
+      // the window of end position e starts 2e bits in — a compile-time funnel shift for ANY k — and the
+      // three words of their reverse complement, where that window starts 2·(15 − e) bits in
+      const uint32_t w0 = gA.x, w1 = gB.x, w2 = my_pw;
+      const uint32_t v0 = __builtin_amdgcn_alignbit(w0, w1, 32u - of0), v1 = __builtin_amdgcn_alignbit(w1, w2, 32u - of0), v2 = w2 << of0;
+      const uint32_t rw0 = rev2(~w2), rw1 = rev2(~w1), rw2 = rev2(~w0);
+#pragma unroll
+      for (int q = 0; q < SPAN / 8; ++q) {
+        uint32_t pcs[8], rks[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int e = q * 8 + r;
+          const int orv = 2 * (15 - e);
+          const uint32_t f_hi = e ? __builtin_amdgcn_alignbit(v0, v1, (32 - 2 * e) & 31) : v0;
+          const uint32_t f_lo = e ? __builtin_amdgcn_alignbit(v1, v2, (32 - 2 * e) & 31) : v1;
+          const uint32_t r_hi = orv ? __builtin_amdgcn_alignbit(rw0, rw1, (32 - orv) & 31) : rw0;
+          const uint32_t r_lo = orv ? __builtin_amdgcn_alignbit(rw1, rw2, (32 - orv) & 31) : rw1;
+          // min(fwd, rev) on the frames as they are (see k_scatter32): the borrow of rev − fwd selects
+          uint32_t c_hi, c_lo, scratch;
+          asm("v_sub_co_u32 %2, vcc, %5, %3\n\t"
+              "v_subb_co_u32 %2, vcc, %6, %4, vcc\n\t"
+              "v_cndmask_b32 %0, %3, %5, vcc\n\t"
+              "v_cndmask_b32 %1, %4, %6, vcc"
+              : "=&v"(c_lo), "=&v"(c_hi), "=&v"(scratch)
+              : "v"(f_lo), "v"(f_hi), "v"(r_lo), "v"(r_hi)
+              : "vcc");
+          km_lo[e] = __builtin_amdgcn_alignbit(c_hi, c_lo, LS);  // the k-mer, right-aligned (LS < 32)
+          km_hi[e] = c_hi >> LS;
+          // top word of (left-aligned key · M) mod 2^64 = the top of the mixed key
+          const uint32_t cl = c_lo & lo_keep;
+          const uint32_t yhi = __umulhi(cl, M_lo) + cl * M_hi + c_hi * M_lo;
+          const uint32_t page = yhi >> psh;
+          uint32_t em;
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(em) : "v"(okw), "n"(q * 8 + r));  // all ones where a k-mer ends here
+          asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(pcs[r]) : "v"(em), "v"(page), "v"(spare_pc));
+          rks[r] = atomicAdd(&cnt[pcs[r]], 1u);  // rank < 2^14
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pr[q * 8 + r] = (pcs[r] << 18) | rks[r];
+      }
+    }
+    __syncthreads();
+    STAMP(2);
+    // ---- exclusive scan of the even-padded counts → tstart ---------------------------------------
+    {
+      const bool mine = threadIdx.x < P;
+      const uint32_t c1 = mine ? cnt[threadIdx.x] : 0u;
+      const uint32_t sacc = (c1 + 1u) & ~1u;
+      const uint32_t inc = wave_scan_incl(sacc);
+      if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+      __syncthreads();
+      const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+      const uint32_t part = (ln < wv && ln < (uint32_t)(NT / 64)) ? wsum[ln] : 0u;
+      const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(part), 63);
+      if (mine) tstart[threadIdx.x] = woff + inc - sacc;
+    }
+    // reserve this sub-tile's (even-padded) run in every partition's region
+    uint32_t gres = 0, my_c1 = 0;
+    if (threadIdx.x < P) {
+      my_c1 = cnt[threadIdx.x];
+      if (my_c1) gres = atomicAdd(&cursor[threadIdx.x], (my_c1 + 1u) & ~1u);
+    }
+    __syncthreads();  // the staged pairs are dead from here: `sorted` may overwrite them; tstart is complete
+    STAMP(3);
+    // ---- place: the records themselves ---------------------------------------------------------
+    {
+      const char *const ts_b = reinterpret_cast<const char *>(tstart);
+      uint2 *__restrict__ const dst = sorted;
+#pragma unroll
+      for (int i = 0; i < SPAN; ++i) {
+        const uint32_t v = pr[i];  // partition · 2^18 | rank; partitions ≥ P are the spare counters (no record)
+        if (v < (P << 18)) dst[*reinterpret_cast<const uint32_t *>(ts_b + (v >> 16)) + (v & 0x3FFFFu)] = make_uint2(km_lo[i], km_hi[i]);
+      }
+      if (threadIdx.x < P) {
+        const uint32_t ts = tstart[threadIdx.x];
+        gbase[threadIdx.x] = gres - ts;  // (overwrites cnt[i]: nobody else looks at it any more)
+        if (my_c1 & 1u) dst[ts + my_c1] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // EMPTY behind an odd run
+        if (threadIdx.x == P - 1) n_ent_sh = ts + ((my_c1 + 1u) & ~1u);
+      }
+    }
+    __syncthreads();
+    STAMP(4);
+    // ---- write: one aligned PAIR of records per lane and step, both of one partition -----------------
+    {
+      const uint32_t n_ent = n_ent_sh;  // records, padding included (even)
+      const ulonglong2 *sorted2 = reinterpret_cast<const ulonglong2 *>(sorted);
+      char *const base = reinterpret_cast<char *>(part_buf);
+#pragma unroll 2
+      for (uint32_t i = threadIdx.x; 2 * i < n_ent; i += NT) {
+        const ulonglong2 rec = sorted2[i];
+        const uint32_t pc = (uint32_t)(((rec.x * M) << LS) >> 32) >> psh;
+        const uint32_t at = gbase[pc] + 2 * i;  // record index inside partition pc's region
+        if (at + 2 <= cap_p) {
+          const uint32_t byte_off = (pc * cap_p + at) * 8u;  // < 2^32 (the host sizes a launch's regions so)
+          *reinterpret_cast<ulonglong2 *>(base + byte_off) = rec;
+        } else {  // the region is full (skewed input): these records take the spill path
+          const unsigned long long j = atomicAdd(&stats->spill_count, rec.y == EMPTY ? 1ull : 2ull);
+          if (j < sp.cap) {
+            sp.keys[j] = rec.x;
+            sp.lanes[j] = lane;
+            sp.counts[j] = 1u;
+          }
+          if (rec.y != EMPTY && j + 1 < sp.cap) {
+            sp.keys[j + 1] = rec.y;
+            sp.lanes[j + 1] = lane;
+            sp.counts[j + 1] = 1u;
+          }
+        }
+      }
+    }
+    STAMP(5);
+    t = nt;
+    t0 = n0;
+    t1 = n1;
+    lane = nl;
+    sub = nsub;
+    have = hn;
+  }
+  __syncthreads();
+  {
+    uint32_t tot = wg_sum<NT>(n_non_n, red);
+    if (threadIdx.x == 0 && tot) atomicAdd(&lane_bases[lane_filter], (unsigned long long)tot);
+  }
+#ifdef SHK_PHASE_TIMING
+  if (dbg && threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i) dbg[(uint64_t)blockIdx.x * 8 + i] = ph[i];
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
 // k_part_rescatter: second level of the partition for tables with more pages than one LDS sort
 // can fan out to (> MAX_PARTS).  Level 1 (k_part_scatter_sorted with log_parts < log_pages) has
 // grouped the records by SUPER-PAGE (2^log_sub consecutive pages); this kernel takes one

@@ -270,7 +270,7 @@ struct shk_ctx {
   hipEvent_t copy_done[NST] = {};
   int stage_last = -1;            // the staging set the last slice of the previous host-buffer ingest took (its count may still be in flight)
   bool zero_count_keys = false;   // some key may have been inserted with count 0 (shk_insert_counts, merges): k_histo reads the keys
-  bool lds_attr_scatter = false, lds_attr_rescatter = false, lds_attr_scatter_own = false;  // hipFuncSetAttribute done for this context's device
+  bool lds_attr_scatter = false, lds_attr_rescatter = false, lds_attr_scatter_own = false, lds_attr_scatter64 = false;  // hipFuncSetAttribute done for this context's device
   HostBuf h_rebased[NST];           // pinned staging of a slice's re-based offsets (a pageable source would make the copy synchronous)
   DevBuf in_bases, in_offsets, st_bases[NST], st_offsets[NST], startbits, tiles, spillA, spillB, misc, part, part2, part3, part_meta;
   DevBuf pk_stage[NST], nm_stage[NST], nz_dev[NST], pk_ascii;
@@ -1001,6 +1001,23 @@ static int launch_scatter32(shk_ctx *c, bool wide, uint32_t G, size_t lds, const
   return SHK_OK;
 }
 
+// k_scatter64: the 8-byte-record scatter with k_scatter32's shape (records carried in registers, sorted in LDS)
+static size_t scatter64_lds(uint32_t P1) { return (size_t)(SC32_TT + P1) * 8 + (size_t)P1 * 8 + 32; }
+static bool use_scatter64(const shk_ctx *c, const PartGeom &g) {
+  return !use_rec32(c, g) && g.log_p1 >= 3 && g.P1 <= (uint32_t)SC32_NT && c->cfg.k >= 18 && SC32_NT == 1024 && scatter64_lds(g.P1) <= SC32_LDS_MAX &&
+         env_int("SHK_SCATTER64", 1) != 0;
+}
+static int launch_scatter64(shk_ctx *c, uint32_t G, const BatchRef &b, uint32_t log_p1, uint32_t lane, unsigned int *cursor, uint32_t cap,
+                            uint64_t *buf, SpillRef sp, unsigned long long *dbg) {
+  if (!c->lds_attr_scatter64) {
+    HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter64<1024, 16384>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
+    c->lds_attr_scatter64 = true;
+  }
+  hipLaunchKernelGGL((k_scatter64<1024, 16384>), dim3(G), dim3(1024), scatter64_lds(1u << log_p1), c->stream, b, log_p1, lane, cursor, cap, buf,
+                     c->d_stats, c->d_lane_bases, sp, dbg);
+  return SHK_OK;
+}
+
 // ---- the owner layout -------------------------------------------------------------------------------
 struct XlPlan {
   uint32_t log_p1w, n_grp, cap1, n_seg;  // super-page bits of a share; regions per segment; records per region; segments
@@ -1351,7 +1368,12 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       } else if (rec32)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, true>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, cursor1, cap1, c->part.p, c->d_stats, c->d_lane_bases, sp, dbg);
-      else if (defer && !two_level)  // straight into this lane's accumulation regions (8-byte records)
+      else if (use_scatter64(c, pg)) {  // 8-byte records, k_scatter32's machine (deferred one-level: straight into this lane's accumulation regions)
+        const bool acc1 = defer && !two_level;
+        int rcl = launch_scatter64(c, std::min<uint32_t>(G, c->n_cus_scatter), b, log_p1, lane, acc1 ? (unsigned int *)c->acc_cur.p + (size_t)lane * n_pages : cursor1,
+                                   acc1 ? c->acc_cap : cap1, acc1 ? (uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap : (uint64_t *)c->part.p, sp, dbg);
+        if (rcl != SHK_OK) return rcl;
+      } else if (defer && !two_level)  // straight into this lane's accumulation regions (8-byte records)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, false>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
                            b, log_p1, lane, (unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
                            (void *)((uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap), c->d_stats,
