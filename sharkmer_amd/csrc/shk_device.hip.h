@@ -2471,10 +2471,16 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
 // k_part_scatter_sorted<.., false>, which it replaces for ≤ 1024 partitions and k ≥ 18, kept 16-bit
 // position entries and rebuilt every k-mer from the packed tile in its write phase (three LDS reads, funnel
 // shifts and the multiply per RECORD: 37 % of that kernel on BASELINE configs[2]).
-// LDS: 8·(TT + P) (the sorted records; aliases the staged pairs) + 8·P; same output, same cursors, same
-// padding (EMPTY behind an odd run) as the kernel it replaces.
+// LDS: 8·(TT + P) (the sorted records) + 12·P + 8·(NT + 2) (the staged pairs, a buffer of their own: the next
+// tile is staged while this one's records wait to be written); same output, same cursors, same padding (EMPTY
+// behind an odd run) as the kernel it replaces.
 // ------------------------------------------------------------------------------------------
-template <int NT, int TT>
+// IL: the output regions BLOCK-INTERLEAVED in blocks of RS_TILE records (record j of region r at
+// ((j / RS_TILE) · P + r) · RS_TILE + j mod RS_TILE) — the level-1 buffer k_part_rescatter reads tile by tile: the P
+// write fronts stay within P · 32 KiB of one another instead of one per region-sized stride (a dozen address
+// translations per store instruction otherwise).  !IL: region r at r · cap_p (page regions k_pages reads).
+constexpr int S64_IL_LOG = 12;  // = log2(RS_TILE), asserted below
+template <int NT, int TT, bool IL>
 __global__ void __launch_bounds__(NT, 4) k_scatter64(
     BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
     uint32_t cap_p, uint64_t *__restrict__ part_buf, DevStats *__restrict__ stats,
@@ -2488,11 +2494,11 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
   constexpr int GROUPS = (TT + HALO) / 16;
   static_assert(SPAN == 16 && GROUPS == NT + 2, "a thread walks exactly the group it staged");
   const uint32_t P = 1u << log_parts;                  // ≤ NT
-  uint2 *pg = reinterpret_cast<uint2 *>(sh);           // the stage's (packed word, masks) per group; dead once the walk has read them
-  uint2 *sorted = reinterpret_cast<uint2 *>(sh);       // TT + P records (every run starts at an EVEN index); aliases pg
+  uint2 *sorted = reinterpret_cast<uint2 *>(sh);       // TT + P records (every run starts at an EVEN index)
   uint32_t *cnt = sh + 2 * (TT + P);                   // P
-  uint32_t *tstart = cnt + P;                          // P  (tstart[0..7] double as the walk's spare counters: written after it)
-  uint32_t *gbase = cnt;                               // P: (this tile's reservation) − tstart, in records — takes cnt's place
+  uint32_t *tstart = cnt + P;                          // P  (tstart[0..7] double as the walk's spare counters: rewritten by every scan)
+  uint32_t *gbase = tstart + P;                        // P: (this tile's reservation) − tstart, in records
+  uint2 *pg = reinterpret_cast<uint2 *>(gbase + P);    // GROUPS staged (packed word, masks) pairs — of the NEXT tile while this one is written out
 #ifdef SHK_PHASE_TIMING
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = 0;
@@ -2506,43 +2512,64 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
   const uint32_t M_lo = (uint32_t)M, M_hi = (uint32_t)(M >> 32);
   const uint32_t psh = 32u - log_parts;                // log_parts ≥ 1
 
-  uint64_t t = blockIdx.x, t0, t1;
-  uint32_t lane;
-  bool have = next_tile(b, t, true, lane_filter, t0, t1, lane);
-  uint32_t sub = 0;
+  // The tiles of this workgroup, one after another; a tile's sub-tiles of TT end positions.  Three in flight: the one
+  // being walked (c_*), the one staged next (n_*: its bytes are in `pre`), the one after it (asked for when n is staged).
+  uint64_t c_t = blockIdx.x, c_t0 = 0, c_t1 = 0, n_t = 0, n_t0 = 0, n_t1 = 0;
+  uint32_t c_lane = 0, c_sub = 0, n_lane = 0, n_sub = 0;
+  bool c_have = next_tile(b, c_t, true, lane_filter, c_t0, c_t1, c_lane), n_have = false;
+#define SHK_S64_BOUNDS(t0_, t1_, sub_, s0_, s1_) \
+  const uint64_t s0_ = (t0_) + (uint64_t)(sub_) * TT; \
+  const uint64_t s1_ = s0_ + TT < (t1_) ? s0_ + TT : (t1_)
+  // (XX_*) ← the sub-tile after (YY_*)
+#define SHK_S64_ADVANCE(XX, YY)                                                        \
+  do {                                                                               \
+    XX##_t = YY##_t, XX##_t0 = YY##_t0, XX##_t1 = YY##_t1, XX##_lane = YY##_lane;            \
+    XX##_sub = YY##_sub + 1;                                                           \
+    XX##_have = true;                                                                 \
+    if (YY##_t0 + (uint64_t)XX##_sub * TT >= YY##_t1) {                                 \
+      XX##_sub = 0;                                                                   \
+      XX##_t = YY##_t + gridDim.x;                                                     \
+      XX##_have = next_tile(b, XX##_t, true, lane_filter, XX##_t0, XX##_t1, XX##_lane);   \
+    }                                                                                \
+  } while (0)
   StageRegs32<NT, TT> pre;
-  if (have) stage32_prefetch<NT, TT>(b, t0, pre);
-  while (have) {
-    const uint64_t s0 = t0 + (uint64_t)sub * TT;
-    const uint64_t s1 = s0 + TT < t1 ? s0 + TT : t1;
-    __syncthreads();  // previous sub-tile's write phase is done with sorted/cnt/tstart/gbase
+  uint32_t my_pw = 0, my_gm = 0;  // this thread's group of the tile about to be walked: packed bases, N | read-start masks
+  // stage: the prefetched bytes of a sub-tile → this thread's registers + one LDS pair for the neighbours
+  auto stage = [&](uint64_t s0, uint64_t s1) {
+    uint32_t nn = 0;
+    my_pw = stage32_group_regs(b, s0, s1, (int)threadIdx.x + 2, pre.raw[0], pre.sb0[0], pre.sb1[0], stats, &my_gm, &nn);
+    pg[threadIdx.x + 2] = make_uint2(my_pw, my_gm);
+    if (threadIdx.x < 2) {
+      uint32_t gm1;
+      const uint32_t pw1 = stage32_group_regs(b, s0, s1, (int)threadIdx.x, pre.raw[1], pre.sb0[1], pre.sb1[1], stats, &gm1, &nn);
+      pg[threadIdx.x] = make_uint2(pw1, gm1);
+    }
+    n_non_n += nn;
+  };
+
+  if (threadIdx.x < P) cnt[threadIdx.x] = 0;
+  if (c_have) {
+    SHK_S64_BOUNDS(c_t0, c_t1, c_sub, s0, s1);
+    stage32_prefetch<NT, TT>(b, s0, pre);
+    stage(s0, s1);
+    SHK_S64_ADVANCE(n, c);
+    if (n_have) {
+      SHK_S64_BOUNDS(n_t0, n_t1, n_sub, ns0, ns1);
+      (void)ns1;
+      stage32_prefetch<NT, TT>(b, ns0, pre);
+    }
+  }
+  // Order of a tile's phases: walk, scan + reserve, place, THE NEXT TILE'S STAGE, write.  The stores of the write
+  // phase are the last thing a tile issues: they drain under the next tile's walk, and nothing that waits on the
+  // vector-memory counter (the prefetched bytes are consumed before them, the reservations' returns a walk later)
+  // stands behind them.
+  while (c_have) {
+    SHK_S64_BOUNDS(c_t0, c_t1, c_sub, s0, s1);
+    const uint32_t lane = c_lane;
+    __syncthreads();  // the staged pairs and the cleared counts are there; the previous write phase is done with sorted / gbase
 #ifdef SHK_PHASE_TIMING
     tprev = __builtin_readcyclecounter();
 #endif
-    for (uint32_t i = threadIdx.x; i < P; i += NT) cnt[i] = 0;
-    uint32_t my_pw, my_gm;
-    {
-      uint32_t nn = 0;
-      my_pw = stage32_group_regs(b, s0, s1, (int)threadIdx.x + 2, pre.raw[0], pre.sb0[0], pre.sb1[0], stats, &my_gm, &nn);
-      pg[threadIdx.x + 2] = make_uint2(my_pw, my_gm);
-      if (threadIdx.x < 2) {
-        uint32_t gm1;
-        const uint32_t pw1 = stage32_group_regs(b, s0, s1, (int)threadIdx.x, pre.raw[1], pre.sb0[1], pre.sb1[1], stats, &gm1, &nn);
-        pg[threadIdx.x] = make_uint2(pw1, gm1);
-      }
-      n_non_n += nn;
-    }
-    uint64_t nt = t, n0 = t0, n1 = t1;
-    uint32_t nl = lane, nsub = sub + 1;
-    bool hn = true;
-    if (t0 + (uint64_t)nsub * TT >= t1) {
-      nsub = 0;
-      nt = t + gridDim.x;
-      hn = next_tile(b, nt, true, lane_filter, n0, n1, nl);
-    }
-    if (hn) stage32_prefetch<NT, TT>(b, n0 + (uint64_t)nsub * TT, pre);  // in flight during the rest of this one
-    __syncthreads();
-    STAMP(0);
     // ---- walk ---------------------------------------------------------------------------------
     uint32_t pr[SPAN], km_lo[SPAN], km_hi[SPAN];
     {
@@ -2594,10 +2621,13 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
     __syncthreads();
     STAMP(2);
     // ---- exclusive scan of the even-padded counts → tstart ---------------------------------------
+    uint32_t gres = 0, my_c1 = 0;
     {
       const bool mine = threadIdx.x < P;
-      const uint32_t c1 = mine ? cnt[threadIdx.x] : 0u;
-      const uint32_t sacc = (c1 + 1u) & ~1u;
+      my_c1 = mine ? cnt[threadIdx.x] : 0u;
+      const uint32_t sacc = (my_c1 + 1u) & ~1u;
+      // reserve this sub-tile's (even-padded) run in the partition's region: the return is looked at in the place phase
+      if (my_c1) gres = atomicAdd(&cursor[threadIdx.x], sacc);
       const uint32_t inc = wave_scan_incl(sacc);
       if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
       __syncthreads();
@@ -2606,13 +2636,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
       const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(part), 63);
       if (mine) tstart[threadIdx.x] = woff + inc - sacc;
     }
-    // reserve this sub-tile's (even-padded) run in every partition's region
-    uint32_t gres = 0, my_c1 = 0;
-    if (threadIdx.x < P) {
-      my_c1 = cnt[threadIdx.x];
-      if (my_c1) gres = atomicAdd(&cursor[threadIdx.x], (my_c1 + 1u) & ~1u);
-    }
-    __syncthreads();  // the staged pairs are dead from here: `sorted` may overwrite them; tstart is complete
+    __syncthreads();  // tstart is complete; nobody looks at the counts any more
     STAMP(3);
     // ---- place: the records themselves ---------------------------------------------------------
     {
@@ -2625,49 +2649,89 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
       }
       if (threadIdx.x < P) {
         const uint32_t ts = tstart[threadIdx.x];
-        gbase[threadIdx.x] = gres - ts;  // (overwrites cnt[i]: nobody else looks at it any more)
+        gbase[threadIdx.x] = gres - ts;
         if (my_c1 & 1u) dst[ts + my_c1] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // EMPTY behind an odd run
         if (threadIdx.x == P - 1) n_ent_sh = ts + ((my_c1 + 1u) & ~1u);
+        cnt[threadIdx.x] = 0;  // for the next tile's walk
       }
     }
-    __syncthreads();
     STAMP(4);
-    // ---- write: one aligned PAIR of records per lane and step, both of one partition -----------------
+    // ---- the next tile's stage (its bytes were asked for a tile ago), and the one after it asked for ----
+    uint64_t a_t = 0, a_t0 = 0, a_t1 = 0;
+    uint32_t a_lane = 0, a_sub = 0;
+    bool a_have = false;
+#ifdef SHK_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)");  // (phase build only: what the stage would wait for, booked apart)
+    STAMP(6);
+#endif
+    if (n_have) {
+      SHK_S64_BOUNDS(n_t0, n_t1, n_sub, ns0, ns1);
+      stage(ns0, ns1);
+      SHK_S64_ADVANCE(a, n);
+    }
+    STAMP(1);
+    __syncthreads();  // the sorted records are complete
+    STAMP(0);
+    // ---- write: one aligned PAIR of records per lane and step, both of one partition; four steps' LDS reads
+    // (the pair, then its partition's base) are in flight together — one step at a time the loop is a chain of two
+    // LDS round trips per store ------------------------------------------------------------------------------
     {
-      const uint32_t n_ent = n_ent_sh;  // records, padding included (even)
+      const uint32_t n_pairs = n_ent_sh >> 1;  // (records, padding included: even)
       const ulonglong2 *sorted2 = reinterpret_cast<const ulonglong2 *>(sorted);
       char *const base = reinterpret_cast<char *>(part_buf);
-#pragma unroll 2
-      for (uint32_t i = threadIdx.x; 2 * i < n_ent; i += NT) {
-        const ulonglong2 rec = sorted2[i];
-        const uint32_t pc = (uint32_t)(((rec.x * M) << LS) >> 32) >> psh;
-        const uint32_t at = gbase[pc] + 2 * i;  // record index inside partition pc's region
-        if (at + 2 <= cap_p) {
-          const uint32_t byte_off = (pc * cap_p + at) * 8u;  // < 2^32 (the host sizes a launch's regions so)
-          *reinterpret_cast<ulonglong2 *>(base + byte_off) = rec;
-        } else {  // the region is full (skewed input): these records take the spill path
-          const unsigned long long j = atomicAdd(&stats->spill_count, rec.y == EMPTY ? 1ull : 2ull);
-          if (j < sp.cap) {
-            sp.keys[j] = rec.x;
-            sp.lanes[j] = lane;
-            sp.counts[j] = 1u;
-          }
-          if (rec.y != EMPTY && j + 1 < sp.cap) {
-            sp.keys[j + 1] = rec.y;
-            sp.lanes[j + 1] = lane;
-            sp.counts[j + 1] = 1u;
+#ifndef SHK_S64_WB
+#define SHK_S64_WB 1
+#endif
+      constexpr int WB = SHK_S64_WB;
+      for (uint32_t i0 = threadIdx.x; i0 < n_pairs; i0 += WB * NT) {
+        ulonglong2 rec[WB];
+        uint32_t pc[WB], at[WB];
+#pragma unroll
+        for (int j = 0; j < WB; ++j) {
+          const uint32_t i = i0 + j * NT;
+          rec[j] = sorted2[i < n_pairs ? i : n_pairs - 1u];
+        }
+#pragma unroll
+        for (int j = 0; j < WB; ++j) pc[j] = (uint32_t)(((rec[j].x * M) << LS) >> 32) >> psh;
+#pragma unroll
+        for (int j = 0; j < WB; ++j) at[j] = gbase[pc[j]] + 2 * (i0 + j * NT);  // record index inside partition pc's region
+#pragma unroll
+        for (int j = 0; j < WB; ++j) {
+          if (i0 + j * NT >= n_pairs) continue;
+          if (at[j] + 2 <= cap_p) {
+            const uint32_t rec_off = IL ? ((((at[j] >> S64_IL_LOG) << log_parts) + pc[j]) << S64_IL_LOG) | (at[j] & ((1u << S64_IL_LOG) - 1u))
+                                        : pc[j] * cap_p + at[j];
+            const uint32_t byte_off = rec_off * 8u;  // < 2^32 (the host sizes a launch's regions so)
+            *reinterpret_cast<ulonglong2 *>(base + byte_off) = rec[j];
+          } else {  // the region is full (skewed input): these records take the spill path
+            const unsigned long long jj = atomicAdd(&stats->spill_count, rec[j].y == EMPTY ? 1ull : 2ull);
+            if (jj < sp.cap) {
+              sp.keys[jj] = rec[j].x;
+              sp.lanes[jj] = lane;
+              sp.counts[jj] = 1u;
+            }
+            if (rec[j].y != EMPTY && jj + 1 < sp.cap) {
+              sp.keys[jj + 1] = rec[j].y;
+              sp.lanes[jj + 1] = lane;
+              sp.counts[jj + 1] = 1u;
+            }
           }
         }
       }
     }
+    // the bytes of the tile after the next one: asked for BEHIND this tile's stores (in front of them the loads' misses
+    // hold up the stores of every wave of the CU in the L1's queue: write phase 2.4× as long), consumed a tile later
+    if (a_have) {
+      SHK_S64_BOUNDS(a_t0, a_t1, a_sub, as0, as1);
+      (void)as1;
+      stage32_prefetch<NT, TT>(b, as0, pre);
+    }
     STAMP(5);
-    t = nt;
-    t0 = n0;
-    t1 = n1;
-    lane = nl;
-    sub = nsub;
-    have = hn;
+    c_t = n_t, c_t0 = n_t0, c_t1 = n_t1, c_lane = n_lane, c_sub = n_sub, c_have = n_have;
+    n_t = a_t, n_t0 = a_t0, n_t1 = a_t1, n_lane = a_lane, n_sub = a_sub, n_have = a_have;
   }
+#undef SHK_S64_BOUNDS
+#undef SHK_S64_ADVANCE
   __syncthreads();
   {
     uint32_t tot = wg_sum<NT>(n_non_n, red);
@@ -2701,9 +2765,10 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
     uint32_t tiles_per_region, uint32_t log_pages, uint32_t log_sub, uint32_t key_bits,
     unsigned int *__restrict__ dst_cursor,
     uint32_t dst_cap, uint64_t *__restrict__ dst_buf, uint32_t lane, DevStats *__restrict__ stats,
-    SpillRef sp) {
+    SpillRef sp, uint32_t src_interleaved) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[RS_NT / 64];
+  static_assert(RS_TILE == 1 << S64_IL_LOG, "k_scatter64's interleave block is this kernel's tile");
   if (stats->bad != ~0ull) return;
   const uint32_t S = 1u << log_sub;  // pages per super-page
   // (the tiles of one source region go to ONE XCD: see k_part_rescatter32)
@@ -2714,7 +2779,9 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
   const uint32_t r0 = tile * RS_TILE;
   if (r0 >= filled) return;
   const uint32_t n = filled - r0 < (uint32_t)RS_TILE ? filled - r0 : (uint32_t)RS_TILE;  // even
-  const uint64_t *src = src_buf + (uint64_t)region * src_cap + r0;
+  // (src_interleaved: k_scatter64<.., true>'s layout — tile t of region r is block t · n_regions + r)
+  const uint64_t *src = src_interleaved ? src_buf + (((uint64_t)tile * (gridDim.x / tiles_per_region) + region) << S64_IL_LOG)
+                                        : src_buf + (uint64_t)region * src_cap + r0;
   uint64_t *recs = reinterpret_cast<uint64_t *>(sh);                       // RS_TILE records
   uint16_t *sorted = reinterpret_cast<uint16_t *>(sh + 2 * RS_TILE);       // RS_TILE + S entries
   uint32_t *cnt = sh + 2 * RS_TILE + (((uint32_t)RS_TILE + S) * 2 + 15) / 16 * 4;  // S

@@ -1001,20 +1001,34 @@ static int launch_scatter32(shk_ctx *c, bool wide, uint32_t G, size_t lds, const
   return SHK_OK;
 }
 
-// k_scatter64: the 8-byte-record scatter with k_scatter32's shape (records carried in registers, sorted in LDS)
-static size_t scatter64_lds(uint32_t P1) { return (size_t)(SC32_TT + P1) * 8 + (size_t)P1 * 8 + 32; }
+// k_scatter64: the 8-byte-record scatter with k_scatter32's shape (records carried in registers, sorted in LDS).
+// (Two 512-thread workgroups per CU on 8 Ki-position tiles and 512 partitions — the shape that lets two workgroups'
+// phases overlap without doubling the reservations per k-mer — measured 12.2 ms against 11.4-11.6 per 24 M reads of
+// config 3, the level-2 pass 3 % slower on top: not kept.)
+static size_t scatter64_lds(uint32_t P1) { return (size_t)(SC32_TT + P1) * 8 + (size_t)P1 * 12 + (size_t)(SC32_NT + 2) * 8 + 32; }
 static bool use_scatter64(const shk_ctx *c, const PartGeom &g) {
   return !use_rec32(c, g) && g.log_p1 >= 3 && g.P1 <= (uint32_t)SC32_NT && c->cfg.k >= 18 && SC32_NT == 1024 && scatter64_lds(g.P1) <= SC32_LDS_MAX &&
          env_int("SHK_SCATTER64", 1) != 0;
 }
+template <bool IL>
+static hipError_t scatter64_variant(shk_ctx *c, bool set_attr, uint32_t G, size_t lds, const BatchRef &b, uint32_t log_p1, uint32_t lane,
+                                    unsigned int *cursor, uint32_t cap, uint64_t *buf, SpillRef sp, unsigned long long *dbg) {
+  if (set_attr)
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter64<1024, 16384, IL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX);
+  hipLaunchKernelGGL((k_scatter64<1024, 16384, IL>), dim3(G), dim3(1024), lds, c->stream, b, log_p1, lane, cursor, cap, buf, c->d_stats, c->d_lane_bases, sp, dbg);
+  return hipSuccess;
+}
+// interleaved: the level-1 buffer of a two-level pass (what k_part_rescatter reads tile by tile); otherwise page regions
 static int launch_scatter64(shk_ctx *c, uint32_t G, const BatchRef &b, uint32_t log_p1, uint32_t lane, unsigned int *cursor, uint32_t cap,
-                            uint64_t *buf, SpillRef sp, unsigned long long *dbg) {
+                            uint64_t *buf, SpillRef sp, unsigned long long *dbg, bool interleaved) {
+  const size_t lds = scatter64_lds(1u << log_p1);
   if (!c->lds_attr_scatter64) {
-    HIPC(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter64<1024, 16384>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX));
+    HIPC(c, scatter64_variant<false>(c, true, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg));
+    HIPC(c, scatter64_variant<true>(c, true, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg));
     c->lds_attr_scatter64 = true;
   }
-  hipLaunchKernelGGL((k_scatter64<1024, 16384>), dim3(G), dim3(1024), scatter64_lds(1u << log_p1), c->stream, b, log_p1, lane, cursor, cap, buf,
-                     c->d_stats, c->d_lane_bases, sp, dbg);
+  HIPC(c, interleaved ? scatter64_variant<true>(c, false, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg)
+                      : scatter64_variant<false>(c, false, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg));
   return SHK_OK;
 }
 
@@ -1311,7 +1325,10 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
   }
   // (4-byte-record regions are block-interleaved, rec_slot: whole blocks of 2^RB_LOG records)
   const uint64_t pads = rec32 ? 0 : b.tile_count;  // (only 8-B record runs are padded, once per (tile, region) at most)
-  uint32_t cap1 = (region_cap(lane_kmers_ub, P1, pads) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
+  // (the level-1 regions of k_scatter64 are interleaved in blocks of RS_TILE records: whole blocks)
+  const bool il64 = !rec32 && two_level && use_scatter64(c, pg) && env_int("SHK_S64_INTERLEAVE", 1) != 0;
+  const uint32_t cap1_unit = il64 ? (uint32_t)RS_TILE : 1u << RB_LOG;
+  uint32_t cap1 = (region_cap(lane_kmers_ub, P1, pads) + cap1_unit - 1u) & ~(cap1_unit - 1u);
   if (all_lanes && (uint64_t)NL * P1 * cap1 * 4 > 0xFFFFFFFFull) {  // 32-bit byte offsets: fall back to a pass per lane
     all_lanes = false;
     cap1 = (region_cap(sub_kmers_ub, P1, pads) + (1u << RB_LOG) - 1u) & ~((1u << RB_LOG) - 1u);
@@ -1371,7 +1388,8 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       else if (use_scatter64(c, pg)) {  // 8-byte records, k_scatter32's machine (deferred one-level: straight into this lane's accumulation regions)
         const bool acc1 = defer && !two_level;
         int rcl = launch_scatter64(c, std::min<uint32_t>(G, c->n_cus_scatter), b, log_p1, lane, acc1 ? (unsigned int *)c->acc_cur.p + (size_t)lane * n_pages : cursor1,
-                                   acc1 ? c->acc_cap : cap1, acc1 ? (uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap : (uint64_t *)c->part.p, sp, dbg);
+                                   acc1 ? c->acc_cap : cap1, acc1 ? (uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap : (uint64_t *)c->part.p, sp, dbg,
+                                   il64);
         if (rcl != SHK_OK) return rcl;
       } else if (defer && !two_level)  // straight into this lane's accumulation regions (8-byte records)
         hipLaunchKernelGGL((k_part_scatter_sorted<SC_NT, false>), dim3(G), dim3(SC_NT), lds_sorted, c->stream,
@@ -1398,11 +1416,11 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
         hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
                            (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
                            log_sub, 2 * c->cfg.k, (unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
-                           (uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap, lane, c->d_stats, sp);
+                           (uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap, lane, c->d_stats, sp, il64 ? 1u : 0u);
       else
         hipLaunchKernelGGL(k_part_rescatter, dim3(P1 * tiles_per_region), dim3(RS_NT), lds_rs, c->stream,
                            (const uint64_t *)c->part.p, (const unsigned int *)cursor1, cap1, tiles_per_region, lp,
-                           log_sub, 2 * c->cfg.k, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp);
+                           log_sub, 2 * c->cfg.k, cursor_pg, cap_pg, (uint64_t *)buf_pg.p, lane, c->d_stats, sp, il64 ? 1u : 0u);
     }
     if (!defer) {
       const uint32_t l_lo = all_lanes ? 0u : lane, l_hi = all_lanes ? NL : lane + 1;
@@ -1437,7 +1455,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       for (int i = 0; i < 8; ++i) tot += ph[i];
       fprintf(stderr, "[phase cycles/WG] stage %.0f pack %.0f walk %.0f scan %.0f place %.0f write %.0f | share:",
               ph[0] / G, ph[1] / G, ph[2] / G, ph[3] / G, ph[4] / G, ph[5] / G);
-      for (int i = 0; i < 6; ++i) fprintf(stderr, " %.1f%%", 100 * ph[i] / tot);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %.1f%%", 100 * ph[i] / tot);
       fprintf(stderr, "\n");
     }
 #endif
