@@ -1250,6 +1250,18 @@ __global__ void __launch_bounds__(HISTO_WG) k_histo(TableRef tb, uint64_t slot0,
   }
 }
 
+// The control block (launch outcome, totals, lane sums, histogram) straight into the caller's pinned, device-visible
+// copy of it: the first `head8` words whatever they hold, the histogram words only where they are not zero (the host
+// cleared its copy before the launch; nearly all of them are, and stores over the link are slow).  Takes the place of
+// a copy queued behind k_histo — the barrier between a kernel and a blit costs 12-14 µs, a fortieth of a 1 M-read job.
+__global__ void __launch_bounds__(WG) k_ctl_out(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst,
+                                                uint32_t n8, uint32_t head8) {
+  const uint32_t i = blockIdx.x * WG + threadIdx.x;
+  if (i >= n8) return;
+  const unsigned long long v = src[i];
+  if (i < head8 || v) dst[i] = v;
+}
+
 // ==========================================================================================
 // K_LOOKUP / K_EXPORT: merged-table read API (counting.rs:205-241).
 // ==========================================================================================

@@ -2698,7 +2698,14 @@ static int finalize_scan(shk_ctx *c) {
 // The back half: one copy brings back the whole control block (launch outcome, totals, non-N base counts,
 // histogram), and one host sync serves both the last counting launch and the scan.
 static int finalize_fetch(shk_ctx *c) {
-  HIPC(c, hipMemcpyAsync(c->h_ctl, c->d_ctl, c->ctl_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (c->ctl_bytes <= (1u << 20) && env_int("SHK_CTL_OUT_KERNEL", 1) != 0) {  // (a few columns: a kernel's stores over the link; more: the copy engine)
+    memset(c->h_ctl + c->ctl_hist_off, 0, c->ctl_bytes - c->ctl_hist_off);  // (nobody reads the host copy between here and the wait below)
+    const uint32_t n8 = (uint32_t)(c->ctl_bytes / 8);
+    hipLaunchKernelGGL(k_ctl_out, dim3((n8 + WG - 1) / WG), dim3(WG), 0, c->stream, (const unsigned long long *)c->d_ctl, (unsigned long long *)c->h_ctl, n8,
+                       (uint32_t)(c->ctl_hist_off / 8));
+  } else {
+    HIPC(c, hipMemcpyAsync(c->h_ctl, c->d_ctl, c->ctl_bytes, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPC(c, hipEventRecord(c->done_ev, c->stream));  // the host waits for the copy, not for what follows it
   c->hist_dirty = true;  // (cleared by whoever comes next: reset, an ingest, or the next scan)
   {
