@@ -3209,7 +3209,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
       atomicAdd(&dl[slot >> 1], (found & (uint32_t)(kq != EMPTY)) << (16u * (slot & 1u)));
       const bool missed = !found;
       const unsigned long long mm = __ballot(missed);
-      if (missed) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = kq;
+      if (missed) mq[n_miss + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = kq;
       n_miss += (uint32_t)__popcll(mm);
     }
     // drain after each of the first DRAIN_EVERY steps (an empty page misses on every first
@@ -3299,12 +3299,33 @@ static_assert(MQ32 >= 2 * 64 * P32_RPS, "the queue must take a whole step of mis
 // empty, counts start at zero — and written out whole at the end: every lane's counts, and the keys rebuilt from
 // the tags (a tag and the page identify the key), EMPTY where no tag is.  What a reset would have written is
 // written once, with the result in it, and a page in costs nothing.
-template <bool FRESH>
-__global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo, uint32_t lane_hi,
-                                                   uint32_t lane_stride, uint32_t n_regions_,
-                                                   const unsigned int *__restrict__ cursor, uint32_t cap_p,
-                                                   const uint32_t *__restrict__ part_buf,
-                                                   DevStats *__restrict__ stats, SpillRef sp, uint32_t page0 = 0) {
+//
+// HIST (with FRESH): the page's share of EVERY histogram column and of the totals on the way out.  A fresh pass has
+// each slot's counts of every chunk lane in its registers as it writes them — what k_histo would read back a moment
+// later (4 B per slot and lane: a fifth of a ten-lane job on a 30 Mb genome).  Column l is the histogram of the
+// clamped prefix sums over lanes 0..l (k_histo's comment; counting.rs:171-202, histogram.rs:51-85): a thread keeps
+// the running sum of its sixteen slots across the lane loop, bins below FH_BINS go through LDS histograms (every
+// wave's own, then idle, miss queue) into this page's row of `partial` — plain stores, k_hist_reduce sums the rows —
+// and the few beyond straight into `hist`.  The host uses the result only if nothing else touches the table before
+// the histogram is asked for (shk_ctx::fused_valid); otherwise k_histo runs as before.
+constexpr uint32_t FH_BINS = 512;
+struct FusedHist {
+  uint32_t *partial;             // [page][col][FH_BINS]
+  unsigned long long *ptot;      // [page][4]: occupied slots, Σ clamped sums, Σ lane counts, any saturated
+  unsigned long long *hist;      // the context's histogram (bins ≥ FH_BINS)
+  unsigned long long histo_max;
+  uint32_t n_cols;
+  uint32_t pad;
+};
+template <bool FRESH, bool HIST = false>
+__global__ void __launch_bounds__(PG_WG, 4) k_pages32(TableRef tb, uint32_t lane_lo, uint32_t lane_hi,
+                                                      uint32_t lane_stride, uint32_t n_regions_,
+                                                      const unsigned int *__restrict__ cursor, uint32_t cap_p,
+                                                      const uint32_t *__restrict__ part_buf,
+                                                      DevStats *__restrict__ stats, SpillRef sp, uint32_t page0 = 0,
+                                                      FusedHist fh = FusedHist{}) {
+  static_assert(!HIST || FRESH, "the fused histogram is a fresh pass's");
+  static_assert(FH_BINS == MQ32, "a wave bins into its own miss queue");
   __shared__ __attribute__((aligned(16))) uint32_t tags[PAGE_SLOTS];
   __shared__ __attribute__((aligned(16))) uint32_t dl[PAGE_SLOTS];  // this pass's count per slot
   __shared__ __attribute__((aligned(16))) uint32_t mqs[(PG_WG / 64) * MQ32];
@@ -3417,6 +3438,58 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
     n_miss = 0;
     update_may_insert();
   };
+  // HIST: the running (clamped) sums of this thread's sixteen slots over the lanes so far, and its share of the totals
+  constexpr int WBH = PAGE_SLOTS / 4 / PG_WG;
+  uint32_t cum[HIST ? WBH * 4 : 1];
+  unsigned long long fh_lane = 0;
+  if (HIST) {
+#pragma unroll
+    for (int i = 0; i < WBH * 4; ++i) cum[i] = 0;
+  }
+  // one lane's counts d (this thread's quads) folded into the sums; column `lane` of the page → partial.  Called by
+  // every thread of the workgroup, the miss queues idle (between a lane's drain and the next lane's first record).
+  auto fold_hist = [&](const uint4 (&d)[WBH]) {
+    if (!HIST) return;
+    // every wave bins into its OWN miss queue (MQ32 = FH_BINS words, idle since the wave's last drain): nothing to
+    // agree on before, one barrier before the rows are summed, one before the queues are queues again
+    const bool col = lane < fh.n_cols;
+    if (col) {
+      for (uint32_t i = lane_id; i < FH_BINS; i += 64) mq[i] = 0;
+    }
+    const unsigned long long hlen = fh.histo_max + 2;
+    // bin of a sum cc: min(cc, histo_max + 1) — in 32 bits (histo_max ≥ 2^32 - 1: every sum is its own bin)
+    const uint32_t top32 = fh.histo_max >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)fh.histo_max + 1u;
+    uint32_t lsum = 0, lcarry = 0;  // Σ of this lane's sixteen counts
+#pragma unroll
+    for (int u = 0; u < WBH; ++u) {
+      const uint32_t v[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t s1 = lsum + v[q];
+        lcarry += s1 < lsum;
+        lsum = s1;
+        const uint32_t cc = sat_add_u32(cum[u * 4 + q], v[q]);
+        cum[u * 4 + q] = cc;
+        const uint32_t bin = cc < top32 ? cc : top32;
+        if (col && cc) {
+          if (bin < FH_BINS) atomicAdd(&mq[bin], 1u);
+          else atomicAdd(&fh.hist[(unsigned long long)lane * hlen + bin], 1ull);
+        }
+      }
+    }
+    fh_lane += ((unsigned long long)lcarry << 32) | lsum;
+    if (col) {
+      lds_barrier();
+      uint32_t *row = fh.partial + ((size_t)page * fh.n_cols + lane) * FH_BINS;
+      for (uint32_t i = threadIdx.x; i < FH_BINS; i += PG_WG) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < PG_WG / 64; ++w) sum += mqs[w * MQ32 + i];
+        row[i] = sum;
+      }
+      lds_barrier();  // (the next lane's misses go where the bins were)
+    }
+  };
   for (lane = lane_lo; lane < lane_hi; ++lane) {
     {
       const uint32_t filled = cursor[lane * lane_stride + page];
@@ -3428,6 +3501,12 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
 #pragma unroll
         for (int u = 0; u < PAGE_SLOTS / 4 / PG_WG; ++u)
           reinterpret_cast<uint4 *>(gv)[threadIdx.x + u * PG_WG] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (HIST) {  // (the column still counts every slot whose sum so far is not zero)
+        uint4 z[WBH];
+#pragma unroll
+        for (int u = 0; u < WBH; ++u) z[u] = make_uint4(0u, 0u, 0u, 0u);
+        fold_hist(z);
       }
       continue;
     }
@@ -3486,7 +3565,8 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
   #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const unsigned long long mm = __ballot(missed[q]);
-        if (missed[q]) mq[n_miss + __popcll(mm & ((1ull << lane_id) - 1ull))] = rr[q];
+        // (lanes below this one that missed: v_mbcnt_lo/hi take the mask as it is)
+        if (missed[q]) mq[n_miss + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = rr[q];
         n_miss += (uint32_t)__popcll(mm);
       }
       // drain when the next step might not fit (worst case: every record of it misses), and after
@@ -3524,6 +3604,7 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
           if (d[u].x | d[u].y | d[u].z | d[u].w)
             reinterpret_cast<uint4 *>(dl)[threadIdx.x + u * PG_WG] = make_uint4(0u, 0u, 0u, 0u);
         }
+        fold_hist(d);
       }
       if (!FRESH && !prefetch) {
 #pragma unroll
@@ -3570,6 +3651,63 @@ __global__ void __launch_bounds__(PG_WG) k_pages32(TableRef tb, uint32_t lane_lo
   }
   const uint32_t nnew = pg_wg_sum(n_new, dl);
   if (nnew && threadIdx.x == 0) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
+  if (HIST) {  // the page's share of the totals (k_histo's HistoTotals), one row of ptot
+    unsigned long long t4[4] = {0, 0, fh_lane, 0};
+#pragma unroll
+    for (int i = 0; i < WBH * 4; ++i) {
+      t4[0] += cum[i] != 0;
+      t4[1] += cum[i];
+      t4[3] |= cum[i] == 0xFFFFFFFFu;
+    }
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(dl);  // [wave][4]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned long long v = t4[j];
+      for (int off = 32; off > 0; off >>= 1) v = j == 3 ? (v | __shfl_down(v, off, 64)) : v + __shfl_down(v, off, 64);
+      if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 4 + j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      unsigned long long v = 0;
+      for (int w = 0; w < PG_WG / 64; ++w) v = threadIdx.x == 3 ? (v | red[w * 4 + 3]) : v + red[w * 4 + threadIdx.x];
+      fh.ptot[(size_t)page * 4 + threadIdx.x] = v;
+    }
+  }
+}
+
+// The rows of a fused page pass (k_pages32<true, true>) summed into the context's histogram and totals — what k_histo
+// leaves there.  grid.x covers the (column, bin) pairs, grid.y slices the pages.
+__global__ void __launch_bounds__(WG) k_hist_reduce(const uint32_t *__restrict__ partial, const unsigned long long *__restrict__ ptot,
+                                                    uint32_t n_pages, uint32_t n_cols, unsigned long long hlen,
+                                                    unsigned long long *__restrict__ hist, HistoTotals *__restrict__ tot) {
+  const uint32_t per = (n_pages + gridDim.y - 1) / gridDim.y;
+  const uint32_t p0 = blockIdx.y * per, p1 = p0 + per < n_pages ? p0 + per : n_pages;
+  const uint32_t idx = blockIdx.x * WG + threadIdx.x, n_idx = n_cols * FH_BINS;
+  if (idx < n_idx && p0 < p1) {
+    const size_t stride = (size_t)n_idx;
+    unsigned long long s = 0;
+    uint32_t p = p0;
+    for (; p + 8 <= p1; p += 8) {  // eight rows' loads in flight together
+      uint32_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(p + j) * stride + idx];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; p < p1; ++p) s += partial[(size_t)p * stride + idx];
+    const uint32_t col = idx / FH_BINS, bin = idx % FH_BINS;
+    if (s && bin < hlen) atomicAdd(&hist[(unsigned long long)col * hlen + bin], s);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4 && p0 < p1) {
+    unsigned long long v = 0;
+    for (uint32_t p = p0; p < p1; ++p) v = threadIdx.x == 3 ? (v | ptot[(size_t)p * 4 + 3]) : v + ptot[(size_t)p * 4 + threadIdx.x];
+    if (v) {
+      if (threadIdx.x == 0) atomicAdd(&tot->n_unique, v);
+      if (threadIdx.x == 1) atomicAdd(&tot->n_hashed, v);
+      if (threadIdx.x == 2) atomicAdd(&tot->n_lane_sum, v);
+      if (threadIdx.x == 3) atomicOr(&tot->any_saturated, 1ull);
+    }
+  }
 }
 
 }  // namespace shk

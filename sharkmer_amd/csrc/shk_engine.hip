@@ -250,6 +250,12 @@ struct shk_ctx {
   // reduction); the LIVE per-lane base counters the counting kernels add to lie in front of it, so that a repeated
   // _begin / reduce / _end never sums a sum — k_fin_extras copies them into the summed part every time.
   uint8_t *d_ctl = nullptr, *h_ctl = nullptr;
+  // The histogram a FRESH page pass left on its way out (k_pages32<true, true>): rows per page in fh_partial / fh_tot,
+  // good for finalize as long as nothing else has touched the table since (tb_fresh — every writer's and reader's
+  // first call — says so; so do a grow and a reset).
+  DevBuf fh_partial, fh_tot;
+  bool fused_valid = false;
+  uint32_t fused_pages = 0;
   size_t ctl_bytes = 0, ctl_hist_off = 0, ctl_tot_off = 0, ctl_alloc = 0, ctl_alloc_h = 0;
   unsigned long long *d_lane_sum = nullptr, *h_lane_sum = nullptr;
   DevStats *d_stats = nullptr;
@@ -434,7 +440,13 @@ int fill_state(shk_ctx *c, const TableRef &t, bool ctl) {
 }
 
 // The table as everybody but a FRESH page pass needs it: cleared, if the last reset left that for later.
+static void fused_drop(shk_ctx *c) {
+  if (!c->fused_valid) return;
+  c->fused_valid = false;
+  c->hist_dirty = true;  // (the pass may have added high bins to the histogram itself: whoever scans next clears it first)
+}
 int tb_fresh(shk_ctx *c) {
+  fused_drop(c);
   if (!c->tb_stale) return SHK_OK;
   c->tb_stale = false;
   return fill_state(c, c->tb, false);
@@ -482,6 +494,7 @@ int grow_to(shk_ctx *c, uint32_t new_log_pages) {
     if (rcf != SHK_OK) return rcf;
     if (new_log_pages <= c->tb.log_pages) return SHK_OK;
   }
+  fused_drop(c);
   TableRef nt{};
   int rc = alloc_table(c, new_log_pages, &nt);
   if (rc != SHK_OK) return rc;
@@ -1296,6 +1309,22 @@ static int xw_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, X
   return SHK_OK;
 }
 
+// A FRESH page pass over every page and lane may leave the histogram behind (k_pages32<true, true>): room for its rows.
+// (Not for a context that reports a slot range of its table — own_set, the merge-at-finalize counter — or whose
+// histogram was asked to stay with the scan, SHK_FUSED_HIST=0.)
+static bool fused_hist_wanted(const shk_ctx *c) { return !c->own_set && !c->zero_count_keys && env_int("SHK_FUSED_HIST", 1) != 0; }
+static int fused_hist_prepare(shk_ctx *c, uint32_t n_pages, FusedHist *fh) {
+  const uint32_t n_cols = c->cfg.chunks;
+  HIPC(c, c->fh_partial.ensure((size_t)n_pages * std::max<uint32_t>(n_cols, 1) * FH_BINS * 4));
+  HIPC(c, c->fh_tot.ensure((size_t)n_pages * 4 * 8));
+  fh->partial = (uint32_t *)c->fh_partial.p;
+  fh->ptot = (unsigned long long *)c->fh_tot.p;
+  fh->hist = c->d_hist;
+  fh->histo_max = c->cfg.histo_max;
+  fh->n_cols = n_cols;
+  return SHK_OK;
+}
+
 static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed, bool defer) {
   const PartGeom pg = part_geom(c);
   if (xl_route(c, pg, b.tiles != nullptr, defer)) return xl_count(c, b, pg, sub_kmers_ub, sp, prezeroed);
@@ -1429,14 +1458,27 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
         int rcf = tb_fresh(c);
         if (rcf != SHK_OK) return rcf;
       }
+      FusedHist fh{};
+      const bool fuse = rec32 && fresh && fused_hist_wanted(c);
+      if (fuse) {
+        int rch = fused_hist_prepare(c, n_pages, &fh);
+        if (rch != SHK_OK) return rch;
+      }
       ScopedTimer t(c, SHK_K_PAGES, /*chain=*/true);
       if (rec32 && fresh) {
-        hipLaunchKernelGGL(k_pages32<true>, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
-                           all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
-                           (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
+        if (fuse)
+          hipLaunchKernelGGL((k_pages32<true, true>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
+                             all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
+                             (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp, 0u, fh);
+        else
+          hipLaunchKernelGGL((k_pages32<true, false>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
+                             all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
+                             (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp, 0u, fh);
         c->tb_stale = false;
+        c->fused_valid = fuse;
+        c->fused_pages = n_pages;
       } else if (rec32)
-        hipLaunchKernelGGL(k_pages32<false>, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
+        hipLaunchKernelGGL((k_pages32<false, false>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
                            all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
                            (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
       else
@@ -1644,16 +1686,26 @@ static int flush_acc(shk_ctx *c) {
   }
   if (!c->acc_rec32)
     HIPC(c, c->part2.ensure((uint64_t)n_pages * std::min<uint64_t>((uint64_t)c->acc_cap + MISS_SLACK, MISS_PAGE_MAX) * 8));  // (planned with the regions)
+  FusedHist fh{};
+  const bool fuse = fresh && c->acc_rec32 && fused_hist_wanted(c);
+  if (fuse) {
+    int rch = fused_hist_prepare(c, n_pages, &fh);
+    if (rch != SHK_OK) return rch;
+  }
   for (uint64_t p0 = 0; p0 < n_pages; p0 += ppg) {
     const uint32_t gp = (uint32_t)std::min<uint64_t>(ppg, n_pages - p0);
     if (c->acc_rec32) {
       ScopedTimer t(c, SHK_K_PAGES);
-      if (fresh)
-        hipLaunchKernelGGL(k_pages32<true>, dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+      if (fresh && fuse)
+        hipLaunchKernelGGL((k_pages32<true, true>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
                            NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
-                           c->d_stats, sp, (uint32_t)p0);
+                           c->d_stats, sp, (uint32_t)p0, fh);
+      else if (fresh)
+        hipLaunchKernelGGL((k_pages32<true, false>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+                           NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
+                           c->d_stats, sp, (uint32_t)p0, fh);
       else
-        hipLaunchKernelGGL(k_pages32<false>, dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+        hipLaunchKernelGGL((k_pages32<false, false>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
                            NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
                            c->d_stats, sp, (uint32_t)p0);
     } else {  // 8-byte records: one page pass per lane over that lane's regions
@@ -1677,6 +1729,7 @@ static int flush_acc(shk_ctx *c) {
     }
   }
   if (c->acc_rec32) c->tb_stale = false;
+  if (fuse) c->fused_valid = true, c->fused_pages = n_pages;
   HIPC(c, hipMemsetAsync(c->acc_cur.p, 0, (size_t)NL * n_pages * 4, c->stream));
   c->acc_active = false;
   c->acc_records_ub = 0;
@@ -1915,6 +1968,8 @@ void shk_destroy(shk_ctx *c) {
   c->xw_kmers.release();  // (the wide exchange round's output: 12 B per k-mer of the largest batch)
   c->xw_lanes.release();
   c->xw_count.release();
+  c->fh_partial.release();
+  c->fh_tot.release();
   for (int i = 0; i < shk_ctx::NST; ++i) c->pk_stage[i].release(), c->nm_stage[i].release(), c->nz_dev[i].release(), c->nz_host[i].release(), c->hp_pk[i].release(), c->hp_nm[i].release();
   c->pk_ascii.release();
   lap("scratch given back");
@@ -1945,6 +2000,7 @@ int shk_reset(shk_ctx *c) {
     if (rc != SHK_OK) return rc;
     c->tb_stale = !env_int("SHK_NO_FRESH", 0);
     c->hist_dirty = false;
+    c->fused_valid = false;
   }
   c->job_idx++;
   c->timing_now = !(c->cfg.flags & SHK_FLAG_TIMING_SAMPLED) || ((c->job_idx - 1) % 4 == 0);
@@ -2653,12 +2709,29 @@ static int finalize_scan(shk_ctx *c) {
     if (rcs != SHK_OK) return rcs;
     c->finalize_redone = c->n_spilled != before;  // (nothing spilled this time: back to the optimistic order)
   }
-  {
+  // the histogram the (one) fresh page pass left behind, if the table is still as that pass wrote it
+  const bool fused = c->fused_valid && !c->tb_stale && !c->own_set && !c->zero_count_keys && c->fused_pages == (1u << c->tb.log_pages);
+  if (!fused) {
     int rcf = tb_fresh(c);
     if (rcf != SHK_OK) return rcf;
   }
   const uint32_t n_cols = c->cfg.chunks;
   const uint64_t hlen = c->cfg.histo_max + 2;
+  if (fused) {
+    // (d_tot is zero and d_hist holds the pass's bins ≥ FH_BINS only: both were cleared before that pass — by the
+    // reset, or by the k_mark_starts of its ingest — and nobody has written them since, or fused_valid would be off)
+    ScopedTimer t(c, SHK_K_HISTO);
+    const uint32_t n_pages = c->fused_pages;
+    const uint32_t gx = std::max<uint32_t>((n_cols * FH_BINS + WG - 1) / WG, 1), gy = std::min<uint32_t>(std::max<uint32_t>(n_pages / 8, 1), 1024);  // (eight rows per thread up to 8 Ki pages; 1024 slices beyond)
+    hipLaunchKernelGGL(k_hist_reduce, dim3(gx, gy), dim3(WG), 0, c->stream, (const uint32_t *)c->fh_partial.p, (const unsigned long long *)c->fh_tot.p, n_pages,
+                       n_cols, (unsigned long long)hlen, c->d_hist, c->d_tot);
+    c->fused_valid = false;  // (its bins are in the histogram now: a second scan would add them again)
+    c->hist_dirty = false;
+    c->fin_scanned = true;
+    c->fin_was_unsettled = c->unsettled;
+    c->fin_summed = false;
+    return SHK_OK;
+  }
   if (c->hist_dirty) {  // nothing has come between the last read-back and this scan: histogram + totals back to zero now
     FillSegs f{};
     f.ptr[0] = c->d_tot;
