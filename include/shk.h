@@ -138,7 +138,8 @@ enum {
   SHK_K_SYNTH = 10,
   SHK_K_MERGE = 11,
   SHK_K_PCOUNT = 12,   /* validate + count k-mers per partition (k_part_count) */
-  SHK_K_PSCAN = 13     /* the two small exclusive scans between count and scatter */
+  SHK_K_PSCAN = 13,    /* the two small exclusive scans between count and scatter */
+  SHK_K_HISTO_ROWS = 14 /* histograms + totals from the rows the (one) fresh page pass of a job left behind, instead of SHK_K_HISTO's scan */
 };
 
 /* ---- lifecycle ------------------------------------------------------------ */

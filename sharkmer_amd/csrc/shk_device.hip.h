@@ -3442,6 +3442,7 @@ __global__ void __launch_bounds__(PG_WG, 4) k_pages32(TableRef tb, uint32_t lane
   constexpr int WBH = PAGE_SLOTS / 4 / PG_WG;
   uint32_t cum[HIST ? WBH * 4 : 1];
   unsigned long long fh_lane = 0;
+  uint32_t n_high = 0;  // sums this thread sent past the LDS bins (same-line global adds: a job full of them should leave the histogram to k_histo — the host looks)
   if (HIST) {
 #pragma unroll
     for (int i = 0; i < WBH * 4; ++i) cum[i] = 0;
@@ -3473,7 +3474,7 @@ __global__ void __launch_bounds__(PG_WG, 4) k_pages32(TableRef tb, uint32_t lane
         const uint32_t bin = cc < top32 ? cc : top32;
         if (col && cc) {
           if (bin < FH_BINS) atomicAdd(&mq[bin], 1u);
-          else atomicAdd(&fh.hist[(unsigned long long)lane * hlen + bin], 1ull);
+          else atomicAdd(&fh.hist[(unsigned long long)lane * hlen + bin], 1ull), ++n_high;
         }
       }
     }
@@ -3657,19 +3658,20 @@ __global__ void __launch_bounds__(PG_WG, 4) k_pages32(TableRef tb, uint32_t lane
     for (int i = 0; i < WBH * 4; ++i) {
       t4[0] += cum[i] != 0;
       t4[1] += cum[i];
-      t4[3] |= cum[i] == 0xFFFFFFFFu;
+      t4[3] += cum[i] == 0xFFFFFFFFu;
     }
+    t4[3] += (unsigned long long)n_high << 32;  // word 3: low half = saturated sums (a count here, a flag to the host), high half = adds past the LDS bins
     unsigned long long *red = reinterpret_cast<unsigned long long *>(dl);  // [wave][4]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned long long v = t4[j];
-      for (int off = 32; off > 0; off >>= 1) v = j == 3 ? (v | __shfl_down(v, off, 64)) : v + __shfl_down(v, off, 64);
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
       if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 4 + j] = v;
     }
     __syncthreads();
     if (threadIdx.x < 4) {
       unsigned long long v = 0;
-      for (int w = 0; w < PG_WG / 64; ++w) v = threadIdx.x == 3 ? (v | red[w * 4 + 3]) : v + red[w * 4 + threadIdx.x];
+      for (int w = 0; w < PG_WG / 64; ++w) v += red[w * 4 + threadIdx.x];
       fh.ptot[(size_t)page * 4 + threadIdx.x] = v;
     }
   }
@@ -3700,12 +3702,12 @@ __global__ void __launch_bounds__(WG) k_hist_reduce(const uint32_t *__restrict__
   }
   if (blockIdx.x == 0 && threadIdx.x < 4 && p0 < p1) {
     unsigned long long v = 0;
-    for (uint32_t p = p0; p < p1; ++p) v = threadIdx.x == 3 ? (v | ptot[(size_t)p * 4 + 3]) : v + ptot[(size_t)p * 4 + threadIdx.x];
+    for (uint32_t p = p0; p < p1; ++p) v += ptot[(size_t)p * 4 + threadIdx.x];
     if (v) {
       if (threadIdx.x == 0) atomicAdd(&tot->n_unique, v);
       if (threadIdx.x == 1) atomicAdd(&tot->n_hashed, v);
       if (threadIdx.x == 2) atomicAdd(&tot->n_lane_sum, v);
-      if (threadIdx.x == 3) atomicOr(&tot->any_saturated, 1ull);
+      if (threadIdx.x == 3) atomicAdd(&tot->any_saturated, v);  // (low half: saturated sums — non-zero is what counts; high half: adds past the LDS bins)
     }
   }
 }

@@ -254,7 +254,7 @@ struct shk_ctx {
   // good for finalize as long as nothing else has touched the table since (tb_fresh — every writer's and reader's
   // first call — says so; so do a grow and a reset).
   DevBuf fh_partial, fh_tot;
-  bool fused_valid = false;
+  bool fused_valid = false, fused_off = false;
   uint32_t fused_pages = 0;
   size_t ctl_bytes = 0, ctl_hist_off = 0, ctl_tot_off = 0, ctl_alloc = 0, ctl_alloc_h = 0;
   unsigned long long *d_lane_sum = nullptr, *h_lane_sum = nullptr;
@@ -1312,7 +1312,12 @@ static int xw_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, X
 // A FRESH page pass over every page and lane may leave the histogram behind (k_pages32<true, true>): room for its rows.
 // (Not for a context that reports a slot range of its table — own_set, the merge-at-finalize counter — or whose
 // histogram was asked to stay with the scan, SHK_FUSED_HIST=0.)
-static bool fused_hist_wanted(const shk_ctx *c) { return !c->own_set && !c->zero_count_keys && env_int("SHK_FUSED_HIST", 1) != 0; }
+static bool fused_hist_wanted(const shk_ctx *c) {
+  // (one lane on a large table: the scan's 4 B per slot cost less than the pass's extra work — measured on a 30 Mb
+  // genome, 8192 pages: pages + 0.06 ms for a scan of 0.077; from two lanes on, and on small tables, the pass wins)
+  if (c->n_lanes == 1 && c->tb.log_pages > 11 && env_int("SHK_FUSED_HIST", 1) != 2) return false;
+  return !c->own_set && !c->zero_count_keys && !c->fused_off && env_int("SHK_FUSED_HIST", 1) != 0;
+}
 static int fused_hist_prepare(shk_ctx *c, uint32_t n_pages, FusedHist *fh) {
   const uint32_t n_cols = c->cfg.chunks;
   HIPC(c, c->fh_partial.ensure((size_t)n_pages * std::max<uint32_t>(n_cols, 1) * FH_BINS * 4));
@@ -2720,7 +2725,7 @@ static int finalize_scan(shk_ctx *c) {
   if (fused) {
     // (d_tot is zero and d_hist holds the pass's bins ≥ FH_BINS only: both were cleared before that pass — by the
     // reset, or by the k_mark_starts of its ingest — and nobody has written them since, or fused_valid would be off)
-    ScopedTimer t(c, SHK_K_HISTO);
+    ScopedTimer t(c, SHK_K_HISTO_ROWS);
     const uint32_t n_pages = c->fused_pages;
     const uint32_t gx = std::max<uint32_t>((n_cols * FH_BINS + WG - 1) / WG, 1), gy = std::min<uint32_t>(std::max<uint32_t>(n_pages / 8, 1), 1024);  // (eight rows per thread up to 8 Ki pages; 1024 slices beyond)
     hipLaunchKernelGGL(k_hist_reduce, dim3(gx, gy), dim3(WG), 0, c->stream, (const uint32_t *)c->fh_partial.p, (const unsigned long long *)c->fh_tot.p, n_pages,
@@ -2791,6 +2796,12 @@ static int finalize_fetch(shk_ctx *c) {
     HIPC(c, q);
   }
   c->h_tot = *c->h_totp;
+  {  // a fused page pass's adds past its LDS bins ride in the upper half of the saturation word; many of them (deep coverage: same-line
+     // global adds, one after the other) and this context's later jobs leave the histogram to k_histo
+    const unsigned long long n_high = c->h_tot.any_saturated >> 32;
+    c->h_tot.any_saturated = (c->h_tot.any_saturated & 0xFFFFFFFFull) != 0;
+    if (n_high > (1ull << 16)) c->fused_off = true;
+  }
   c->fin_scanned = false;
   return SHK_OK;
 }

@@ -28,7 +28,7 @@ FASTQ_GZIP_ALL_MEMBERS = 1  # shk_fastq_open_ex / shk_run_config.fastq_flags (in
 FLAG_DEFER_ERRORS = 8  # host-buffer ingests return once queued; errors surface at the next call (include/shk.h)
 
 KERNEL_NAMES = ["mark", "scan", "direct", "scatter", "pages", "histo", "grow", "insert",
-                "lookup", "export", "synth", "merge", "pcount", "pscan"]
+                "lookup", "export", "synth", "merge", "pcount", "pscan", "histo_rows"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
