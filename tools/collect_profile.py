@@ -23,7 +23,7 @@ stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursi
 shutil.copy(stats, f"profiles/{rnd}_kernel_stats.csv")
 
 # kernel-name prefix → short name used by bench.py (first match wins)
-NAMES = [("k_scatter32", "scatter"), ("k_part_scatter_sorted", "scatter"), ("k_pages32", "pages"),
+NAMES = [("k_scatter32", "scatter"), ("k_scatter64", "scatter"), ("k_part_scatter_sorted", "scatter"), ("k_pages32", "pages"), ("k_hist_reduce", "histo_rows"), ("k_ctl_out", "ctl_out"),
          ("k_pages", "pages"), ("k_part_rescatter", "rescatter"), ("k_fill", "fill"), ("k_histo", "histo"),
          ("k_direct", "direct"), ("k_scan", "scan"), ("k_mark_starts", "mark")]
 
