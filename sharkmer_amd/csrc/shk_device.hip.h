@@ -2772,12 +2772,19 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
 constexpr int RS_NT = SHK_RS_NT;
 constexpr int RS_TILE = 4096;              // records per tile: they stay in LDS (32 KiB) for the write-out
 constexpr int RS_SPAN = RS_TILE / RS_NT;   // records per thread
+// LIST mode of k_part_rescatter (below): a flat list of n k-mers (+ lanes) as the source; sub_shift / owner bits: which
+// bits of a k-mer's page this pass sorts by (0 / none for the ordinary second level)
+struct RescatterList {
+  const uint32_t *lanes;  // chunk lane per k-mer, or nullptr: all of them are `lane`'s
+  uint64_t n;             // 0: not a list
+  uint32_t sub_shift, owner_bits, owner_id, pad;
+};
 __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
     const uint64_t *__restrict__ src_buf, const unsigned int *__restrict__ src_cursor, uint32_t src_cap,
     uint32_t tiles_per_region, uint32_t log_pages, uint32_t log_sub, uint32_t key_bits,
     unsigned int *__restrict__ dst_cursor,
     uint32_t dst_cap, uint64_t *__restrict__ dst_buf, uint32_t lane, DevStats *__restrict__ stats,
-    SpillRef sp, uint32_t src_interleaved) {
+    SpillRef sp, uint32_t src_interleaved, RescatterList ls = RescatterList{}) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[RS_NT / 64];
   static_assert(RS_TILE == 1 << S64_IL_LOG, "k_scatter64's interleave block is this kernel's tile");
@@ -2786,14 +2793,27 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
   // (the tiles of one source region go to ONE XCD: see k_part_rescatter32)
   uint32_t bid = blockIdx.x;
   if ((gridDim.x & 7u) == 0) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const uint32_t region = bid / tiles_per_region, tile = bid % tiles_per_region;
-  const uint32_t filled = src_cursor[region] < src_cap ? src_cursor[region] : src_cap;
-  const uint32_t r0 = tile * RS_TILE;
+  // LIST mode (ls.n > 0): the source is a flat list of k-mers (+ their chunk lanes) instead of a region — the first
+  // level of the partition for k-mers that arrive as k-mers (shk_insert_device: the wide exchange round's receiver).
+  // One "region" 0, tile = workgroup; k-mers of other lanes and — on an owner share — of other owners are skipped.
+  const bool list = ls.n != 0;
+  const uint32_t region = list ? 0u : bid / tiles_per_region, tile = list ? bid : bid % tiles_per_region;
+  const uint64_t filled = list ? ls.n : (uint64_t)(src_cursor[region] < src_cap ? src_cursor[region] : src_cap);
+  const uint64_t r0 = (uint64_t)tile * RS_TILE;
   if (r0 >= filled) return;
-  const uint32_t n = filled - r0 < (uint32_t)RS_TILE ? filled - r0 : (uint32_t)RS_TILE;  // even
+  const uint32_t n = filled - r0 < (uint64_t)RS_TILE ? (uint32_t)(filled - r0) : (uint32_t)RS_TILE;  // (even, except a list's last tile)
+  const uint32_t lp_mask = log_pages >= 32 ? 0xFFFFFFFFu : (1u << log_pages) - 1u;
+  // the page of a k-mer inside this table (an owner share: the low log_pages bits of its page in the virtual table;
+  // *own = the top bits name this share) and from it the partition this pass sorts by
+  auto sub_of = [&](uint64_t km, bool *own) -> uint32_t {
+    const uint32_t gp = (uint32_t)page_of(hash64(km, key_bits), log_pages + ls.owner_bits);
+    if (own) *own = ls.owner_bits == 0 || (gp >> log_pages) == ls.owner_id;
+    return ((gp & lp_mask) >> ls.sub_shift) & (S - 1u);
+  };
   // (src_interleaved: k_scatter64<.., true>'s layout — tile t of region r is block t · n_regions + r)
-  const uint64_t *src = src_interleaved ? src_buf + (((uint64_t)tile * (gridDim.x / tiles_per_region) + region) << S64_IL_LOG)
-                                        : src_buf + (uint64_t)region * src_cap + r0;
+  const uint64_t *src = list ? src_buf + r0
+                        : src_interleaved ? src_buf + (((uint64_t)tile * (gridDim.x / tiles_per_region) + region) << S64_IL_LOG)
+                                          : src_buf + (uint64_t)region * src_cap + r0;
   uint64_t *recs = reinterpret_cast<uint64_t *>(sh);                       // RS_TILE records
   uint16_t *sorted = reinterpret_cast<uint16_t *>(sh + 2 * RS_TILE);       // RS_TILE + S entries
   uint32_t *cnt = sh + 2 * RS_TILE + (((uint32_t)RS_TILE + S) * 2 + 15) / 16 * 4;  // S
@@ -2803,22 +2823,32 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
   __syncthreads();
   // ---- rank: (page-in-super-page, rank) per record, in registers -------------------------------
   uint32_t pr[RS_SPAN];
-  const uint32_t sub_mask = S - 1;
 #pragma unroll
   for (int q = 0; q < RS_SPAN / 2; ++q) {
     const uint32_t i = (uint32_t)(q * RS_NT + threadIdx.x) * 2;  // record pair, coalesced 16-B loads
     uint32_t va = 0xFFFFFFFFu, vb = 0xFFFFFFFFu;
     if (i < n) {
-      const ulonglong2 rec = *reinterpret_cast<const ulonglong2 *>(src + i);
-      *reinterpret_cast<ulonglong2 *>(recs + i) = rec;
+      ulonglong2 rec;
+      if (list) {  // single k-mers, the lane's and the share's own only
+        rec.x = !ls.lanes || ls.lanes[r0 + i] == lane ? src[i] : EMPTY;
+        rec.y = i + 1 < n && (!ls.lanes || ls.lanes[r0 + i + 1] == lane) ? src[i + 1] : EMPTY;
+      } else {
+        rec = *reinterpret_cast<const ulonglong2 *>(src + i);
+      }
+      uint32_t sa = 0, sb = 0;
       if (rec.x != EMPTY) {
-        const uint32_t sub = (uint32_t)page_of(hash64(rec.x, key_bits), log_pages) & sub_mask;
-        va = (sub << 16) | atomicAdd(&cnt[sub], 1u);
+        bool own;
+        sa = sub_of(rec.x, &own);
+        if (!own) rec.x = EMPTY;
       }
       if (rec.y != EMPTY) {
-        const uint32_t sub = (uint32_t)page_of(hash64(rec.y, key_bits), log_pages) & sub_mask;
-        vb = (sub << 16) | atomicAdd(&cnt[sub], 1u);
+        bool own;
+        sb = sub_of(rec.y, &own);
+        if (!own) rec.y = EMPTY;
       }
+      *reinterpret_cast<ulonglong2 *>(recs + i) = rec;
+      if (rec.x != EMPTY) va = (sa << 16) | atomicAdd(&cnt[sa], 1u);
+      if (rec.y != EMPTY) vb = (sb << 16) | atomicAdd(&cnt[sb], 1u);
     }
     pr[2 * q] = va;
     pr[2 * q + 1] = vb;
@@ -2867,7 +2897,7 @@ __global__ void __launch_bounds__(RS_NT) k_part_rescatter(
     const uint32_t ea = ee & 0xFFFFu, eb = ee >> 16;
     const uint64_t km0 = recs[ea];
     const uint64_t km1 = eb == 0xFFFFu ? EMPTY : recs[eb];
-    const uint32_t sub = (uint32_t)page_of(hash64(km0, key_bits), log_pages) & sub_mask;
+    const uint32_t sub = sub_of(km0, nullptr);
     const uint32_t at = gbase[sub] + (2 * i - tstart[sub]);
     const uint64_t page = ((uint64_t)region << log_sub) + sub;
     if (at + 2 <= dst_cap) {

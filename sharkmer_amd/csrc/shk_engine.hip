@@ -2642,11 +2642,90 @@ int shk_xchg_spill_clear(shk_ctx *c) {
   return SHK_OK;
 }
 
+// A LIST of k-mer occurrences (count 1 each, with their chunk lanes) through the paged passes instead of the global
+// atomics of k_insert: what the receiver of a wide exchange round holds (k > 21 between owner shares: 8-byte k-mers
+// cross the links).  The list is partitioned like a batch of reads — level 1 by k_part_rescatter in its list mode (one
+// pass per chunk lane: k-mers of other lanes, and of other owners, are skipped), level 2 into the waiting (lane, page)
+// regions — and counted by the page pass the window's budget or a finalize asks for.  A k = 31 share of 300 M
+// distinct k-mers absorbed 14 G k-mers/s through k_insert; see DESIGN.md §6 for what it does this way.
+static bool insert_list_paged_ok(const shk_ctx *c, const void *d_counts, uint64_t n) {
+  if (d_counts || n < (uint64_t)env_int("SHK_INSERT_PAGED_MIN", 1 << 20) || env_int("SHK_INSERT_PAGED", 1) == 0) return false;
+  if (!paged_feasible(c) || (c->cfg.flags & SHK_FLAG_FORCE_DIRECT) || env_int("SHK_DEFER", 1) == 0) return false;
+  const PartGeom g = part_geom(c);
+  if (use_rec32(c, g) || !g.two_level || c->tb.log_pages < 8) return false;  // (4-byte records have the owner layout; a table of one level is small)
+  if (g.log_p1 - g.lw > 10 || g.log_sub > 10) return false;  // (fan-outs of ≤ 1024: the kernel's LDS stays below 64 KiB)
+  return n < (1ull << 32);
+}
+static int insert_list_paged(shk_ctx *c, const uint64_t *d_kmers, const uint32_t *d_lanes, uint64_t n) {
+  int rc = settle_light(c);  // the last launch's outcome (its spills would be overwritten by this one's)
+  if (rc != SHK_OK) return rc;
+  const uint32_t NL = c->n_lanes;
+  // (every lane's regions may get all of the list: nothing is known about its lanes)
+  rc = acc_prepare(c, n, NL == 1 ? 0 : -1, n);
+  if (rc != SHK_OK) return rc;
+  if (!insert_list_paged_ok(c, nullptr, n)) return SHK_ERR_STATE;  // (a flush in acc_prepare grew the table out of the route: the caller falls back)
+  const PartGeom g = part_geom(c);
+  const uint32_t lp = g.lp, n_pages = g.n_pages, S1_log = g.log_p1 - g.lw, S1 = 1u << S1_log, log_sub = g.log_sub, S2 = 1u << log_sub;
+  const uint32_t tiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+  const uint32_t cap1 = (region_cap(n, S1, tiles) + 1u) & ~1u;
+  if ((uint64_t)S1 * cap1 * 8 > 0xFFFFFFFFull * 8ull) return SHK_ERR_STATE;
+  HIPC(c, c->part.ensure((uint64_t)S1 * cap1 * 8));
+  HIPC(c, c->part_meta.ensure(std::max<size_t>(cursor_buf_bytes(c, g, false), (size_t)S1 * 4 + 64)));
+  unsigned int *cursor1 = (unsigned int *)c->part_meta.p;
+  const uint64_t spill_cap = std::max<uint64_t>(c->acc_spill_cap, n);
+  c->acc_spill_cap = spill_cap;
+  HIPC(c, c->spillA.ensure(spill_cap * 16));
+  SpillRef sp = spill_ref(c->spillA, spill_cap);
+  HIPC(c, hipMemsetAsync(&c->d_stats->spill_count, 0, sizeof(unsigned long long), c->stream));
+  auto lds_for = [](uint32_t S) { return (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12; };
+  const uint32_t tiles_per_region = (cap1 + RS_TILE - 1) / RS_TILE;
+  for (uint32_t lane = 0; lane < NL; ++lane) {
+    HIPC(c, hipMemsetAsync(cursor1, 0, (size_t)S1 * 4, c->stream));
+    RescatterList ls{};
+    ls.lanes = NL > 1 ? d_lanes : nullptr;
+    ls.n = n;
+    ls.sub_shift = log_sub;
+    ls.owner_bits = g.lw;
+    ls.owner_id = c->tb.owner_id;
+    {
+      ScopedTimer t(c, SHK_K_SCATTER);  // level 1: list → the share's super-page regions
+      hipLaunchKernelGGL(k_part_rescatter, dim3(tiles), dim3(RS_NT), lds_for(S1), c->stream, d_kmers, (const unsigned int *)nullptr, 0u, tiles, lp, S1_log,
+                         2 * c->cfg.k, cursor1, cap1, (uint64_t *)c->part.p, lane, c->d_stats, sp, 0u, ls);
+    }
+    {
+      ScopedTimer t(c, SHK_K_PSCAN, /*chain=*/true);  // level 2: → this lane's waiting page regions
+      RescatterList l2{};
+      l2.owner_bits = g.lw;
+      l2.owner_id = c->tb.owner_id;
+      hipLaunchKernelGGL(k_part_rescatter, dim3(S1 * tiles_per_region), dim3(RS_NT), lds_for(S2), c->stream, (const uint64_t *)c->part.p,
+                         (const unsigned int *)cursor1, cap1, tiles_per_region, lp, log_sub, 2 * c->cfg.k,
+                         (unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
+                         (uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap, lane, c->d_stats, sp, 0u, l2);
+    }
+  }
+  HIPC(c, hipGetLastError());
+  c->acc_active = true;
+  acc_book(c, n, NL == 1 ? 0 : -1, n);
+  c->unsettled = true;
+  c->unsettled_spill_cap = spill_cap;
+  return SHK_OK;
+}
+
 int shk_insert_device(shk_ctx *c, const void *d_kmers, const void *d_lanes, const void *d_counts, uint64_t n) {
   if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c) return SHK_ERR_BAD_ARG;
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
   HIPC(c, hipSetDevice(c->cfg.device));
+  if (d_kmers && insert_list_paged_ok(c, d_counts, n) && (d_lanes || c->n_lanes == 1)) {
+    fused_drop(c);
+    c->finalized = c->hist_ready = false;
+    const int rcp = insert_list_paged(c, (const uint64_t *)d_kmers, (const uint32_t *)d_lanes, n);
+    if (rcp == SHK_OK) {
+      c->n_inserted += n;
+      return SHK_OK;
+    }
+    if (rcp != SHK_ERR_STATE) return rcp;  // (SHK_ERR_STATE: not this way after all — the general path below)
+  }
   {
     int rcf = tb_fresh(c);
     if (rcf != SHK_OK) return rcf;

@@ -117,7 +117,7 @@ def test_owner_share_skewed_input_spills_exactly(orc, monkeypatch):
 
 # ---- exchange mode: W contexts on one card as W ranks ------------------------------------------------
 
-def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint, reserve_cus=0):
+def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint, reserve_cus=0, timing=False):
     """Every rank ingests its own 1000-read batches (round-robin, shard_batches), one batch per round."""
     n_reads = len(offsets) - 1
     ref = orc.run_batch(bases, offsets, k, chunks, histo_max) if orc is not None else None
@@ -128,7 +128,8 @@ def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint, reserve_cu
 
     def run(rank):
         try:
-            eng = sa.KmerEngine(k, chunks, histo_max, capacity_hint=hint, n_owners=W, owner_id=rank, reserve_cus=reserve_cus)
+            eng = sa.KmerEngine(k, chunks, histo_max, capacity_hint=hint, n_owners=W, owner_id=rank, reserve_cus=reserve_cus,
+                                flags=sa.FLAG_TIMING if timing else 0)
             oc = OwnerCounter(eng, ThreadGroup(shared, rank), device=0, round_bases=1000 * 160)
             mine = shard_batches(n_reads, rank, W)
             keep = []
@@ -141,7 +142,7 @@ def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint, reserve_cu
                 offs = torch.from_numpy((offsets[first:first + n + 1] - offsets[first]).astype(np.int64)).cuda()
                 keep.append(offs)
                 oc.round((d_bases[o0:o1].data_ptr(), offs.data_ptr(), n, o1 - o0, first))
-            results[rank] = (oc.finalize_histograms(), oc.totals, eng.counters()["n_spilled"], oc.n_foreign_rounds)
+            results[rank] = (oc.finalize_histograms(), oc.totals, eng.counters()["n_spilled"], oc.n_foreign_rounds, eng.timings() if timing else None)
             eng.close()
         except Exception as e:  # noqa: BLE001
             errors.append(e)
@@ -154,7 +155,7 @@ def _exchange_run(orc, bases, offsets, k, chunks, histo_max, W, hint, reserve_cu
         t.join()
     assert not errors, errors
     st = ref.stats
-    for hist, tot, _, _ in results:
+    for hist, tot, _, _, _ in results:
         assert np.array_equal(hist, ref.histograms())
         for f in ("n_kmers_ingested", "n_unique_kmers", "n_reads_ingested", "n_bases_ingested", "n_hashed_kmers"):
             assert tot[f] == st[f], f
@@ -170,6 +171,51 @@ def test_exchange_between_contexts_like_ranks(orc, monkeypatch, W, k, chunks, lv
     spec = sa.SynthSpec(genome_len=80_000, sub_per_64k=250, n_per_64k=50)
     bases, offsets = sa.synth_reads(spec, 0, 20_500)
     _exchange_run(orc, bases, offsets, k, chunks, 300, W, hint=4_200_000 if lvl1 == 10 else 1_000_000)  # (2k - lvl1 ≤ 32: 4-byte records)
+
+
+@pytest.mark.parametrize("W,k,chunks", [(2, 31, 10), (4, 27, 3), (8, 23, 1), (1, 31, 2), (2, 22, 0)])
+def test_wide_round_receiver_through_the_paged_passes(orc, monkeypatch, W, k, chunks):
+    """The receiver of a wide round counts a list of a million k-mers and more through the partition + page passes
+    (shk_insert_device's list route: level 1 by k_part_rescatter in its list mode, a pass per chunk lane, foreign owners'
+    k-mers skipped) instead of k_insert's global atomics.  SHK_INSERT_PAGED_MIN=1 takes these small rounds that way;
+    the result is the oracle's either way."""
+    monkeypatch.setenv("SHK_LEVEL1_LOG", "10")
+    monkeypatch.setenv("SHK_INSERT_PAGED_MIN", "1")
+    spec = sa.SynthSpec(genome_len=80_000, sub_per_64k=250, n_per_64k=50)
+    bases, offsets = sa.synth_reads(spec, 0, 20_500)
+    res = _exchange_run(orc, bases, offsets, k, chunks, 300, W, hint=4_200_000, timing=True)
+    for r in res:
+        assert "insert" not in r[4] or r[4]["insert"][1] <= 2, r[4]   # (a repair insert at most: the rounds went the paged way)
+        assert "pages" in r[4], r[4]
+    monkeypatch.setenv("SHK_INSERT_PAGED", "0")
+    res = _exchange_run(orc, bases, offsets, k, chunks, 300, W, hint=4_200_000, timing=True)
+    assert all("insert" in r[4] for r in res)
+
+
+def test_a_list_of_k_mers_with_lanes_either_way(orc, monkeypatch):
+    """shk_insert_device on one context: k-mer occurrences with their chunk lanes, the list route against k_insert and
+    against counting by hand; then more reads on top, and a grow in between (no capacity hint)."""
+    rng = np.random.default_rng(3)
+    k, chunks = 31, 3
+    distinct = rng.integers(0, 1 << 62, size=40_000, dtype=np.uint64)
+    kmers = distinct[rng.integers(0, len(distinct), size=300_000)]
+    lanes = rng.integers(0, chunks, size=len(kmers)).astype(np.uint32)
+    tables = []
+    for paged in ("1", "0"):
+        monkeypatch.setenv("SHK_INSERT_PAGED", paged)
+        monkeypatch.setenv("SHK_INSERT_PAGED_MIN", "1")
+        with sa.KmerEngine(k, chunks, 1000, capacity_hint=40_000_000, flags=sa.FLAG_TIMING) as eng:   # 2^27 slots: two levels
+            eng.insert_tensors(torch.from_numpy(kmers.view(np.int64)).cuda(), torch.from_numpy(lanes.view(np.int32)).cuda(), None)
+            eng.insert_tensors(torch.from_numpy(kmers[:1000].view(np.int64)).cuda(), torch.from_numpy(lanes[:1000].view(np.int32)).cuda(), None)
+            eng.finalize()
+            tim = eng.timings()
+            assert ("insert" in tim) == (paged == "0"), tim
+            tables.append((eng.export_table(), eng.histograms().copy()))
+    (k1, c1), h1 = tables[0]
+    (k0, c0), h0 = tables[1]
+    assert np.array_equal(k1, k0) and np.array_equal(c1, c0) and np.array_equal(h1, h0)
+    want_k, want_c = np.unique(np.concatenate([kmers, kmers[:1000]]), return_counts=True)
+    assert np.array_equal(k1, want_k) and np.array_equal(c1, want_c.astype(np.uint32))
 
 
 @pytest.mark.parametrize("reserve", [sa.RESERVE_NONE, 8, 100, 250])

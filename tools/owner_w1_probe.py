@@ -13,7 +13,7 @@ import torch.distributed as dist  # noqa: E402
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 12_500_000
 genome = int(sys.argv[2]) if len(sys.argv) > 2 else 300_000_000
 lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-L, k = 150, 21
+L, k = 150, (int(sys.argv[4]) if len(sys.argv) > 4 else 21)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)
