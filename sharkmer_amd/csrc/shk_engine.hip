@@ -255,6 +255,7 @@ struct shk_ctx {
   // first call — says so; so do a grow and a reset).
   DevBuf fh_partial, fh_tot;
   bool fused_valid = false, fused_off = false;
+  bool flush_for_finalize = false;  // the settle in progress is finalize's own (the last page pass of the job, as far as anybody knows)
   uint32_t fused_pages = 0;
   size_t ctl_bytes = 0, ctl_hist_off = 0, ctl_tot_off = 0, ctl_alloc = 0, ctl_alloc_h = 0;
   unsigned long long *d_lane_sum = nullptr, *h_lane_sum = nullptr;
@@ -1692,7 +1693,9 @@ static int flush_acc(shk_ctx *c) {
   if (!c->acc_rec32)
     HIPC(c, c->part2.ensure((uint64_t)n_pages * std::min<uint64_t>((uint64_t)c->acc_cap + MISS_SLACK, MISS_PAGE_MAX) * 8));  // (planned with the regions)
   FusedHist fh{};
-  const bool fuse = fresh && c->acc_rec32 && fused_hist_wanted(c);
+  // (only the flush a finalize asked for: a window that ends on its budget is followed by another, whose pass would
+  // overtake this one's histogram — configs[4]'s share, ten lanes: 4.5 ms of fold for nothing)
+  const bool fuse = fresh && c->acc_rec32 && c->flush_for_finalize && fused_hist_wanted(c);
   if (fuse) {
     int rch = fused_hist_prepare(c, n_pages, &fh);
     if (rch != SHK_OK) return rch;
@@ -2780,7 +2783,9 @@ static int finalize_scan(shk_ctx *c) {
     return fail(c, SHK_ERR_NO_READS,
                 "No reads were ingested. Check that input files contain valid FASTQ records.");
   if (c->acc_active) {  // records still waiting for their page pass
+    c->flush_for_finalize = true;
     int rcf = settle(c);
+    c->flush_for_finalize = false;
     if (rcf != SHK_OK) return rcf;
   }
   // The scan below is queued optimistically behind a counting launch nobody has looked at yet; if that launch
