@@ -752,10 +752,28 @@ struct GzSource final : Source {
     issue_up_to(ahead);
 
     // a piece of output on its way out: [window w_len][n bytes] in one block; `pending` jobs still write into it
+    // (a count the workers take down and this thread sleeps on — it used to spin with yield())
+    struct Pending {
+      std::mutex m;
+      std::condition_variable cv;
+      int n = 0;
+      void set(int k) {
+        std::lock_guard<std::mutex> lk(m);
+        n = k;
+      }
+      void done() {
+        std::lock_guard<std::mutex> lk(m);
+        if (--n <= 0) cv.notify_all();
+      }
+      void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return n <= 0; });
+      }
+    };
     struct Piece {
       std::shared_ptr<Buf> buf;
       size_t w_len = 0, n = 0;
-      std::shared_ptr<std::atomic<int>> pending;
+      std::shared_ptr<Pending> pending;
     };
     std::deque<Piece> out_q;
     std::vector<uint8_t> W;       // the last ≤ 32 KiB of everything decoded so far
@@ -780,7 +798,7 @@ struct GzSource final : Source {
       out_q.pop_front();
       {
         const double t0 = tnow();
-        while (pc.pending && pc.pending->load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        if (pc.pending) pc.pending->wait();
         t_wait_resolve += tnow() - t0;
       }
       const double t_e0 = tnow();
@@ -891,7 +909,7 @@ struct GzSource final : Source {
       pc.buf = b;
       pc.w_len = w_len;
       pc.n = n;
-      pc.pending = std::make_shared<std::atomic<int>>(0);
+      pc.pending = std::make_shared<Pending>();
       // the next window first (the last 32 KiB of this chunk's bytes), by this thread
       {
         const size_t t0 = n > 32768 ? n - 32768 : 0;
@@ -911,7 +929,7 @@ struct GzSource final : Source {
       // all of it, in slices, by the workers
       const size_t slice = 1u << 20;
       const size_t n_slices = (n + slice - 1) / slice;
-      pc.pending->store((int)n_slices, std::memory_order_release);
+      pc.pending->set((int)n_slices);
       auto keep = std::make_shared<SpecResult>(std::move(r));
       for (size_t sl = 0; sl < n_slices; ++sl) {
         const size_t j0 = sl * slice, j1 = std::min(n, j0 + slice);
@@ -924,7 +942,7 @@ struct GzSource final : Source {
             const uint16_t s2 = sy[j];
             dst[j] = s2 < 256 ? (uint8_t)s2 : ((size_t)(s2 - 256) >= shift ? base[(size_t)(s2 - 256) - shift] : (uint8_t)0);
           }
-          pend->fetch_sub(1, std::memory_order_acq_rel);
+          pend->done();
         });
       }
       out_q.emplace_back(std::move(pc));
@@ -1030,7 +1048,7 @@ struct GzSource final : Source {
           pc.n -= t;
           cut -= t;
           if (pc.n == 0 && out_q.size() > 1) {
-            while (pc.pending && pc.pending->load(std::memory_order_acquire) > 0) std::this_thread::yield();
+            if (pc.pending) pc.pending->wait();
             out_q.pop_back();
           } else if (pc.n == 0) {
             break;
