@@ -2671,7 +2671,6 @@ static int insert_list_paged(shk_ctx *c, const uint64_t *d_kmers, const uint32_t
   const uint32_t lp = g.lp, n_pages = g.n_pages, S1_log = g.log_p1 - g.lw, S1 = 1u << S1_log, log_sub = g.log_sub, S2 = 1u << log_sub;
   const uint32_t tiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
   const uint32_t cap1 = (region_cap(n, S1, tiles) + 1u) & ~1u;
-  if ((uint64_t)S1 * cap1 * 8 > 0xFFFFFFFFull * 8ull) return SHK_ERR_STATE;
   HIPC(c, c->part.ensure((uint64_t)S1 * cap1 * 8));
   HIPC(c, c->part_meta.ensure(std::max<size_t>(cursor_buf_bytes(c, g, false), (size_t)S1 * 4 + 64)));
   unsigned int *cursor1 = (unsigned int *)c->part_meta.p;
