@@ -381,9 +381,12 @@ typedef struct shk_xchg_layout {
   uint32_t n_lanes;         /* chunk lanes (max(chunks, 1)) */
   uint32_t log_p1;          /* level-1 fan-out bits, owner bits included */
   uint32_t regions;         /* regions per owner segment: n_lanes << (log_p1 − log2 W), ordered [lane][super-page] */
-  uint32_t region_cap;      /* records per region (a multiple of 1024); the regions of a segment are
-                               block-interleaved: record j of region g at ((j>>10)·regions + g)<<10 | (j & 1023) */
-  uint32_t reserved;
+  uint32_t region_cap;      /* records per region (a multiple of 1024); 4-byte records: the regions of a segment are
+                               block-interleaved — record j of region g at ((j>>10)·regions + g)<<10 | (j & 1023); 8-byte
+                               records: region g at g·region_cap, linear */
+  uint32_t record_bytes;    /* 4: the low bits of the mixed key below the level-1 fan-out (2k − log_p1 ≤ 32: k ≤ 21);
+                               8 (round 4): the canonical k-mer itself (k ≥ 18 on a two-level table) — runs are padded to
+                               even length with the all-ones word; 0 reads as 4 */
   uint64_t segment_records; /* regions · region_cap */
 } shk_xchg_layout;
 /* layout_bases: what the segments are sized for — every rank of a round passes the same number

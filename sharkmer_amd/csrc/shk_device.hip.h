@@ -2492,11 +2492,23 @@ __global__ void __launch_bounds__(NT, 4) k_scatter32(
 // write fronts stay within P · 32 KiB of one another instead of one per region-sized stride (a dozen address
 // translations per store instruction otherwise).  !IL: region r at r · cap_p (page regions k_pages reads).
 constexpr int S64_IL_LOG = 12;  // = log2(RS_TILE), asserted below
-template <int NT, int TT, bool IL>
+// OWN (layout 2): the OWNER layout of the exchange between owner shares, as k_scatter32's — the fan-out covers the
+// virtual table (the top own.log_w bits of a partition are the record's owner), regions and cursors are ordered
+// [owner][lane][super-page], every owner's own.seg_recs records' worth of regions one contiguous piece (what crosses the
+// link), linear inside; records of all owners are kept, a full region spills to the list sp.count counts.
+constexpr int S64_LINEAR = 0, S64_INTERLEAVED = 1, S64_OWNER = 2;
+template <int NT, int TT, int LAYOUT>
 __global__ void __launch_bounds__(NT, 4) k_scatter64(
     BatchRef b, uint32_t log_parts, uint32_t lane_filter, unsigned int *__restrict__ cursor,
     uint32_t cap_p, uint64_t *__restrict__ part_buf, DevStats *__restrict__ stats,
-    unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg) {
+    unsigned long long *__restrict__ lane_bases, SpillRef sp, unsigned long long *__restrict__ dbg,
+    OwnerCfg own = OwnerCfg{}, uint32_t n_region_lanes = 1) {
+  constexpr bool IL = LAYOUT == S64_INTERLEAVED, OWN = LAYOUT == S64_OWNER;
+  const uint32_t log_p1w = OWN ? log_parts - own.log_w : 0u;  // super-page bits inside an owner's share
+  const uint32_t p1w_mask = (1u << log_p1w) - 1u;
+  const uint32_t n_grp = n_region_lanes << log_p1w;           // regions of one owner segment
+  // region of partition i for a tile of chunk lane ln, among ALL regions of the launch ([owner][lane][super-page])
+  auto own_region = [&](uint32_t i, uint32_t ln) -> uint32_t { return (i >> log_p1w) * n_grp + ((ln << log_p1w) | (i & p1w_mask)); };
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[NT / 64];
   __shared__ uint32_t red[NT / 64];
@@ -2639,7 +2651,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
       my_c1 = mine ? cnt[threadIdx.x] : 0u;
       const uint32_t sacc = (my_c1 + 1u) & ~1u;
       // reserve this sub-tile's (even-padded) run in the partition's region: the return is looked at in the place phase
-      if (my_c1) gres = atomicAdd(&cursor[threadIdx.x], sacc);
+      if (my_c1) gres = atomicAdd(&cursor[OWN ? own_region(threadIdx.x, lane) : threadIdx.x], sacc);
       const uint32_t inc = wave_scan_incl(sacc);
       if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
       __syncthreads();
@@ -2712,11 +2724,11 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
           if (i0 + j * NT >= n_pairs) continue;
           if (at[j] + 2 <= cap_p) {
             const uint32_t rec_off = IL ? ((((at[j] >> S64_IL_LOG) << log_parts) + pc[j]) << S64_IL_LOG) | (at[j] & ((1u << S64_IL_LOG) - 1u))
-                                        : pc[j] * cap_p + at[j];
+                                        : (OWN ? own_region(pc[j], lane) : pc[j]) * cap_p + at[j];
             const uint32_t byte_off = rec_off * 8u;  // < 2^32 (the host sizes a launch's regions so)
             *reinterpret_cast<ulonglong2 *>(base + byte_off) = rec[j];
           } else {  // the region is full (skewed input): these records take the spill path
-            const unsigned long long jj = atomicAdd(&stats->spill_count, rec[j].y == EMPTY ? 1ull : 2ull);
+            const unsigned long long jj = atomicAdd(OWN && sp.count ? sp.count : &stats->spill_count, rec[j].y == EMPTY ? 1ull : 2ull);
             if (jj < sp.cap) {
               sp.keys[jj] = rec[j].x;
               sp.lanes[jj] = lane;

@@ -960,8 +960,9 @@ static bool first_launch_defers(shk_ctx *c, uint64_t kmers_ub, bool multi) { ret
 
 // Bytes of the per-launch cursor buffer (part_meta).  One size for everybody who asks: the buffer
 // must not be reallocated between k_mark_starts (which clears cursors in it) and the partition launch.
+static bool xl64_feasible(const shk_ctx *c, const PartGeom &g);
 static size_t cursor_buf_bytes(const shk_ctx *c, const PartGeom &g, bool multi) {
-  const bool lanes = use_all_lanes(c, g, multi) || xl_feasible(c, g);  // (the owner layout: n_lanes · P1 words, whatever the number of segments)
+  const bool lanes = use_all_lanes(c, g, multi) || xl_feasible(c, g) || xl64_feasible(c, g);  // (the owner layouts: n_lanes · P1 words, whatever the number of segments)
   return ((size_t)(lanes ? c->n_lanes : 1) * g.P1 + g.n_pages) * 4 + 64;
 }
 
@@ -1024,25 +1025,32 @@ static bool use_scatter64(const shk_ctx *c, const PartGeom &g) {
   return !use_rec32(c, g) && g.log_p1 >= 3 && g.P1 <= (uint32_t)SC32_NT && c->cfg.k >= 18 && SC32_NT == 1024 && scatter64_lds(g.P1) <= SC32_LDS_MAX &&
          env_int("SHK_SCATTER64", 1) != 0;
 }
-template <bool IL>
+template <int LAYOUT>
 static hipError_t scatter64_variant(shk_ctx *c, bool set_attr, uint32_t G, size_t lds, const BatchRef &b, uint32_t log_p1, uint32_t lane,
-                                    unsigned int *cursor, uint32_t cap, uint64_t *buf, SpillRef sp, unsigned long long *dbg) {
+                                    unsigned int *cursor, uint32_t cap, uint64_t *buf, SpillRef sp, unsigned long long *dbg,
+                                    OwnerCfg own = OwnerCfg{}, uint32_t n_region_lanes = 1) {
   if (set_attr)
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter64<1024, 16384, IL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX);
-  hipLaunchKernelGGL((k_scatter64<1024, 16384, IL>), dim3(G), dim3(1024), lds, c->stream, b, log_p1, lane, cursor, cap, buf, c->d_stats, c->d_lane_bases, sp, dbg);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter64<1024, 16384, LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC32_LDS_MAX);
+  hipLaunchKernelGGL((k_scatter64<1024, 16384, LAYOUT>), dim3(G), dim3(1024), lds, c->stream, b, log_p1, lane, cursor, cap, buf, c->d_stats, c->d_lane_bases, sp, dbg,
+                     own, n_region_lanes);
   return hipSuccess;
+}
+static int scatter64_attrs(shk_ctx *c, const BatchRef &b, SpillRef sp) {
+  if (c->lds_attr_scatter64) return SHK_OK;
+  HIPC(c, scatter64_variant<S64_LINEAR>(c, true, 0, 0, b, 0, 0, nullptr, 0, nullptr, sp, nullptr));
+  HIPC(c, scatter64_variant<S64_INTERLEAVED>(c, true, 0, 0, b, 0, 0, nullptr, 0, nullptr, sp, nullptr));
+  HIPC(c, scatter64_variant<S64_OWNER>(c, true, 0, 0, b, 0, 0, nullptr, 0, nullptr, sp, nullptr));
+  c->lds_attr_scatter64 = true;
+  return SHK_OK;
 }
 // interleaved: the level-1 buffer of a two-level pass (what k_part_rescatter reads tile by tile); otherwise page regions
 static int launch_scatter64(shk_ctx *c, uint32_t G, const BatchRef &b, uint32_t log_p1, uint32_t lane, unsigned int *cursor, uint32_t cap,
                             uint64_t *buf, SpillRef sp, unsigned long long *dbg, bool interleaved) {
   const size_t lds = scatter64_lds(1u << log_p1);
-  if (!c->lds_attr_scatter64) {
-    HIPC(c, scatter64_variant<false>(c, true, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg));
-    HIPC(c, scatter64_variant<true>(c, true, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg));
-    c->lds_attr_scatter64 = true;
-  }
-  HIPC(c, interleaved ? scatter64_variant<true>(c, false, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg)
-                      : scatter64_variant<false>(c, false, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg));
+  int rc = scatter64_attrs(c, b, sp);
+  if (rc != SHK_OK) return rc;
+  HIPC(c, interleaved ? scatter64_variant<S64_INTERLEAVED>(c, false, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg)
+                      : scatter64_variant<S64_LINEAR>(c, false, G, lds, b, log_p1, lane, cursor, cap, buf, sp, dbg));
   return SHK_OK;
 }
 
@@ -1164,6 +1172,70 @@ static int xl_count(shk_ctx *c, const BatchRef &b, const PartGeom &g, uint64_t s
   return xl_absorb(c, g, (const uint32_t *)c->xbuf.p, (const unsigned int *)c->part_meta.p, x.cap1, x.n_grp, sp);
 }
 
+// ---- the owner layout with 8-byte records (k > 21: the mixed key's remainder does not fit a word) -------------------
+// The same segments — [owner][lane][super-page] regions of cap1 records, their fill levels beside them — with the
+// canonical k-mer as the record: k_scatter64 in its owner layout at the sender (a launch per chunk lane present in the
+// batch), k_part_rescatter at the receiver (a launch per lane of a segment) into the waiting (lane, page) regions that
+// k_pages counts.  Only the exchange rounds use it (a share's own ingest at k > 21 stays with the global atomics).
+static bool xl64_feasible(const shk_ctx *c, const PartGeom &g) {
+  // (≤ 32 chunk lanes: a round's segments — lanes · 2^log_p1 regions of at least 1024 records — stay below the 4 GiB the scatter addresses)
+  return g.two_level && use_scatter64(c, g) && g.log_sub <= 10 && c->n_lanes <= 32 && g.lpg <= MAX_LOG_PAGES &&
+         env_int("SHK_DEFER", 1) != 0 && env_int("SHK_XL64", 1) != 0;
+}
+static int xl64_scatter(shk_ctx *c, const BatchRef &b, const PartGeom &g, const XlPlan &x, SpillRef sp) {
+  const uint32_t NL = c->n_lanes;
+  const uint64_t total = (uint64_t)x.n_seg * x.seg_recs;
+  if (total * 8 > 0xFFFFFFFFull)
+    return fail(c, SHK_ERR_INVARIANT, "level-1 buffer of one launch exceeds 4 GiB (%llu 8-byte records)", (unsigned long long)total);
+  HIPC(c, c->xbuf.ensure(total * 8));
+  unsigned int *cursor = (unsigned int *)c->part_meta.p;
+  if (c->part_meta.cap < (size_t)x.n_seg * x.n_grp * 4) return fail(c, SHK_ERR_INVARIANT, "cursor buffer too small for the owner layout");
+  int rc = scatter64_attrs(c, b, sp);
+  if (rc != SHK_OK) return rc;
+  OwnerCfg own{};
+  own.log_w = g.lw;
+  own.keep = 0xFFFFFFFFu;
+  own.seg_recs = (uint32_t)x.seg_recs;
+  const uint32_t G = std::min<uint32_t>(grid_for(b.tile_count, 1, (uint32_t)env_int("SHK_PART_G", 512)), c->n_cus_scatter);
+  const size_t lds = scatter64_lds(g.P1);
+  // a batch inside one 1000-read block is one lane's; a tile list (k_build_tiles) may hold every lane's tiles
+  const uint32_t lane_lo = b.tiles ? 0u : b.lane0, lane_hi = b.tiles ? NL : b.lane0 + 1;
+  for (uint32_t lane = lane_lo; lane < lane_hi; ++lane) {
+    ScopedTimer t(c, SHK_K_SCATTER, /*chain=*/lane == lane_lo && c->chain_from_mark);
+    c->chain_from_mark = false;
+    HIPC(c, scatter64_variant<S64_OWNER>(c, false, G, lds, b, g.log_p1, lane, cursor, x.cap1, (uint64_t *)c->xbuf.p, sp, nullptr, own, NL));
+  }
+  return SHK_OK;
+}
+// Level-2 pass over ONE owner segment of 8-byte records into the waiting (lane, page) regions.
+static int xl64_absorb(shk_ctx *c, const PartGeom &g, const uint64_t *src_buf, const unsigned int *src_cursor, uint32_t cap1, uint32_t n_grp,
+                       SpillRef sp) {
+  const uint32_t NL = c->n_lanes, n_pages = g.n_pages;
+  const uint32_t log_p1w = g.log_p1 - g.lw, S1w = 1u << log_p1w;
+  if (n_grp != NL << log_p1w) return fail(c, SHK_ERR_BAD_ARG, "segment has %u regions, this context expects %u", n_grp, NL << log_p1w);
+  if (!c->acc_cur.p || c->acc_lp != g.lp || c->acc_rec32 || c->acc_region_lanes != NL)
+    return fail(c, SHK_ERR_INVARIANT, "accumulation regions not planned for 8-byte records");
+  const uint32_t S = 1u << g.log_sub, tiles_per_region = (cap1 + RS_TILE - 1) / RS_TILE;
+  const size_t lds_rs = (size_t)RS_TILE * 8 + (((size_t)RS_TILE + S) * 2 + 15) / 16 * 16 + (size_t)S * 12;
+  RescatterList ls{};  // (not a list: the owner bits of a k-mer's page are this share's, the rest is the page)
+  ls.owner_bits = g.lw;
+  ls.owner_id = c->tb.owner_id;
+  for (uint32_t lane = 0; lane < NL; ++lane) {
+    ScopedTimer t(c, SHK_K_PSCAN, /*chain=*/true);
+    hipLaunchKernelGGL(k_part_rescatter, dim3(S1w * tiles_per_region), dim3(RS_NT), lds_rs, c->stream, src_buf + (size_t)lane * S1w * cap1,
+                       src_cursor + (size_t)lane * S1w, cap1, tiles_per_region, g.lp, g.log_sub, 2 * c->cfg.k,
+                       (unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
+                       (uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap, lane, c->d_stats, sp, 0u, ls);
+  }
+  HIPC(c, hipGetLastError());
+  return SHK_OK;
+}
+// the record of an exchange segment at this geometry: 4 bytes (the 4-byte owner layout), 8 (the one above), 0: neither
+static uint32_t xchg_rec_bytes(const shk_ctx *c, const PartGeom &g) {
+  if (xl_feasible(c, g) && count_path(c, 0) == PATH_DEFER) return 4;
+  return xl64_feasible(c, g) ? 8u : 0u;
+}
+
 // ---- exchange rounds between owner shares (shk_xchg_*) ------------------------------------------------
 // The exchange layout depends only on (layout_bases, n_lanes, geometry), never on the batch at hand: every
 // rank of a round must come out with the same segment size.
@@ -1187,10 +1259,10 @@ static XlPlan xchg_plan(const shk_ctx *c, const PartGeom &g, uint64_t layout_bas
 }
 static int xchg_check(shk_ctx *c, const PartGeom &g) {
   if (!c->is_share()) return fail(c, SHK_ERR_STATE, "not an owner share (shk_config.n_owners = 0: say 1 for a share that is the whole key space)");
-  if (!xl_feasible(c, g) || count_path(c, 0) != PATH_DEFER)
+  if (!xchg_rec_bytes(c, g))
     return fail(c, SHK_ERR_STATE,
-                "the owner exchange needs 4-byte records (2k - %u ≤ 32) and ≤ 128 chunk lanes at this table geometry; "
-                "merge the tables at finalize instead", g.log_p1);
+                "the owner exchange needs 4-byte records (2k - %u ≤ 32) or k ≥ 18 on a two-level table, and ≤ 128 chunk lanes at this "
+                "table geometry; take the wide round or merge the tables at finalize instead", g.log_p1);
   return SHK_OK;
 }
 static int xchg_prepare_cursors(shk_ctx *c, uint32_t *n_words) {
@@ -1231,11 +1303,12 @@ static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub,
     c->xspill = nb;
     c->xspill_cap = ncap;
   }
+  const uint32_t rec_bytes = xchg_rec_bytes(c, g);
   if (kmers_ub) {
-    rc = xl_scatter(c, b, g, x, xspill_ref(c), /*keep_all=*/true, /*prezeroed=*/true);
+    rc = rec_bytes == 8 ? xl64_scatter(c, b, g, x, xspill_ref(c)) : xl_scatter(c, b, g, x, xspill_ref(c), /*keep_all=*/true, /*prezeroed=*/true);
     if (rc != SHK_OK) return rc;
   } else {  // an empty batch still takes part in the round: all-zero cursors
-    HIPC(c, c->xbuf.ensure((uint64_t)x.n_seg * x.seg_recs * 4));
+    HIPC(c, c->xbuf.ensure((uint64_t)x.n_seg * x.seg_recs * rec_bytes));
     HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, true)));
     HIPC(c, hipMemsetAsync(c->part_meta.p, 0, (size_t)x.n_seg * x.n_grp * 4, c->stream));
   }
@@ -1254,7 +1327,7 @@ static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub,
   xo->lay.log_p1 = g.log_p1;
   xo->lay.regions = x.n_grp;
   xo->lay.region_cap = x.cap1;
-  xo->lay.reserved = 0;
+  xo->lay.record_bytes = rec_bytes;
   xo->lay.segment_records = x.seg_recs;
   xo->n_foreign = c->h_stats->scratch[0];
   return SHK_OK;
@@ -2552,7 +2625,7 @@ int shk_xchg_wide_scatter_device(shk_ctx *c, const void *d_bases, const void *d_
 int shk_xchg_feasible(shk_ctx *c) {
   if (!c || c->group || !c->is_share()) return 0;
   const PartGeom g = part_geom(c);
-  return xl_feasible(c, g) && count_path(c, 0) == PATH_DEFER ? 1 : 0;
+  return xchg_rec_bytes(c, g) ? 1 : 0;
 }
 
 int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, const shk_xchg_layout *lay) {
@@ -2565,9 +2638,10 @@ int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, co
   if (rc != SHK_OK) return rc;
   if (lay->n_owners != c->n_owners || lay->n_lanes != c->n_lanes || lay->log_p1 != g.log_p1 ||
       lay->regions != c->n_lanes << (g.log_p1 - g.lw) || lay->region_cap == 0 || (lay->region_cap & ((1u << RB_LOG) - 1u)) ||
-      lay->segment_records != (uint64_t)lay->regions * lay->region_cap)
-    return fail(c, SHK_ERR_BAD_ARG, "exchange segment layout does not match this context (owners %u/%u, lanes %u/%u, level-1 bits %u/%u)",
-                lay->n_owners, c->n_owners, lay->n_lanes, c->n_lanes, lay->log_p1, g.log_p1);
+      lay->segment_records != (uint64_t)lay->regions * lay->region_cap || (lay->record_bytes ? lay->record_bytes : 4u) != xchg_rec_bytes(c, g))
+    return fail(c, SHK_ERR_BAD_ARG, "exchange segment layout does not match this context (owners %u/%u, lanes %u/%u, level-1 bits %u/%u, record bytes %u/%u)",
+                lay->n_owners, c->n_owners, lay->n_lanes, c->n_lanes, lay->log_p1, g.log_p1, lay->record_bytes ? lay->record_bytes : 4u, xchg_rec_bytes(c, g));
+  const bool rec8 = xchg_rec_bytes(c, g) == 8;
   if (!d_records || !d_cursors) return fail(c, SHK_ERR_BAD_ARG, "null segment");
   c->finalized = c->hist_ready = false;
   // a segment's regions are sized 1.25 × (1.5 ×) their expected fill: 4/5 of it bounds what it holds in practice
@@ -2592,7 +2666,8 @@ int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, co
     HIPC(c, c->spillA.ensure(spill_cap * 16));
   }
   SpillRef sp = spill_ref(c->spillA, spill_cap);
-  rc = xl_absorb(c, g, (const uint32_t *)d_records, (const unsigned int *)d_cursors, lay->region_cap, lay->regions, sp);
+  rc = rec8 ? xl64_absorb(c, g, (const uint64_t *)d_records, (const unsigned int *)d_cursors, lay->region_cap, lay->regions, sp)
+            : xl_absorb(c, g, (const uint32_t *)d_records, (const unsigned int *)d_cursors, lay->region_cap, lay->regions, sp);
   if (rc != SHK_OK) return rc;
   if (trace_on()) {  // (debugging aid: where did the segment's records go?)
     const size_t nreg = (size_t)c->n_lanes << c->tb.log_pages;

@@ -309,7 +309,7 @@ int group_round(shk_ctx *top, const uint8_t *bases, const uint64_t *offsets, con
     for (uint32_t s = 0; s < D; ++s) foreign |= g->n_foreign[s] > 0;
     // ---- phase 2: pull my segment out of every peer's buffer and absorb it
     const shk_xchg_layout L = g->lay[d];
-    const size_t seg_bytes = (size_t)L.segment_records * 4, cur_bytes = (size_t)L.regions * 4;
+    const size_t seg_bytes = (size_t)L.segment_records * (L.record_bytes == 8 ? 8 : 4), cur_bytes = (size_t)L.regions * 4;
     hipc(g->recv_rec[d].ensure(seg_bytes));
     hipc(g->recv_cur[d].ensure(cur_bytes));
     for (uint32_t i = 0; i < D && g->status[d] == SHK_OK; ++i) {

@@ -253,7 +253,7 @@ class OwnerCounter:
             tr[2] += t_out - t_ar
             tr[3] += 1
         self.n_rounds += 1
-        self.wire_bytes += (W - 1) * (lay.segment_records + lay.regions) * 4
+        self.wire_bytes += (W - 1) * (lay.segment_records * rec.element_size() + lay.regions * 4)
         return lay
 
     def _absorb_pending(self):

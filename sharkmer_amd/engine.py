@@ -56,7 +56,7 @@ class _Config(C.Structure):
 class XchgLayout(C.Structure):
     """shk_xchg_layout: how one exchange round's owner segments are laid out (include/shk.h)."""
     _fields_ = [("n_owners", C.c_uint32), ("n_lanes", C.c_uint32), ("log_p1", C.c_uint32),
-                ("regions", C.c_uint32), ("region_cap", C.c_uint32), ("reserved", C.c_uint32),
+                ("regions", C.c_uint32), ("region_cap", C.c_uint32), ("record_bytes", C.c_uint32),
                 ("segment_records", C.c_uint64)]
 
 
@@ -694,12 +694,13 @@ class KmerEngine:
         return torch.as_tensor(_Raw(ptr, (n,), typestr), device=device)
 
     def xchg_scatter_tensors(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int, layout_bases: int = 0):
-        """One round's level-1 scatter → (records int32[W·segment_records], cursors int32[W·regions],
+        """One round's level-1 scatter → (records int32 or int64 [W·segment_records], cursors int32[W·regions],
         layout, n_foreign_spilled) as zero-copy views of the context's exchange buffer."""
         rec, cur, lay, nf = self.xchg_scatter_device(d_bases, d_offsets, n_seqs, n_bases, layout_bases)
         W = lay.n_owners
-        return (self._raw_tensor(rec, W * lay.segment_records, "<i4", self._tdev), self._raw_tensor(cur, W * lay.regions, "<i4", self._tdev),
-                lay, nf)
+        # (a tensor element is one record: int32 for the 4-byte layout, int64 for the 8-byte one — layout.record_bytes)
+        return (self._raw_tensor(rec, W * lay.segment_records, "<i8" if lay.record_bytes == 8 else "<i4", self._tdev),
+                self._raw_tensor(cur, W * lay.regions, "<i4", self._tdev), lay, nf)
 
     def xchg_absorb_tensors(self, rec_t, cur_t, lay):
         assert rec_t.is_contiguous() and cur_t.is_contiguous()

@@ -181,15 +181,33 @@ def test_wide_round_receiver_through_the_paged_passes(orc, monkeypatch, W, k, ch
     the result is the oracle's either way."""
     monkeypatch.setenv("SHK_LEVEL1_LOG", "10")
     monkeypatch.setenv("SHK_INSERT_PAGED_MIN", "1")
+    monkeypatch.setenv("SHK_XL64", "0")   # (the wide round: without this, k > 21 takes the owner layout with 8-byte records)
     spec = sa.SynthSpec(genome_len=80_000, sub_per_64k=250, n_per_64k=50)
     bases, offsets = sa.synth_reads(spec, 0, 20_500)
     res = _exchange_run(orc, bases, offsets, k, chunks, 300, W, hint=4_200_000, timing=True)
     for r in res:
+        assert "pcount" in r[4], r[4]                                  # the wide round's count-by-owner pass ran
         assert "insert" not in r[4] or r[4]["insert"][1] <= 2, r[4]   # (a repair insert at most: the rounds went the paged way)
         assert "pages" in r[4], r[4]
     monkeypatch.setenv("SHK_INSERT_PAGED", "0")
     res = _exchange_run(orc, bases, offsets, k, chunks, 300, W, hint=4_200_000, timing=True)
     assert all("insert" in r[4] for r in res)
+
+
+@pytest.mark.parametrize("W,k,chunks", [(2, 31, 10), (4, 27, 3), (8, 23, 1), (1, 31, 2), (2, 22, 0), (2, 31, 32)])
+def test_owner_layout_with_8_byte_records(orc, monkeypatch, W, k, chunks):
+    """k > 21 between owner shares: the exchange rounds carry the same [owner][lane][super-page] segments as for k ≤ 21,
+    with the canonical k-mer as the record (shk_xchg_layout.record_bytes = 8: k_scatter64's owner layout at the sender,
+    k_part_rescatter + k_pages at the receiver) — no wide round, no insert by global atomics."""
+    monkeypatch.setenv("SHK_LEVEL1_LOG", "10")
+    spec = sa.SynthSpec(genome_len=80_000, sub_per_64k=250, n_per_64k=50)
+    bases, offsets = sa.synth_reads(spec, 0, 20_500)
+    with sa.KmerEngine(k, chunks, 300, capacity_hint=4_200_000, n_owners=W, owner_id=0) as eng:
+        assert eng.xchg_feasible()
+    res = _exchange_run(orc, bases, offsets, k, chunks, 300, W, hint=4_200_000, timing=True)
+    for r in res:
+        assert "pcount" not in r[4] and "scatter" in r[4] and "pscan" in r[4] and "pages" in r[4], r[4]
+        assert "insert" not in r[4] or r[4]["insert"][1] <= 2, r[4]
 
 
 def test_a_list_of_k_mers_with_lanes_either_way(orc, monkeypatch):
@@ -251,7 +269,13 @@ def test_exchange_invalid_byte_fails_every_rank(monkeypatch, k):
 
 
 def test_exchange_feasibility_is_a_function_of_the_configuration(monkeypatch):
-    for k, want in ((21, True), (22, False), (31, False), (15, True)):
+    for k, want in ((21, True), (22, True), (31, True), (15, True)):   # (k > 21: the 8-byte owner layout, round 4)
+        with sa.KmerEngine(k, 3, 100, capacity_hint=4_200_000, n_owners=4, owner_id=1) as eng:
+            assert eng.xchg_feasible() == want, k
+    with sa.KmerEngine(31, 40, 100, capacity_hint=4_200_000, n_owners=4, owner_id=1) as eng:   # more than 32 lanes at k > 21: the wide round
+        assert not eng.xchg_feasible()
+    monkeypatch.setenv("SHK_XL64", "0")
+    for k, want in ((21, True), (22, False), (31, False)):
         with sa.KmerEngine(k, 3, 100, capacity_hint=4_200_000, n_owners=4, owner_id=1) as eng:
             assert eng.xchg_feasible() == want, k
     with sa.KmerEngine(21, 3, 100) as eng:   # not a share at all

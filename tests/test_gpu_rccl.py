@@ -32,12 +32,18 @@ def rccl_world_of_one():
 @pytest.mark.parametrize("k,chunks,lvl1,hint,round_reads,max_msg", [(21, 1, 10, 4_200_000, 5_000, 0), (21, 10, 10, 4_200_000, 2_300, 0),
                                                                     (17, 3, 6, 600_000, 1_000, 0), (19, 0, 8, 1_000_000, 7_777, 0),
                                                                     (21, 3, 10, 4_200_000, 5_000, 65536),
-                                                                    (31, 3, 10, 4_200_000, 5_000, 0), (27, 10, 10, 4_200_000, 2_300, 65536)])
+                                                                    (31, 3, 10, 4_200_000, 5_000, 0), (27, 10, 10, 4_200_000, 2_300, 65536),
+                                                                    (31, 3, 10, 4_200_000, 5_000, -1), (27, 10, 10, 4_200_000, 2_300, -65536)])
 def test_owner_counter_over_rccl_world_of_one(orc, rccl_world_of_one, monkeypatch, k, chunks, lvl1, hint, round_reads, max_msg):
     """max_msg: the message limit pinned below a segment's size — the segment then never goes through the communicator
     in one piece (RCCL was measured to deliver only half of a message above 2^30 bytes, tools/rccl_a2a_probe.py), and the
-    rank's own segment is absorbed where the scatter left it.  k > 21: the wide round (whole k-mers, unequal parts)."""
+    rank's own segment is absorbed where the scatter left it.  k > 21: the same segments with 8-byte records (round 4);
+    max_msg < 0: the wide round instead (SHK_XL64=0: whole k-mers, unequal parts), |max_msg| > 1 the limit."""
     monkeypatch.setenv("SHK_LEVEL1_LOG", str(lvl1))
+    wide = max_msg < 0
+    if wide:
+        monkeypatch.setenv("SHK_XL64", "0")
+        max_msg = -max_msg if max_msg < -1 else 0
     if max_msg:
         import sharkmer_amd.dist as sd
         monkeypatch.setattr(sd, "MAX_MESSAGE_BYTES", max_msg)
@@ -55,9 +61,9 @@ def test_owner_counter_over_rccl_world_of_one(orc, rccl_world_of_one, monkeypatc
             offs = torch.from_numpy((offsets[first:first + n + 1] - offsets[first]).astype(np.int64)).cuda()
             keep.append(offs)
             lay = oc.round((d_bases[o0:o1].data_ptr(), offs.data_ptr(), n, o1 - o0, first))
-            if k <= 21:
-                assert lay.n_owners == 1 and lay.n_lanes == max(chunks, 1)
-            else:   # the wide round (k-mers that do not fit 4-byte records): no layout to report
+            if not wide:
+                assert lay.n_owners == 1 and lay.n_lanes == max(chunks, 1) and (lay.record_bytes or 4) == (4 if k <= 21 else 8)
+            else:   # the wide round: no layout to report
                 assert lay is None and not eng.xchg_feasible()
         oc.round(None)   # a rank that has run out of reads still takes part
         hist = oc.finalize_histograms()
