@@ -350,20 +350,24 @@ def extras(sa, torch, dev):
                 "fixed_cost_ms": round(res["merged"] - res["plain"], 4)}
     guarded("dist_fixed_cost", dist_fixed_cost)
 
-    # the WIDE exchange round (k > 21 between owner shares: whole k-mers cross the links) in a world of one: a share of
-    # configs[2]'s shape (k = 31, 300 Mb genome) through OwnerCounter's rounds — the receiver counts what arrives through
-    # the partition + page passes (round 4; k_insert's global atomics before) — beside the same reads through the plain ingest
-    def wide_round():
+    # k > 21 between owner shares, a world of one: a share of configs[2]'s shape (k = 31, 300 Mb genome) through
+    # OwnerCounter's rounds — the owner layout with 8-byte records (round 4: the same segment exchange as for k ≤ 21), and
+    # the WIDE round it replaces for ≤ 32 chunk lanes (SHK_XL64=0: whole k-mers grouped by owner, 12 B each on the links,
+    # counted at the receiver through the partition + page passes since round 4, by global atomics before) — beside the
+    # same reads through the plain ingest
+    def exchange_k31():
         import subprocess
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "owner_w1_probe.py"), "12500000", "300000000", "1", "31"],
-                           env={**os.environ, "MASTER_PORT": "29547"}, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True)
-        rows = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
-        best = {m: max((x for x in rows if x["mode"] == m), key=lambda x: x["gbases_per_s"]) for m in ("share_w1", "plain")}
-        return {"workload": "12.5 M reads x 150 bp, k=31, 300 Mb genome (2^30-slot table): OwnerCounter's wide rounds over RCCL, a world of one (n_owners = 1), "
-                            "against the plain ingest of the same reads; best of 2 passes each",
-                "wide_rounds": {"Gbases_per_s": best["share_w1"]["gbases_per_s"], "kernels_ms": {k_: v[0] for k_, v in best["share_w1"]["kernel_ms"].items()}},
-                "plain_ingest": {"Gbases_per_s": best["plain"]["gbases_per_s"], "kernels_ms": {k_: v[0] for k_, v in best["plain"]["kernel_ms"].items()}}}
-    guarded("wide_round_k31", wide_round)
+        res = {"workload": "12.5 M reads x 150 bp, k=31, 300 Mb genome (2^30-slot table): OwnerCounter's rounds over RCCL, a world of one (n_owners = 1), "
+                           "against the plain ingest of the same reads; best of 2 passes each"}
+        for name, env in (("owner_layout_8_byte_records", {}), ("wide_round", {"SHK_XL64": "0"})):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "owner_w1_probe.py"), "12500000", "300000000", "1", "31"],
+                               env={**os.environ, "MASTER_PORT": "29547", **env}, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            rows = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+            best = {m: max((x for x in rows if x["mode"] == m), key=lambda x: x["gbases_per_s"]) for m in ("share_w1", "plain")}
+            res[name] = {"Gbases_per_s": best["share_w1"]["gbases_per_s"], "kernels_ms": {k_: v[0] for k_, v in best["share_w1"]["kernel_ms"].items()}}
+            res["plain_ingest"] = {"Gbases_per_s": best["plain"]["gbases_per_s"], "kernels_ms": {k_: v[0] for k_, v in best["plain"]["kernel_ms"].items()}}
+        return res
+    guarded("exchange_k31", exchange_k31)
     return out
 
 
