@@ -1390,6 +1390,9 @@ static bool fused_hist_wanted(const shk_ctx *c) {
   // (one lane on a large table: the scan's 4 B per slot cost less than the pass's extra work — measured on a 30 Mb
   // genome, 8192 pages: pages + 0.06 ms for a scan of 0.077; from two lanes on, and on small tables, the pass wins)
   if (c->n_lanes == 1 && c->tb.log_pages > 11 && env_int("SHK_FUSED_HIST", 1) != 2) return false;
+  // (the rows: 2 KiB per page and column — many lanes on a large table would be tens of GB: the scan then)
+  const uint64_t rows_bytes = ((uint64_t)1 << c->tb.log_pages) * std::max<uint32_t>(c->cfg.chunks, 1) * FH_BINS * 4;
+  if (rows_bytes > (4ull << 30)) return false;
   return !c->own_set && !c->zero_count_keys && !c->fused_off && env_int("SHK_FUSED_HIST", 1) != 0;
 }
 static int fused_hist_prepare(shk_ctx *c, uint32_t n_pages, FusedHist *fh) {
