@@ -3359,7 +3359,9 @@ struct FusedHist {
   uint32_t n_cols;
   uint32_t pad;
 };
-template <bool FRESH, bool HIST = false>
+// (HIST = 2: the launch covers ONE chunk lane — no running sums to carry across a lane loop: the fold's sixteen
+// registers and what they cost the record loop's code are not there)
+template <bool FRESH, int HIST = 0>
 __global__ void __launch_bounds__(PG_WG, 4) k_pages32(TableRef tb, uint32_t lane_lo, uint32_t lane_hi,
                                                       uint32_t lane_stride, uint32_t n_regions_,
                                                       const unsigned int *__restrict__ cursor, uint32_t cap_p,
@@ -3482,10 +3484,11 @@ __global__ void __launch_bounds__(PG_WG, 4) k_pages32(TableRef tb, uint32_t lane
   };
   // HIST: the running (clamped) sums of this thread's sixteen slots over the lanes so far, and its share of the totals
   constexpr int WBH = PAGE_SLOTS / 4 / PG_WG;
-  uint32_t cum[HIST ? WBH * 4 : 1];
+  uint32_t cum[HIST == 1 ? WBH * 4 : 1];
+  uint32_t one_unique = 0, one_sat = 0;  // HIST = 2: the totals as the (only) lane's counts go by
   unsigned long long fh_lane = 0;
   uint32_t n_high = 0;  // sums this thread sent past the LDS bins (same-line global adds: a job full of them should leave the histogram to k_histo — the host looks)
-  if (HIST) {
+  if (HIST == 1) {
 #pragma unroll
     for (int i = 0; i < WBH * 4; ++i) cum[i] = 0;
   }
@@ -3511,8 +3514,15 @@ __global__ void __launch_bounds__(PG_WG, 4) k_pages32(TableRef tb, uint32_t lane
         const uint32_t s1 = lsum + v[q];
         lcarry += s1 < lsum;
         lsum = s1;
-        const uint32_t cc = sat_add_u32(cum[u * 4 + q], v[q]);
-        cum[u * 4 + q] = cc;
+        uint32_t cc;
+        if (HIST == 1) {
+          cc = sat_add_u32(cum[u * 4 + q], v[q]);
+          cum[u * 4 + q] = cc;
+        } else {
+          cc = v[q];
+          one_unique += cc != 0;
+          one_sat |= cc == 0xFFFFFFFFu;
+        }
         const uint32_t bin = cc < top32 ? cc : top32;
         if (col && cc) {
           if (bin < FH_BINS) atomicAdd(&mq[bin], 1u);
@@ -3696,11 +3706,17 @@ __global__ void __launch_bounds__(PG_WG, 4) k_pages32(TableRef tb, uint32_t lane
   if (nnew && threadIdx.x == 0) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
   if (HIST) {  // the page's share of the totals (k_histo's HistoTotals), one row of ptot
     unsigned long long t4[4] = {0, 0, fh_lane, 0};
+    if (HIST == 1) {
 #pragma unroll
-    for (int i = 0; i < WBH * 4; ++i) {
-      t4[0] += cum[i] != 0;
-      t4[1] += cum[i];
-      t4[3] += cum[i] == 0xFFFFFFFFu;
+      for (int i = 0; i < WBH * 4; ++i) {
+        t4[0] += cum[i] != 0;
+        t4[1] += cum[i];
+        t4[3] += cum[i] == 0xFFFFFFFFu;
+      }
+    } else {  // (one lane: a slot's sum is its count)
+      t4[0] = one_unique;
+      t4[1] = fh_lane;
+      t4[3] = one_sat;
     }
     t4[3] += (unsigned long long)n_high << 32;  // word 3: low half = saturated sums (a count here, a flag to the host), high half = adds past the LDS bins
     unsigned long long *red = reinterpret_cast<unsigned long long *>(dl);  // [wave][4]

@@ -1548,19 +1548,23 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
       }
       ScopedTimer t(c, SHK_K_PAGES, /*chain=*/true);
       if (rec32 && fresh) {
-        if (fuse)
-          hipLaunchKernelGGL((k_pages32<true, true>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
+        if (fuse && l_hi - l_lo == 1)
+          hipLaunchKernelGGL((k_pages32<true, 2>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
+                             all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
+                             (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp, 0u, fh);
+        else if (fuse)
+          hipLaunchKernelGGL((k_pages32<true, 1>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
                              all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
                              (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp, 0u, fh);
         else
-          hipLaunchKernelGGL((k_pages32<true, false>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
+          hipLaunchKernelGGL((k_pages32<true, 0>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
                              all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
                              (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp, 0u, fh);
         c->tb_stale = false;
         c->fused_valid = fuse;
         c->fused_pages = n_pages;
       } else if (rec32)
-        hipLaunchKernelGGL((k_pages32<false, false>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
+        hipLaunchKernelGGL((k_pages32<false, 0>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, l_lo, l_hi,
                            all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
                            (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
       else
@@ -1780,16 +1784,20 @@ static int flush_acc(shk_ctx *c) {
     const uint32_t gp = (uint32_t)std::min<uint64_t>(ppg, n_pages - p0);
     if (c->acc_rec32) {
       ScopedTimer t(c, SHK_K_PAGES);
-      if (fresh && fuse)
-        hipLaunchKernelGGL((k_pages32<true, true>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+      if (fresh && fuse && NL == 1)
+        hipLaunchKernelGGL((k_pages32<true, 2>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, 0u,
+                           NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
+                           c->d_stats, sp, (uint32_t)p0, fh);
+      else if (fresh && fuse)
+        hipLaunchKernelGGL((k_pages32<true, 1>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
                            NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
                            c->d_stats, sp, (uint32_t)p0, fh);
       else if (fresh)
-        hipLaunchKernelGGL((k_pages32<true, false>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+        hipLaunchKernelGGL((k_pages32<true, 0>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
                            NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
                            c->d_stats, sp, (uint32_t)p0, fh);
       else
-        hipLaunchKernelGGL((k_pages32<false, false>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
+        hipLaunchKernelGGL((k_pages32<false, 0>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
                            NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
                            c->d_stats, sp, (uint32_t)p0);
     } else {  // 8-byte records: one page pass per lane over that lane's regions
