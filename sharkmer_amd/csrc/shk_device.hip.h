@@ -2507,8 +2507,13 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
   const uint32_t log_p1w = OWN ? log_parts - own.log_w : 0u;  // super-page bits inside an owner's share
   const uint32_t p1w_mask = (1u << log_p1w) - 1u;
   const uint32_t n_grp = n_region_lanes << log_p1w;           // regions of one owner segment
-  // region of partition i for a tile of chunk lane ln, among ALL regions of the launch ([owner][lane][super-page])
-  auto own_region = [&](uint32_t i, uint32_t ln) -> uint32_t { return (i >> log_p1w) * n_grp + ((ln << log_p1w) | (i & p1w_mask)); };
+  // region of partition i for a tile of chunk lane ln, among ALL regions of the launch ([owner][lane][super-page]);
+  // own.keep = an owner id: only that owner's records are kept (dropped in the walk) and there is ONE segment
+  // (own.seg_recs = 0) — a share's own ingest; own.keep = ~0: every owner's records, a segment each (the exchange)
+  const uint32_t keep_mask = own.keep == 0xFFFFFFFFu ? 0u : 0xFFFFFFFFu;
+  auto own_region = [&](uint32_t i, uint32_t ln) -> uint32_t {
+    return (own.seg_recs ? i >> log_p1w : 0u) * n_grp + ((ln << log_p1w) | (i & p1w_mask));
+  };
   extern __shared__ __attribute__((aligned(16))) uint32_t sh[];
   __shared__ uint32_t wsum[NT / 64];
   __shared__ uint32_t red[NT / 64];
@@ -2635,6 +2640,7 @@ __global__ void __launch_bounds__(NT, 4) k_scatter64(
           const uint32_t page = yhi >> psh;
           uint32_t em;
           asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(em) : "v"(okw), "n"(q * 8 + r));  // all ones where a k-mer ends here
+          if (OWN) em &= 0u - (uint32_t)((((page >> log_p1w) ^ own.keep) & keep_mask) == 0u);  // a foreign owner's record: dropped
           asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(pcs[r]) : "v"(em), "v"(page), "v"(spare_pc));
           rks[r] = atomicAdd(&cnt[pcs[r]], 1u);  // rank < 2^14
         }

@@ -804,6 +804,9 @@ static bool xl_feasible(const shk_ctx *c, const PartGeom &g) {
   return g.two_level && use_scatter32(c, g) && (1u << g.log_sub) <= (uint32_t)MAX_PARTS && c->n_lanes <= shk::SC32_MAX_LANES &&
          g.lpg <= MAX_LOG_PAGES;
 }
+static bool xl64_feasible(const shk_ctx *c, const PartGeom &g);
+// … and the same layout with 8-byte records for a share whose records do not fit a word (k > 21): its own ingest
+static bool xl64_route(const shk_ctx *c, const PartGeom &g) { return c->is_share() && !xl_feasible(c, g) && xl64_feasible(c, g); }
 static bool xl_route(const shk_ctx *c, const PartGeom &g, bool multi, bool defer) {
   if (!xl_feasible(c, g)) return false;
   if (c->is_share()) return true;
@@ -834,8 +837,10 @@ static CountPath count_path(const shk_ctx *c, uint64_t sub_kmers_ub, bool multi 
     const PartGeom g2 = part_geom(c);
     if (g2.two_level && xl_feasible(c, g2)) return PATH_DEFER;
   }
-  if (c->is_share())  // an owner share: the owner layout + deferred page passes, or global atomics (both drop foreign k-mers)
-    return xl_feasible(c, part_geom(c)) && env_int("SHK_DEFER", 1) != 0 ? PATH_DEFER : PATH_DIRECT;
+  if (c->is_share()) {  // an owner share: an owner layout (4- or 8-byte records) + deferred page passes, or global atomics (all drop foreign k-mers)
+    const PartGeom gs = part_geom(c);
+    return (xl_feasible(c, gs) || xl64_feasible(c, gs)) && env_int("SHK_DEFER", 1) != 0 ? PATH_DEFER : PATH_DIRECT;
+  }
   if ((c->cfg.flags & SHK_FLAG_FORCE_PAGED) || paged_pays(c, sub_kmers_ub)) return PATH_PAGED;
   const PartGeom g = part_geom(c);
   if (env_int("SHK_DEFER", 1) == 0) return PATH_DIRECT;
@@ -970,7 +975,7 @@ static size_t cursor_buf_bytes(const shk_ctx *c, const PartGeom &g, bool multi) 
 static int prepare_cursors(shk_ctx *c, bool multi, bool defer, uint32_t *n_words) {
   const PartGeom g = part_geom(c);
   HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, multi)));
-  if (defer && xl_route(c, g, multi, defer)) {  // one segment's cursors: [lane][super-page of the share]
+  if (defer && (xl_route(c, g, multi, defer) || xl64_route(c, g))) {  // one segment's cursors: [lane][super-page of the share]
     *n_words = c->n_lanes << (g.log_p1 - g.lw);
     return SHK_OK;
   }
@@ -1182,7 +1187,7 @@ static bool xl64_feasible(const shk_ctx *c, const PartGeom &g) {
   return g.two_level && use_scatter64(c, g) && g.log_sub <= 10 && c->n_lanes <= 32 && g.lpg <= MAX_LOG_PAGES &&
          env_int("SHK_DEFER", 1) != 0 && env_int("SHK_XL64", 1) != 0;
 }
-static int xl64_scatter(shk_ctx *c, const BatchRef &b, const PartGeom &g, const XlPlan &x, SpillRef sp) {
+static int xl64_scatter(shk_ctx *c, const BatchRef &b, const PartGeom &g, const XlPlan &x, SpillRef sp, bool keep_all = true, bool prezeroed = true) {
   const uint32_t NL = c->n_lanes;
   const uint64_t total = (uint64_t)x.n_seg * x.seg_recs;
   if (total * 8 > 0xFFFFFFFFull)
@@ -1192,10 +1197,11 @@ static int xl64_scatter(shk_ctx *c, const BatchRef &b, const PartGeom &g, const 
   if (c->part_meta.cap < (size_t)x.n_seg * x.n_grp * 4) return fail(c, SHK_ERR_INVARIANT, "cursor buffer too small for the owner layout");
   int rc = scatter64_attrs(c, b, sp);
   if (rc != SHK_OK) return rc;
+  if (!prezeroed) HIPC(c, hipMemsetAsync(cursor, 0, (size_t)x.n_seg * x.n_grp * 4, c->stream));
   OwnerCfg own{};
   own.log_w = g.lw;
-  own.keep = 0xFFFFFFFFu;
-  own.seg_recs = (uint32_t)x.seg_recs;
+  own.keep = keep_all ? 0xFFFFFFFFu : c->owner_id;
+  own.seg_recs = keep_all ? (uint32_t)x.seg_recs : 0u;
   const uint32_t G = std::min<uint32_t>(grid_for(b.tile_count, 1, (uint32_t)env_int("SHK_PART_G", 512)), c->n_cus_scatter);
   const size_t lds = scatter64_lds(g.P1);
   // a batch inside one 1000-read block is one lane's; a tile list (k_build_tiles) may hold every lane's tiles
@@ -1229,6 +1235,13 @@ static int xl64_absorb(shk_ctx *c, const PartGeom &g, const uint64_t *src_buf, c
   }
   HIPC(c, hipGetLastError());
   return SHK_OK;
+}
+// One deferred counting launch of a share's OWN ingest at k > 21: scatter (own records only, one segment), then absorb.
+static int xl64_count(shk_ctx *c, const BatchRef &b, const PartGeom &g, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed) {
+  const XlPlan x = xl_plan(c, g, sub_kmers_ub, /*keep_all=*/false);
+  int rc = xl64_scatter(c, b, g, x, sp, /*keep_all=*/false, prezeroed);
+  if (rc != SHK_OK) return rc;
+  return xl64_absorb(c, g, (const uint64_t *)c->xbuf.p, (const unsigned int *)c->part_meta.p, x.cap1, x.n_grp, sp);
 }
 // the record of an exchange segment at this geometry: 4 bytes (the 4-byte owner layout), 8 (the one above), 0: neither
 static uint32_t xchg_rec_bytes(const shk_ctx *c, const PartGeom &g) {
@@ -1407,9 +1420,11 @@ static int fused_hist_prepare(shk_ctx *c, uint32_t n_pages, FusedHist *fh) {
   return SHK_OK;
 }
 
+static int xl64_count(shk_ctx *c, const BatchRef &b, const PartGeom &g, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed);
 static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, SpillRef sp, bool prezeroed, bool defer) {
   const PartGeom pg = part_geom(c);
   if (xl_route(c, pg, b.tiles != nullptr, defer)) return xl_count(c, b, pg, sub_kmers_ub, sp, prezeroed);
+  if (defer && xl64_route(c, pg)) return xl64_count(c, b, pg, sub_kmers_ub, sp, prezeroed);
   if (pg.lw) return fail(c, SHK_ERR_INVARIANT, "an owner share has no paged path besides the owner layout");
   const uint32_t lp = pg.lp, n_pages = pg.n_pages, log_p1 = pg.log_p1, log_sub = pg.log_sub, P1 = pg.P1;
   const bool two_level = pg.two_level;

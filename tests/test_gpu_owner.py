@@ -36,7 +36,7 @@ def _owner_of(keys, k, W):
     return (y >> np.uint64(bits - lw)).astype(np.int64)
 
 
-def _shares_against_oracle(orc, bases, offsets, k, chunks, histo_max, W, flags=0, hint=0, splits=None):
+def _shares_against_oracle(orc, bases, offsets, k, chunks, histo_max, W, flags=0, hint=0, splits=None, timings=None):
     ref = orc.run_batch(bases, offsets, k, chunks, histo_max)
     rk, rc = ref.merged().export()
     hist_sum = None
@@ -51,6 +51,8 @@ def _shares_against_oracle(orc, bases, offsets, k, chunks, histo_max, W, flags=0
             eng.finalize()
             h = eng.histograms()
             c = eng.counters()
+            if timings is not None:
+                timings.append(eng.timings())
             gk, gc = eng.export_table()
             # point lookups: owned keys give their count, foreign keys 0
             probe = rk[:: max(len(rk) // 300, 1)]
@@ -84,6 +86,18 @@ def test_owner_shares_drop_mode(orc, k, chunks, flags, hint, W):
     spec = sa.SynthSpec(genome_len=60_000, sub_per_64k=300, n_per_64k=60)
     bases, offsets = sa.synth_reads(spec, 0, 12_500)
     _shares_against_oracle(orc, bases, offsets, k, chunks, 200, W, flags=flags, hint=hint, splits=[3_100, 9_000])
+
+
+@pytest.mark.parametrize("W,k,chunks", [(1, 31, 1), (2, 31, 3), (8, 27, 10), (4, 23, 0)])
+def test_a_share_s_own_reads_at_k_over_21_take_the_8_byte_owner_layout(orc, W, k, chunks):
+    """Drop mode at k > 21: the share's own ingest goes through k_scatter64's owner layout (its own records only, one
+    segment), the level-2 pass and the page passes — no global atomics (they were the only way until round 4)."""
+    spec = sa.SynthSpec(genome_len=60_000, sub_per_64k=300, n_per_64k=60)
+    bases, offsets = sa.synth_reads(spec, 0, 12_500)
+    tims = []
+    _shares_against_oracle(orc, bases, offsets, k, chunks, 200, W, flags=sa.FLAG_TIMING, hint=4_200_000, splits=[3_100, 9_000], timings=tims)
+    for t in tims:
+        assert "direct" not in t and "scatter" in t and "pscan" in t and "pages" in t, t
 
 
 @pytest.mark.parametrize("W,k,chunks,lvl1,hint,budget", [(2, 21, 10, 10, 4_200_000, 0), (4, 21, 3, 10, 2_000_000, 600_000),
