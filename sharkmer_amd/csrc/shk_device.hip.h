@@ -3124,6 +3124,12 @@ constexpr uint32_t PG_DRAIN_EVERY = SHK_PG_DRAIN_EVERY; // k_pages: steps (of 4 
 // since the last one: a page's slice of miss_buf is capped at that, however large its region is.
 constexpr uint32_t MISS_WAVE_MAX = PG_DRAIN_EVERY * 4 * 64;
 constexpr uint32_t MISS_PAGE_MAX = (PG_WG / 64) * MISS_WAVE_MAX;
+// FK / FV: the table holds nothing yet and its memory has not been cleared (the first page pass after a reset, over
+// every page and lane: k_pages32's FRESH, for 8-byte records) — FK: the page's keys are not read (they start EMPTY)
+// and are written out whole at the end; FV: this lane's counts of the page are zeroed here, first, instead of by a
+// fill of the whole table that the pass would then read back.  Lane 0's launch of the pass is <true, true>, the other
+// lanes' <false, true>.
+template <bool FK, bool FV>
 __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
                                                  const unsigned int *__restrict__ cursor, uint32_t cap_p,
                                                  const uint64_t *__restrict__ part_buf,
@@ -3134,13 +3140,26 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
   if (stats->bad != ~0ull) return;
   const uint32_t page = blockIdx.x + page0;  // (page0: a launch over a range of pages — grouped flush, see flush_acc)
   const uint32_t filled = cursor[page] < cap_p ? cursor[page] : cap_p;  // beyond cap_p: spilled
-  if (filled == 0) return;  // nothing for this page: leave it untouched in HBM
   uint64_t *gk = tb.keys + ((uint64_t)page << PAGE_LOG);
   uint32_t *gv = tb.vals + (uint64_t)lane * tb.cap + ((uint64_t)page << PAGE_LOG);
+  if (FV) {
+    for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 4; j += PG_WG) reinterpret_cast<uint4 *>(gv)[j] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (filled == 0) {  // nothing for this page: leave it untouched in HBM — or, a fresh table's, empty
+    if (FK)
+      for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 2; j += PG_WG) {
+        ulonglong2 e;
+        e.x = e.y = EMPTY;
+        reinterpret_cast<ulonglong2 *>(gk)[j] = e;
+      }
+    return;
+  }
   // page keys → LDS (16-B vectors), counting occupied slots on the way
   uint32_t my_occ = 0;
   for (uint32_t i = threadIdx.x; i < PAGE_SLOTS / 2; i += PG_WG) {
-    ulonglong2 v = reinterpret_cast<const ulonglong2 *>(gk)[i];
+    ulonglong2 v;
+    if (FK) v.x = v.y = EMPTY;
+    else v = reinterpret_cast<const ulonglong2 *>(gk)[i];
     reinterpret_cast<ulonglong2 *>(keys)[i] = v;
     my_occ += (v.x != EMPTY) + (v.y != EMPTY);
   }
@@ -3300,10 +3319,10 @@ __global__ void __launch_bounds__(PG_WG) k_pages(TableRef tb, uint32_t lane,
   }
   __syncthreads();
   const uint32_t nnew = pg_wg_sum(n_new, dl);
-  if (nnew) {
+  if (nnew || FK) {
     for (uint32_t j = threadIdx.x; j < PAGE_SLOTS / 2; j += PG_WG)
       reinterpret_cast<ulonglong2 *>(gk)[j] = reinterpret_cast<const ulonglong2 *>(keys)[j];
-    if (threadIdx.x == 0) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
+    if (threadIdx.x == 0 && nnew) atomicAdd(&stats->n_distinct, (unsigned long long)nnew);
   }
 }
 

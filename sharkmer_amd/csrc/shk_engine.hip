@@ -1583,7 +1583,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
                            all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
                            (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
       else
-        hipLaunchKernelGGL(k_pages, dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
+        hipLaunchKernelGGL((k_pages<false, false>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
                            (const unsigned int *)cursor_pg, cap_pg, (const uint64_t *)buf_pg.p,
                            (uint64_t *)c->part2.p, c->d_stats, sp);
     }
@@ -1767,7 +1767,11 @@ static int flush_acc(shk_ctx *c) {
   if (c->spillA.cap < spill_cap * 16) return fail(c, SHK_ERR_INVARIANT, "spill list of the accumulation window missing");
   SpillRef sp = spill_ref(c->spillA, spill_cap);
   const bool fresh = c->tb_stale && c->acc_rec32 && NL == c->n_lanes && !env_int("SHK_NO_FRESH", 0);
-  if (!fresh) {
+  // (8-byte records: k_pages<FK, FV> — the pass zeroes each lane's counts page by page and writes the keys whole,
+  // instead of a fill of the table beforehand that it would then read back: 26 GB of configs[2]'s traffic)
+  const bool fresh8 = c->tb_stale && !c->acc_rec32 && NL == c->n_lanes && !env_int("SHK_NO_FRESH", 0) && env_int("SHK_FRESH8", 1) != 0;
+  if (fresh8) fused_drop(c);
+  if (!fresh && !fresh8) {
     int rcf = tb_fresh(c);
     if (rcf != SHK_OK) return rcf;
   }
@@ -1818,10 +1822,14 @@ static int flush_acc(shk_ctx *c) {
     } else {  // 8-byte records: one page pass per lane over that lane's regions
       for (uint32_t lane = 0; lane < NL; ++lane) {
         ScopedTimer t(c, SHK_K_PAGES);
-        hipLaunchKernelGGL(k_pages, dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, lane,
-                           (const unsigned int *)c->acc_cur.p + (size_t)lane * n_pages, c->acc_cap,
-                           (const uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap,
-                           (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
+        const unsigned int *cur_l = (const unsigned int *)c->acc_cur.p + (size_t)lane * n_pages;
+        const uint64_t *buf_l = (const uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap;
+        if (fresh8 && lane == 0)  // the table's first page pass: nothing is read, keys and counts are written whole
+          hipLaunchKernelGGL((k_pages<true, true>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, lane, cur_l, c->acc_cap, buf_l, (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
+        else if (fresh8)
+          hipLaunchKernelGGL((k_pages<false, true>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, lane, cur_l, c->acc_cap, buf_l, (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
+        else
+          hipLaunchKernelGGL((k_pages<false, false>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, lane, cur_l, c->acc_cap, buf_l, (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
         if (grouped) {  // (a lane's launch over the group is bounded by gp · acc_cap on its own)
           int rc = read_stats(c);
           if (rc == SHK_OK) rc = hold_spills(c, spill_cap);
@@ -1835,7 +1843,7 @@ static int flush_acc(shk_ctx *c) {
       if (rc != SHK_OK) return rc;
     }
   }
-  if (c->acc_rec32) c->tb_stale = false;
+  if (c->acc_rec32 || fresh8) c->tb_stale = false;
   if (fuse) c->fused_valid = true, c->fused_pages = n_pages;
   HIPC(c, hipMemsetAsync(c->acc_cur.p, 0, (size_t)NL * n_pages * 4, c->stream));
   c->acc_active = false;
