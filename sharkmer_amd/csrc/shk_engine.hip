@@ -915,15 +915,21 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
   if (!(c->acc_buf.p && c->acc_lp == c->tb.log_pages && c->acc_rec32 == rec32 && c->acc_region_lanes == NL &&
         kmers_ub <= c->acc_budget_max && acc_lane_add(c, kmers_ub, lane_one, lane_add_exact) <= c->acc_lane_budget)) {
     // lanes each get a full-size region set; 8-byte records also need k_pages' miss queues
-    const uint64_t rec_bytes = rec32 ? (NL > 1 ? 8ull : 5ull) + 1 : (NL > 1 ? 15ull : 10ull) + 8 + 1;  // regions are 1.25 × the window (× 1.5 over several lanes: each lane's share + 50 %)
-    const uint64_t mem_records = (uint64_t)(free_b / 3 * 2 + c->acc_buf.cap) / rec_bytes;
+    // regions are 1.25 × the window (× 1.5 over several lanes: each lane's share + 50 %); k_pages' miss queues are a
+    // fixed MISS_PAGE_MAX entries per page once a region is longer than that (they were booked at 8 B per RECORD, which
+    // kept configs[2]'s 12 G records from ever being one window)
+    const uint64_t rec_bytes = rec32 ? (NL > 1 ? 8ull : 5ull) + 1 : (NL > 1 ? 15ull : 10ull) + 1;
+    const uint64_t miss_bytes = rec32 ? 0ull : n_pages * (uint64_t)MISS_PAGE_MAX * 8ull;
+    const uint64_t mem_avail = (uint64_t)(free_b / 3 * 2 + c->acc_buf.cap);
+    const uint64_t mem_records = (mem_avail > miss_bytes ? mem_avail - miss_bytes : 0ull) / rec_bytes;
     // up to eight tables' worth of records while that is a few GiB, two and a half tables' worth beyond — and eight
     // again when a capacity hint says that no window will have to end for the table's sake: every page pass streams
     // the whole table (24 GB in and out on configs[2]'s 2^30 slots), so the job should make as few as memory allows
-    // (configs[2]: 12 G records in two passes instead of five)
+    // (configs[2]: 12 G records in two passes instead of five with eight tables' worth — round 3 — and in ONE with sixteen,
+    // memory allowing — round 4: page passes 31.2 → 28.5 ms, the job 117.5 → 122 Gbases/s)
     const uint64_t few_gib = (8ull << 30) / (rec32 ? 4 : 8) / NL;
     const bool hinted = c->cfg.table_capacity_hint && (double)c->cfg.table_capacity_hint <= 0.8 * (double)c->tb.cap;
-    uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), hinted && env_int("SHK_WIDE_WINDOW", 1) ? c->tb.cap * 8 : c->tb.cap * 5 / 2);
+    uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), hinted && env_int("SHK_WIDE_WINDOW", 1) ? c->tb.cap * (uint64_t)env_int("SHK_WINDOW_TABLES", 16) : c->tb.cap * 5 / 2);
     if (env_int("SHK_ACC_MAX_MRECORDS", 0) > 0) bmax = std::min<uint64_t>(bmax, (uint64_t)env_int("SHK_ACC_MAX_MRECORDS", 0) << 20);  // test hook: small windows (several contexts on one card)
     bmax = std::max<uint64_t>(std::min(bmax, mem_records), kmers_ub);
     // a lane's regions take a lane's share of the window (+ 50 %: blocks of uneven read lengths), but at
