@@ -1187,7 +1187,8 @@ static int xl_count(shk_ctx *c, const BatchRef &b, const PartGeom &g, uint64_t s
 // The same segments — [owner][lane][super-page] regions of cap1 records, their fill levels beside them — with the
 // canonical k-mer as the record: k_scatter64 in its owner layout at the sender (a launch per chunk lane present in the
 // batch), k_part_rescatter at the receiver (a launch per lane of a segment) into the waiting (lane, page) regions that
-// k_pages counts.  Only the exchange rounds use it (a share's own ingest at k > 21 stays with the global atomics).
+// k_pages counts.  The exchange rounds use it with every owner's records kept (a segment each), a share's own ingest
+// with its own records only (one segment: xl64_count).
 static bool xl64_feasible(const shk_ctx *c, const PartGeom &g) {
   // (≤ 32 chunk lanes: a round's segments — lanes · 2^log_p1 regions of at least 1024 records — stay below the 4 GiB the scatter addresses)
   return g.two_level && use_scatter64(c, g) && g.log_sub <= 10 && c->n_lanes <= 32 && g.lpg <= MAX_LOG_PAGES &&
