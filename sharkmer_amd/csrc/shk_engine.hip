@@ -963,7 +963,16 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
   c->acc_records_ub = 0;
   c->acc_lane_ub.assign(NL, 0);
   c->acc_nd0 = nd;
-  c->acc_spill_cap = std::min<uint64_t>(std::max<uint64_t>(budget, kmers_ub), 1ull << 28);
+  // The spill list bounds how many pages one launch of the window's page pass may cover (flush_acc: every record of
+  // every page of a group could spill) — 2^28 entries (4 GiB) cut configs[4]'s ten-lane pass into 252 launches with a
+  // host round trip each; with the regions allocated and 48 GiB and more still free the list may be 2^30 entries.
+  size_t free_now = 0, total_now = 0;
+  (void)hipMemGetInfo(&free_now, &total_now);
+  // (what the list already holds counts as free for it; not where SHK_ACC_MAX_MRECORDS says that several contexts share
+  // the card — eight of them each taking 16 GiB on sight of the same free memory is an out-of-memory)
+  const uint64_t spill_max = free_now + c->spillA.cap >= (48ull << 30) && env_int("SHK_ACC_MAX_MRECORDS", 0) == 0 && env_int("SHK_BIG_SPILL", 1)
+                                 ? 1ull << 30 : 1ull << 28;
+  c->acc_spill_cap = std::min<uint64_t>(std::max<uint64_t>(budget, kmers_ub), spill_max);
   return SHK_OK;
 }
 
@@ -1590,7 +1599,7 @@ static int paged_count(shk_ctx *c, const BatchRef &b, uint64_t sub_kmers_ub, Spi
                            all_lanes ? n_pages : 0u, (uint32_t)region_lanes * n_pages,
                            (const unsigned int *)cursor_pg, cap_pg, (const uint32_t *)buf_pg.p, c->d_stats, sp);
       else
-        hipLaunchKernelGGL((k_pages<false, false>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane,
+        hipLaunchKernelGGL((k_pages<false, false>), dim3(n_pages), dim3(PG_WG), 0, c->stream, c->tb, lane, lane + 1, 0u,
                            (const unsigned int *)cursor_pg, cap_pg, (const uint64_t *)buf_pg.p,
                            (uint64_t *)c->part2.p, c->d_stats, sp);
     }
@@ -1783,7 +1792,7 @@ static int flush_acc(shk_ctx *c) {
     if (rcf != SHK_OK) return rcf;
   }
   // pages per launch so that even if every record of every one of them spilled the list would hold them
-  const uint64_t per_page_ub = (uint64_t)(c->acc_rec32 ? NL : 1u) * c->acc_cap;
+  const uint64_t per_page_ub = (uint64_t)NL * c->acc_cap;  // (every lane's regions of a page in one launch, either record width)
   uint64_t ppg = std::max<uint64_t>(spill_cap / std::max<uint64_t>(per_page_ub, 1), 1);
   if (env_int("SHK_FLUSH_GROUP_PAGES", 0) > 0) ppg = (uint64_t)env_int("SHK_FLUSH_GROUP_PAGES", 0);  // test hook
   // (a window whose records all fit the list — the usual case — is one launch whatever the regions could hold)
@@ -1826,22 +1835,18 @@ static int flush_acc(shk_ctx *c) {
         hipLaunchKernelGGL((k_pages32<false, 0>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, NL > 1 ? n_pages : 0u,
                            NL * n_pages, (const unsigned int *)c->acc_cur.p, c->acc_cap, (const uint32_t *)c->acc_buf.p,
                            c->d_stats, sp, (uint32_t)p0);
-    } else {  // 8-byte records: one page pass per lane over that lane's regions
-      for (uint32_t lane = 0; lane < NL; ++lane) {
-        ScopedTimer t(c, SHK_K_PAGES);
-        const unsigned int *cur_l = (const unsigned int *)c->acc_cur.p + (size_t)lane * n_pages;
-        const uint64_t *buf_l = (const uint64_t *)c->acc_buf.p + (size_t)lane * n_pages * c->acc_cap;
-        if (fresh8 && lane == 0)  // the table's first page pass: nothing is read, keys and counts are written whole
-          hipLaunchKernelGGL((k_pages<true, true>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, lane, cur_l, c->acc_cap, buf_l, (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
-        else if (fresh8)
-          hipLaunchKernelGGL((k_pages<false, true>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, lane, cur_l, c->acc_cap, buf_l, (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
-        else
-          hipLaunchKernelGGL((k_pages<false, false>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, lane, cur_l, c->acc_cap, buf_l, (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
-        if (grouped) {  // (a lane's launch over the group is bounded by gp · acc_cap on its own)
-          int rc = read_stats(c);
-          if (rc == SHK_OK) rc = hold_spills(c, spill_cap);
-          if (rc != SHK_OK) return rc;
-        }
+    } else {  // 8-byte records: every lane's regions of a page in one launch (the keys stay in LDS over the lanes)
+      ScopedTimer t(c, SHK_K_PAGES);
+      const unsigned int *cur = (const unsigned int *)c->acc_cur.p;
+      const uint64_t *buf = (const uint64_t *)c->acc_buf.p;
+      if (fresh8)  // the table's first page pass: nothing is read, keys and counts are written whole
+        hipLaunchKernelGGL((k_pages<true, true>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, n_pages, cur, c->acc_cap, buf, (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
+      else
+        hipLaunchKernelGGL((k_pages<false, false>), dim3(gp), dim3(PG_WG), 0, c->stream, c->tb, 0u, NL, n_pages, cur, c->acc_cap, buf, (uint64_t *)c->part2.p, c->d_stats, sp, (uint32_t)p0);
+      if (grouped) {
+        int rc = read_stats(c);
+        if (rc == SHK_OK) rc = hold_spills(c, spill_cap);
+        if (rc != SHK_OK) return rc;
       }
     }
     if (grouped && c->acc_rec32) {
