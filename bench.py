@@ -922,7 +922,7 @@ def main():
         torch.cuda.empty_cache()
         import copy
         a4 = copy.copy(args)
-        a4.steps, a4.warmup, a4.reads, a4.no_cpu_baseline = min(args.steps, 3), 1, 0, True
+        a4.steps, a4.warmup, a4.reads, a4.no_cpu_baseline = min(args.steps, 3), 2, 0, True   # (two warm-up jobs: owner_run's note)
         c4 = owner_run(a4, 4, "exchange", dist_ready=True)
         if rank == 0:
             out["extras"] = {"config4": {key: c4[key] for key in ("value", "ms_per_step", "n_gpus", "config", "kernels_ms_per_step", "exchange",
