@@ -192,6 +192,13 @@ struct DevBuf {  // grow-only device scratch
     if (e != hipSuccess) p = nullptr, cap = 0;
     return e;
   }
+  hipError_t ensure_exact(size_t bytes) {  // (a buffer that is planned once from the free memory: no eighth on top)
+    if (bytes <= cap) return hipSuccess;
+    release();
+    hipError_t e = dev_alloc(&p, bytes + 4096, &cap);
+    if (e != hipSuccess) p = nullptr, cap = 0;
+    return e;
+  }
   void release() {
     dev_free(p, cap);
     p = nullptr;
@@ -920,16 +927,33 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
     // kept configs[2]'s 12 G records from ever being one window)
     const uint64_t rec_bytes = rec32 ? (NL > 1 ? 8ull : 5ull) + 1 : (NL > 1 ? 15ull : 10ull) + 1;
     const uint64_t miss_bytes = rec32 ? 0ull : n_pages * (uint64_t)MISS_PAGE_MAX * 8ull;
-    const uint64_t mem_avail = (uint64_t)(free_b / 3 * 2 + c->acc_buf.cap);
-    const uint64_t mem_records = (mem_avail > miss_bytes ? mem_avail - miss_bytes : 0ull) / rec_bytes;
+    // two thirds of what is free — or, when a capacity hint says the table will not have to grow (its double is what the
+    // third is kept for), all of it but 48 GiB (the spill list's 16, the exchange buffers, staging), and the regions'
+    // bytes reckoned as they will be allocated (1.25 x, over several lanes 1.5 x 1.25 x the records, + 1024 and a rounding
+    // block per region) instead of a byte per record for the rest: configs[4]'s share — 74 rounds booked at 260 M records
+    // = 19.2 G over ten lanes beside a 51 GB table and the reads — was 10 % short of ONE window, and its second page pass
+    // read and wrote the whole table again (the pass 53.6 -> 38 ms of a 159 ms job)
+    const bool hinted0 = c->cfg.table_capacity_hint && (double)c->cfg.table_capacity_hint <= 0.8 * (double)c->tb.cap;
+    const uint64_t keep = (uint64_t)env_int("SHK_WINDOW_KEEP_GIB", 48) << 30;
+    const bool roomy = hinted0 && free_b > keep && free_b - keep > free_b / 3 * 2;
+    const uint64_t mem_avail = (roomy ? free_b - keep : free_b / 3 * 2) + c->acc_buf.cap;
+    uint64_t mem_records = (mem_avail > miss_bytes ? mem_avail - miss_bytes : 0ull) / rec_bytes;
+    if (roomy) {
+      const uint64_t fixed = (uint64_t)NL * n_pages * (1024 + (1ull << RB_LOG)) * (rec32 ? 4 : 8);
+      const uint64_t eighths = (rec32 ? 4ull : 8ull) * (NL > 1 ? 15 : 10);  // bytes per record x 8
+      mem_records = std::max<uint64_t>(mem_records, mem_avail > miss_bytes + fixed ? (mem_avail - miss_bytes - fixed) / eighths * 8 : 0ull);
+    }
+    SHK_TRACEF("acc_prepare: %.1f of %.1f GiB free, %.1f GiB for the regions = %llu records\n", free_b / 1073741824.0, total_b / 1073741824.0,
+               mem_avail / 1073741824.0, (unsigned long long)mem_records);
     // up to eight tables' worth of records while that is a few GiB, two and a half tables' worth beyond — and eight
     // again when a capacity hint says that no window will have to end for the table's sake: every page pass streams
     // the whole table (24 GB in and out on configs[2]'s 2^30 slots), so the job should make as few as memory allows
     // (configs[2]: 12 G records in two passes instead of five with eight tables' worth — round 3 — and in ONE with sixteen,
-    // memory allowing — round 4: page passes 31.2 → 28.5 ms, the job 117.5 → 122 Gbases/s)
+    // memory allowing — round 4: page passes 31.2 → 28.5 ms, the job 117.5 → 122 Gbases/s;
+    // twenty-four, since the rounds of an exchange book their segments' capacity, 12 % over what arrives: configs[4]'s share)
     const uint64_t few_gib = (8ull << 30) / (rec32 ? 4 : 8) / NL;
     const bool hinted = c->cfg.table_capacity_hint && (double)c->cfg.table_capacity_hint <= 0.8 * (double)c->tb.cap;
-    uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), hinted && env_int("SHK_WIDE_WINDOW", 1) ? c->tb.cap * (uint64_t)env_int("SHK_WINDOW_TABLES", 16) : c->tb.cap * 5 / 2);
+    uint64_t bmax = std::max<uint64_t>(std::min<uint64_t>(c->tb.cap * 8, few_gib), hinted && env_int("SHK_WIDE_WINDOW", 1) ? c->tb.cap * (uint64_t)env_int("SHK_WINDOW_TABLES", 24) : c->tb.cap * 5 / 2);
     if (env_int("SHK_ACC_MAX_MRECORDS", 0) > 0) bmax = std::min<uint64_t>(bmax, (uint64_t)env_int("SHK_ACC_MAX_MRECORDS", 0) << 20);  // test hook: small windows (several contexts on one card)
     bmax = std::max<uint64_t>(std::min(bmax, mem_records), kmers_ub);
     // a lane's regions take a lane's share of the window (+ 50 %: blocks of uneven read lengths), but at
@@ -947,7 +971,7 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
     c->acc_rec32 = rec32;
     c->acc_cap = (uint32_t)cap;
     c->acc_budget_max = bmax;
-    HIPC(c, c->acc_buf.ensure((size_t)NL * n_pages * cap * (rec32 ? 4 : 8)));
+    HIPC(c, roomy ? c->acc_buf.ensure_exact((size_t)NL * n_pages * cap * (rec32 ? 4 : 8)) : c->acc_buf.ensure((size_t)NL * n_pages * cap * (rec32 ? 4 : 8)));
     if (!rec32)  // k_pages' miss queues, here rather than at the first flush
       HIPC(c, c->part2.ensure((uint64_t)n_pages * std::min<uint64_t>(cap + MISS_SLACK, MISS_PAGE_MAX) * 8));
   }
@@ -970,7 +994,9 @@ static int acc_prepare(shk_ctx *c, uint64_t kmers_ub, int64_t lane_one, uint64_t
   (void)hipMemGetInfo(&free_now, &total_now);
   // (what the list already holds counts as free for it; not where SHK_ACC_MAX_MRECORDS says that several contexts share
   // the card — eight of them each taking 16 GiB on sight of the same free memory is an out-of-memory)
-  const uint64_t spill_max = free_now + c->spillA.cap >= (48ull << 30) && env_int("SHK_ACC_MAX_MRECORDS", 0) == 0 && env_int("SHK_BIG_SPILL", 1)
+  // (a list that is that long already stays in use whatever came to lie beside it since)
+  const uint64_t spill_max = (c->spillA.cap >= (16ull << 30) || free_now + c->spillA.cap >= (40ull << 30)) && env_int("SHK_ACC_MAX_MRECORDS", 0) == 0 &&
+                                     env_int("SHK_BIG_SPILL", 1)
                                  ? 1ull << 30 : 1ull << 28;
   c->acc_spill_cap = std::min<uint64_t>(std::max<uint64_t>(budget, kmers_ub), spill_max);
   return SHK_OK;
