@@ -44,6 +44,7 @@ struct XchgOut {
   bool wide = false;
   void *d_kmers = nullptr, *d_lanes = nullptr;
   uint64_t *counts = nullptr;
+  bool late_settle = false;  // shk_xchg_scatter_device looks at the previous absorb's outcome AFTER this launch (below)
 };
 static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo);
 static int xw_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo);
@@ -606,7 +607,7 @@ constexpr uint64_t MAX_SUB_BASES = 1ull << 28;  // bases per counting launch (bo
 int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_seqs,
                 uint64_t n_bases, int64_t lane_fixed, XchgOut *xo = nullptr, uint64_t off_bias = 0) {
   if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
-  {
+  if (!(xo && xo->late_settle)) {
     int rc0 = settle_light(c);  // the previous launch's spill list / scratch must be done with
     if (rc0 != SHK_OK) return rc0;
   }
@@ -678,7 +679,9 @@ int ingest_core(shk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, u
     ScopedTimer t(c, SHK_K_MARK);
     hipLaunchKernelGGL(k_mark_starts, dim3((uint32_t)((n_seqs + WG - 1) / WG)), dim3(WG), 0,
                        c->stream, d_offsets, n_seqs, n_bases, (uint32_t *)c->startbits.p, (uint64_t)sb_words,
-                       (unsigned int *)c->part_meta.p, n_cursor_words, &c->d_stats->spill_count, off_bias,
+                       (unsigned int *)c->part_meta.p, n_cursor_words,
+                       xo && xo->late_settle ? nullptr : &c->d_stats->spill_count,  // (the previous absorb's spills are still to be looked at)
+                       off_bias,
                        (uint4 *)c->d_tot, c->hist_dirty ? (uint32_t)(sizeof(HistoTotals) / 16) : 0u, (uint4 *)c->d_hist,
                        c->hist_dirty ? (uint32_t)((c->ctl_bytes - c->ctl_hist_off) / 16) : 0u);
     c->hist_dirty = false;
@@ -2662,14 +2665,28 @@ int shk_xchg_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offse
   xo.layout_bases = layout_bases;
   // Two exchange buffers, taken in turn: what this call hands out stays valid until the next call BUT ONE, so the
   // caller can have round r's segments on the links (another stream, peers pulling) while round r+1 is scattered.
-  {
-    int rcs = settle_light(c);  // (the previous launch may still be reading the cursor block about to be swapped out)
+  // What is unsettled here, between two rounds, is the previous round's ABSORB (a level-2 pass into the waiting page
+  // regions; its spills go to the window's list, which this scatter — foreign spills on a list of its own — does not
+  // touch, and it is in front of this scatter on the stream).  Waiting for it before launching cost a host round trip
+  // with the GPU idle every round; the scatter's own read of the outcome, below, sees the absorb's too.
+  xo.late_settle = c->unsettled && c->acc_active && !c->poisoned && env_int("SHK_XCHG_LATE_SETTLE", 1) != 0;
+  if (!xo.late_settle) {
+    int rcs = settle_light(c);
     if (rcs != SHK_OK) return rcs;
   }
   std::swap(c->xbuf, c->xbuf_alt);
   std::swap(c->part_meta, c->part_meta_alt);
   int rc = ingest_core(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_seqs, n_bases, c->xchg_lane_fixed, &xo);
   if (rc != SHK_OK) return rc;
+  if (xo.late_settle && c->unsettled) {  // (settle_light's look, on the statistics the scatter has just read)
+    if (c->h_stats->spill_count > 0) {
+      SHK_TRACEF("xchg_scatter: the previous absorb spilled %llu records -> settle\n", (unsigned long long)c->h_stats->spill_count);
+      rc = settle(c);
+      if (rc != SHK_OK) return rc;
+    } else {
+      c->unsettled = false;
+    }
+  }
   *d_records = xo.d_records;
   *d_cursors = xo.d_cursors;
   *layout = xo.lay;

@@ -271,6 +271,25 @@ def test_exchange_with_skewed_input_goes_through_the_foreign_spill_list(orc, mon
     assert any(r[3] > 0 for r in res), "the skew was meant to overflow a level-1 region"
 
 
+@pytest.mark.parametrize("late", [1, 0])
+def test_exchange_with_a_hot_page_spills_at_the_absorb(orc, monkeypatch, late):
+    """A k-mer that is a few per cent of every round fits its level-1 region round by round and overflows its PAGE's
+    waiting region over the rounds of a window: the level-2 pass (absorb) spills, and what it spilled is looked at when
+    the next round's scatter reads the statistics (SHK_XCHG_LATE_SETTLE, the default: the scatter is launched without
+    waiting for the absorb in front of it, and the read-start kernel leaves the spill counter alone) or before that
+    scatter is launched (= 0: round 3's order).  Exact either way, and the spill path was taken."""
+    monkeypatch.setenv("SHK_LEVEL1_LOG", "5")         # (few, long level-1 regions: the hot k-mer fits them round by round)
+    monkeypatch.setenv("SHK_ACC_MAX_MRECORDS", "1")   # windows of 2^20 records: page regions of a few thousand
+    monkeypatch.setenv("SHK_XCHG_LATE_SETTLE", str(late))
+    rng = np.random.default_rng(11)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [b"ACAC" * 37 + b"AC" if i % 10 == 0 else lut[rng.integers(0, 4, size=150)].tobytes() for i in range(24_000)]
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    offsets = np.arange(len(seqs) + 1, dtype=np.uint64) * 150
+    res = _exchange_run(orc, bases, offsets, 19, 2, 5000, 2, hint=3_000_000)
+    assert any(r[2] > 0 for r in res), "the hot page was meant to overflow its waiting region (n_spilled)"
+
+
 @pytest.mark.parametrize("k", [19, 31])
 def test_exchange_invalid_byte_fails_every_rank(monkeypatch, k):
     monkeypatch.setenv("SHK_LEVEL1_LOG", "8")
