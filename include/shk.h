@@ -394,6 +394,17 @@ typedef struct shk_xchg_layout {
 int shk_xchg_scatter_device(shk_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_seqs,
                             uint64_t n_bases, uint64_t layout_bases, void **d_records, void **d_cursors,
                             shk_xchg_layout *layout, uint64_t *n_foreign_spilled);
+/* The same scatter in two calls (round 4), for a caller that has something to put on the context's stream while the
+ * scatter runs — the absorbs of the previous round's segments: _begin launches and returns at once, with the
+ * segments' addresses and layout (functions of the configuration, not of the data), _end waits for the scatter
+ * and reports what shk_xchg_scatter_device reports at its return (SHK_ERR_INVALID_CHAR and the poisoned context,
+ * *n_foreign_spilled).  Between the two: shk_xchg_absorb only; the segments are complete when _end has returned.
+ * With the one-call form the GPU stood idle every round from the end of the scatter until the host had woken up
+ * and launched the absorbs (io.rs has no counterpart: it is the counting loop's batch boundary, io.rs:340-361). */
+int shk_xchg_scatter_begin(shk_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_seqs,
+                           uint64_t n_bases, uint64_t layout_bases, void **d_records, void **d_cursors,
+                           shk_xchg_layout *layout);
+int shk_xchg_scatter_end(shk_ctx *ctx, uint64_t *n_foreign_spilled);
 int shk_xchg_absorb(shk_ctx *ctx, const void *d_records, const void *d_cursors, const shk_xchg_layout *layout);
 int shk_xchg_spill(shk_ctx *ctx, void **d_kmers, void **d_lanes, void **d_counts, uint64_t *n);
 int shk_xchg_spill_clear(shk_ctx *ctx);

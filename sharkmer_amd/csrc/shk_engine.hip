@@ -45,6 +45,7 @@ struct XchgOut {
   void *d_kmers = nullptr, *d_lanes = nullptr;
   uint64_t *counts = nullptr;
   bool late_settle = false;  // shk_xchg_scatter_device looks at the previous absorb's outcome AFTER this launch (below)
+  bool two_calls = false;    // shk_xchg_scatter_begin: the statistics' copy is queued behind the launch, not waited for
 };
 static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo);
 static int xw_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo);
@@ -323,6 +324,9 @@ struct shk_ctx {
   std::vector<TimedEvent> events;
   std::vector<hipEvent_t> event_pool;
   hipEvent_t done_ev = nullptr;   // finalize: "the control block has been copied back"
+  hipEvent_t xs_ev = nullptr;     // shk_xchg_scatter_begin: "the statistics behind the scatter have been copied back"
+  bool xs_pending = false, xs_late = false;
+  uint64_t n_absorbs = 0, xs_absorbs = 0;  // absorbs launched so far / when the pending scatter was launched
   hipEvent_t chain_ev = nullptr;  // end event of the last timer (see ScopedTimer)
   uint64_t cur_blocks = 1;        // 1000-read blocks in the batch being counted (ingest_core)
   double cur_kmer_ratio = 1.0;    // (k-mers ÷ bases) of the batch being counted if every read has ≥ k bases: n_bases − (k−1)·n_seqs over n_bases
@@ -1336,6 +1340,18 @@ static SpillRef xspill_ref(shk_ctx *c) {
   sp.count = &c->d_stats->scratch[0];
   return sp;
 }
+// What an exchange scatter left in the statistics (h_stats read back behind it).
+static int xchg_scatter_outcome(shk_ctx *c, uint64_t *n_foreign) {
+  if (c->h_stats->bad != ~0ull) {
+    c->poisoned = true;
+    c->poison_code = SHK_ERR_INVALID_CHAR;
+    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%s' in sequence. Only ACGTN allowed.", shk::byte_as_char((uint8_t)(c->h_stats->bad & 0xFF)).c_str());
+  }
+  if (c->h_stats->scratch[0] > c->xspill_cap) return fail(c, SHK_ERR_INVARIANT, "foreign spill list overflow");
+  *n_foreign = c->h_stats->scratch[0];
+  return SHK_OK;
+}
+
 static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub, XchgOut *xo) {
   const PartGeom g = part_geom(c);
   int rc = xchg_check(c, g);
@@ -1370,14 +1386,6 @@ static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub,
     HIPC(c, c->part_meta.ensure(cursor_buf_bytes(c, g, true)));
     HIPC(c, hipMemsetAsync(c->part_meta.p, 0, (size_t)x.n_seg * x.n_grp * 4, c->stream));
   }
-  rc = read_stats(c);  // (synchronises: the segments are complete when this call returns)
-  if (rc != SHK_OK) return rc;
-  if (c->h_stats->bad != ~0ull) {
-    c->poisoned = true;
-    c->poison_code = SHK_ERR_INVALID_CHAR;
-    return fail(c, SHK_ERR_INVALID_CHAR, "Invalid character '%s' in sequence. Only ACGTN allowed.", shk::byte_as_char((uint8_t)(c->h_stats->bad & 0xFF)).c_str());
-  }
-  if (c->h_stats->scratch[0] > c->xspill_cap) return fail(c, SHK_ERR_INVARIANT, "foreign spill list overflow");
   xo->d_records = c->xbuf.p;
   xo->d_cursors = c->part_meta.p;
   xo->lay.n_owners = c->n_owners;
@@ -1387,8 +1395,15 @@ static int xchg_scatter_launch(shk_ctx *c, const BatchRef &b, uint64_t kmers_ub,
   xo->lay.region_cap = x.cap1;
   xo->lay.record_bytes = rec_bytes;
   xo->lay.segment_records = x.seg_recs;
-  xo->n_foreign = c->h_stats->scratch[0];
-  return SHK_OK;
+  if (xo->two_calls) {  // the outcome is fetched by shk_xchg_scatter_end; what is launched in between runs behind the scatter
+    if (!c->xs_ev) HIPC(c, hipEventCreateWithFlags(&c->xs_ev, hipEventDisableTiming));
+    HIPC(c, hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipEventRecord(c->xs_ev, c->stream));
+    return SHK_OK;
+  }
+  rc = read_stats(c);  // (synchronises: the segments are complete when this call returns)
+  if (rc != SHK_OK) return rc;
+  return xchg_scatter_outcome(c, &xo->n_foreign);
 }
 
 // The wide exchange round: validate (k_scan), count the batch's k-mers by owner, lay the owners' segments out back to
@@ -2091,6 +2106,7 @@ void shk_destroy(shk_ctx *c) {
   if (c->tb.keys) free_table(c->tb);
   lap("table given back");
   if (c->done_ev) (void)hipEventDestroy(c->done_ev);
+  if (c->xs_ev) (void)hipEventDestroy(c->xs_ev);
   if (c->d_ctl) dev_free(c->d_ctl, c->ctl_alloc);
   if (c->h_ctl) host_free(c->h_ctl, c->ctl_alloc_h);
   c->in_bases.release();
@@ -2148,6 +2164,10 @@ int shk_reset(shk_ctx *c) {
     return SHK_OK;
   }
   HIPC(c, hipSetDevice(c->cfg.device));
+  if (c->xs_pending) {  // (a round that was given up between shk_xchg_scatter_begin and _end: its copy of the statistics lands first)
+    (void)hipEventSynchronize(c->xs_ev);
+    c->xs_pending = false;
+  }
   {
     // the control block (stats, totals, histogram); the TABLE is cleared by whoever touches it first — the first
     // page pass writes it whole instead, with the counts in it (k_pages32<true>)
@@ -2653,16 +2673,30 @@ int shk_insert_counts(shk_ctx *c, uint32_t chunk_id, const uint64_t *kmers, cons
   return drain_spill(c, n);
 }
 
-int shk_xchg_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases,
-                            uint64_t layout_bases, void **d_records, void **d_cursors, shk_xchg_layout *layout,
-                            uint64_t *n_foreign_spilled) {
+// settle_light's look at what was unsettled when an exchange scatter was launched without waiting (the absorb in front of
+// it), on the statistics read back behind the scatter.  absorbs_since: launches that those statistics may not cover.
+static int xchg_late_settle(shk_ctx *c, bool late, bool absorbs_since) {
+  if (!c->unsettled || !(late || absorbs_since)) return SHK_OK;
+  if (c->h_stats->spill_count > 0) {
+    SHK_TRACEF("xchg_scatter: an absorb spilled %llu records -> settle\n", (unsigned long long)c->h_stats->spill_count);
+    return settle(c);
+  }
+  if (!absorbs_since) c->unsettled = false;
+  return SHK_OK;
+}
+
+// The exchange scatter, in one call (the outcome waited for) or in two (shk_xchg_scatter_begin / _end).
+static int xchg_scatter_call(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases, uint64_t layout_bases,
+                             void **d_records, void **d_cursors, shk_xchg_layout *layout, uint64_t *n_foreign_spilled, bool two_calls) {
   if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
   if (!c || !d_records || !d_cursors || !layout) return SHK_ERR_BAD_ARG;
   HIPC(c, hipSetDevice(c->cfg.device));
+  if (c->xs_pending) return fail(c, SHK_ERR_STATE, "an exchange scatter is begun and not ended (shk_xchg_scatter_end)");
   if (n_bases > SHK_XCHG_MAX_BASES || (layout_bases && layout_bases > SHK_XCHG_MAX_BASES))
     return fail(c, SHK_ERR_BAD_ARG, "an exchange batch takes at most %llu bases", (unsigned long long)SHK_XCHG_MAX_BASES);
   XchgOut xo{};
   xo.layout_bases = layout_bases;
+  xo.two_calls = two_calls;
   // Two exchange buffers, taken in turn: what this call hands out stays valid until the next call BUT ONE, so the
   // caller can have round r's segments on the links (another stream, peers pulling) while round r+1 is scattered.
   // What is unsettled here, between two rounds, is the previous round's ABSORB (a level-2 pass into the waiting page
@@ -2678,20 +2712,43 @@ int shk_xchg_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offse
   std::swap(c->part_meta, c->part_meta_alt);
   int rc = ingest_core(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_seqs, n_bases, c->xchg_lane_fixed, &xo);
   if (rc != SHK_OK) return rc;
-  if (xo.late_settle && c->unsettled) {  // (settle_light's look, on the statistics the scatter has just read)
-    if (c->h_stats->spill_count > 0) {
-      SHK_TRACEF("xchg_scatter: the previous absorb spilled %llu records -> settle\n", (unsigned long long)c->h_stats->spill_count);
-      rc = settle(c);
-      if (rc != SHK_OK) return rc;
-    } else {
-      c->unsettled = false;
-    }
-  }
   *d_records = xo.d_records;
   *d_cursors = xo.d_cursors;
   *layout = xo.lay;
+  if (two_calls) {
+    c->xs_pending = true;
+    c->xs_late = xo.late_settle;
+    c->xs_absorbs = c->n_absorbs;
+    return SHK_OK;
+  }
   if (n_foreign_spilled) *n_foreign_spilled = xo.n_foreign;
-  return SHK_OK;
+  return xchg_late_settle(c, xo.late_settle, /*absorbs_since=*/false);
+}
+
+int shk_xchg_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases,
+                            uint64_t layout_bases, void **d_records, void **d_cursors, shk_xchg_layout *layout,
+                            uint64_t *n_foreign_spilled) {
+  return xchg_scatter_call(c, d_bases, d_offsets, n_seqs, n_bases, layout_bases, d_records, d_cursors, layout, n_foreign_spilled, false);
+}
+
+int shk_xchg_scatter_begin(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases,
+                           uint64_t layout_bases, void **d_records, void **d_cursors, shk_xchg_layout *layout) {
+  return xchg_scatter_call(c, d_bases, d_offsets, n_seqs, n_bases, layout_bases, d_records, d_cursors, layout, nullptr, true);
+}
+
+int shk_xchg_scatter_end(shk_ctx *c, uint64_t *n_foreign_spilled) {
+  if (c && c->group) return fail(c, SHK_ERR_STATE, "not available on a multi-device context");
+  if (!c) return SHK_ERR_BAD_ARG;
+  if (!c->xs_pending) return fail(c, SHK_ERR_STATE, "no exchange scatter is begun (shk_xchg_scatter_begin)");
+  c->xs_pending = false;
+  HIPC(c, hipSetDevice(c->cfg.device));
+  HIPC(c, hipEventSynchronize(c->xs_ev));  // (a later, synchronous read of the statistics — an absorb that ended a window — only makes them newer)
+  if (c->poisoned) return fail(c, c->poison_code, "%s", c->err.c_str());
+  uint64_t nf = 0;
+  int rc = xchg_scatter_outcome(c, &nf);
+  if (rc != SHK_OK) return rc;
+  if (n_foreign_spilled) *n_foreign_spilled = nf;
+  return xchg_late_settle(c, c->xs_late, c->n_absorbs != c->xs_absorbs);
 }
 
 int shk_xchg_wide_scatter_device(shk_ctx *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases,
@@ -2780,6 +2837,7 @@ int shk_xchg_absorb(shk_ctx *c, const void *d_records, const void *d_cursors, co
   }
   c->acc_active = true;
   acc_book(c, est, -1, lane_bound);
+  c->n_absorbs++;
   c->unsettled = true;
   c->unsettled_spill_cap = spill_cap;
   return SHK_OK;

@@ -124,8 +124,8 @@ class OwnerCounter:
     CUDA engine the collectives run on a stream of their own, step 3 of round r is deferred until round r + 1 has
     scattered (the engine hands its exchange buffers out in turn; the receive buffers here come in two sets), and
     events order the two streams where they meet — round r's segments cross the links while the engine absorbs
-    round r − 1 and scatters round r + 1.  The host waits twice per round: for the scatter's outcome and for the
-    2-word flags.
+    round r − 1 and scatters round r + 1.  The host waits twice per round: for the scatter's outcome — after it has
+    launched the previous round's absorbs behind the scatter (the engine's two-call scatter) — and for the 2-word flags.
 
     finalize_histograms: every rank's histogram covers its share; bins are additive across disjoint key
     sets (KmerCounts::extend, counting.rs:157-166), so one all_reduce(SUM) of histogram + totals
@@ -144,6 +144,7 @@ class OwnerCounter:
         self._pending = None   # the round whose exchange is in flight: absorbed at the next round or at finalize
         self._comm = None
         self._wide = None   # rounds take the wide route (engine.xchg_feasible() is False)
+        self._two_calls = hasattr(engine, "xchg_scatter_begin_tensors") and not os.environ.get("SHK_DIST_ONE_CALL_SCATTER")
         self._trace = [0.0, 0.0, 0.0, 0] if os.environ.get("SHK_DIST_TRACE") else None
         self.n_rounds = 0
         self.n_foreign_rounds = 0   # rounds in which somebody had foreign spills to hand on
@@ -201,12 +202,18 @@ class OwnerCounter:
         if tr is not None:
             import time as _t
             t_in = _t.perf_counter()
+        # (an engine with the two-call scatter — shk_xchg_scatter_begin / _end — is not waited for here: the absorbs below
+        # go onto its stream behind the scatter, and the outcome is fetched after they have been launched)
+        begun = False
         try:
+            args = (batch[0], batch[1], batch[2], batch[3]) if batch is not None else (0, 0, 0, 0)
             if batch is not None:
                 self.eng.set_read_index(batch[4])
-                rec, cur, lay, n_foreign = self.eng.xchg_scatter_tensors(batch[0], batch[1], batch[2], batch[3], self.round_bases)
+            if self._two_calls:
+                rec, cur, lay = self.eng.xchg_scatter_begin_tensors(*args, self.round_bases)
+                begun, n_foreign = True, 0
             else:
-                rec, cur, lay, n_foreign = self.eng.xchg_scatter_tensors(0, 0, 0, 0, self.round_bases)
+                rec, cur, lay, n_foreign = self.eng.xchg_scatter_tensors(*args, self.round_bases)
         except Exception as e:  # noqa: BLE001 — reported to every rank below
             err, n_foreign = e, 0
         if tr is not None:
@@ -221,6 +228,11 @@ class OwnerCounter:
                 self._absorb_pending()
             except Exception as e:  # noqa: BLE001
                 err = e
+        if begun:
+            try:
+                n_foreign = self.eng.xchg_scatter_end()
+            except Exception as e:  # noqa: BLE001
+                err = err if err is not None else e
         r2 = self.n_rounds & 1
         with self._on_comm_stream():
             st = self._dev(torch.tensor([1 if err is not None else 0, n_foreign], dtype=torch.int64))

@@ -111,7 +111,7 @@ ABI_SYMBOLS = [
     "shk_write_histo", "shk_write_final_histo", "shk_write_stats_yaml", "shk_validate_args",
     "shk_run_error", "shk_run_files",
     "shk_xchg_scatter_device", "shk_xchg_absorb", "shk_xchg_spill", "shk_xchg_spill_clear", "shk_insert_device",
-    "shk_xchg_wide_scatter_device", "shk_xchg_feasible",
+    "shk_xchg_wide_scatter_device", "shk_xchg_feasible", "shk_xchg_scatter_begin", "shk_xchg_scatter_end",
     "shk_stream", "shk_compact_owners_packed", "shk_compact_owners_fixed", "shk_merge_pieces_max", "shk_merge_pieces", "shk_set_owner_share", "shk_finalize_begin", "shk_finalize_end",
     "shk_packed_sizes", "shk_pack_reads", "shk_ingest_packed", "shk_ingest_packed_device", "shk_pack_reads_device",
     "shk_unpack_reads_device",
@@ -248,6 +248,8 @@ def load_library():
     L.shk_set_read_index.argtypes = [vp, u64]
     L.shk_xchg_scatter_device.argtypes = [vp, vp, vp, u64, u64, u64, C.POINTER(vp), C.POINTER(vp),
                                           C.POINTER(XchgLayout), C.POINTER(u64)]
+    L.shk_xchg_scatter_begin.argtypes = [vp, vp, vp, u64, u64, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(XchgLayout)]
+    L.shk_xchg_scatter_end.argtypes = [vp, C.POINTER(u64)]
     L.shk_xchg_absorb.argtypes = [vp, vp, vp, C.POINTER(XchgLayout)]
     L.shk_xchg_spill.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.shk_xchg_spill_clear.argtypes = [vp]
@@ -548,6 +550,18 @@ class KmerEngine:
                                                     C.byref(rec), C.byref(cur), C.byref(lay), C.byref(nf)))
         return int(rec.value or 0), int(cur.value or 0), lay, int(nf.value)
 
+    def xchg_scatter_begin(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int, layout_bases: int = 0):
+        """The scatter launched, not waited for → (d_records, d_cursors, XchgLayout); xchg_scatter_end() → n_foreign_spilled."""
+        rec, cur, lay = C.c_void_p(), C.c_void_p(), XchgLayout()
+        self._check(self._L.shk_xchg_scatter_begin(self._h, d_bases, d_offsets, n_seqs, n_bases, layout_bases,
+                                                   C.byref(rec), C.byref(cur), C.byref(lay)))
+        return int(rec.value or 0), int(cur.value or 0), lay
+
+    def xchg_scatter_end(self) -> int:
+        nf = C.c_uint64(0)
+        self._check(self._L.shk_xchg_scatter_end(self._h, C.byref(nf)))
+        return int(nf.value)
+
     def xchg_absorb(self, d_records: int, d_cursors: int, lay):
         self._check(self._L.shk_xchg_absorb(self._h, d_records, d_cursors, C.byref(lay)))
 
@@ -701,6 +715,14 @@ class KmerEngine:
         # (a tensor element is one record: int32 for the 4-byte layout, int64 for the 8-byte one — layout.record_bytes)
         return (self._raw_tensor(rec, W * lay.segment_records, "<i8" if lay.record_bytes == 8 else "<i4", self._tdev),
                 self._raw_tensor(cur, W * lay.regions, "<i4", self._tdev), lay, nf)
+
+    def xchg_scatter_begin_tensors(self, d_bases: int, d_offsets: int, n_seqs: int, n_bases: int, layout_bases: int = 0):
+        """xchg_scatter_tensors without the wait: (records, cursors, layout) — views that are complete once
+        xchg_scatter_end() has returned (stream-ordered users on the engine's stream need not wait for that)."""
+        rec, cur, lay = self.xchg_scatter_begin(d_bases, d_offsets, n_seqs, n_bases, layout_bases)
+        W = lay.n_owners
+        return (self._raw_tensor(rec, W * lay.segment_records, "<i8" if lay.record_bytes == 8 else "<i4", self._tdev),
+                self._raw_tensor(cur, W * lay.regions, "<i4", self._tdev), lay)
 
     def xchg_absorb_tensors(self, rec_t, cur_t, lay):
         assert rec_t.is_contiguous() and cur_t.is_contiguous()

@@ -271,16 +271,20 @@ def test_exchange_with_skewed_input_goes_through_the_foreign_spill_list(orc, mon
     assert any(r[3] > 0 for r in res), "the skew was meant to overflow a level-1 region"
 
 
-@pytest.mark.parametrize("late", [1, 0])
-def test_exchange_with_a_hot_page_spills_at_the_absorb(orc, monkeypatch, late):
+@pytest.mark.parametrize("late,one_call", [(1, False), (0, False), (1, True)])
+def test_exchange_with_a_hot_page_spills_at_the_absorb(orc, monkeypatch, late, one_call):
     """A k-mer that is a few per cent of every round fits its level-1 region round by round and overflows its PAGE's
     waiting region over the rounds of a window: the level-2 pass (absorb) spills, and what it spilled is looked at when
     the next round's scatter reads the statistics (SHK_XCHG_LATE_SETTLE, the default: the scatter is launched without
     waiting for the absorb in front of it, and the read-start kernel leaves the spill counter alone) or before that
-    scatter is launched (= 0: round 3's order).  Exact either way, and the spill path was taken."""
+    scatter is launched (= 0: round 3's order); with the scatter in two calls (shk_xchg_scatter_begin / _end, what
+    OwnerCounter uses: the absorbs are launched between the two) or in one (SHK_DIST_ONE_CALL_SCATTER).  Exact every way,
+    and the spill path was taken."""
     monkeypatch.setenv("SHK_LEVEL1_LOG", "5")         # (few, long level-1 regions: the hot k-mer fits them round by round)
     monkeypatch.setenv("SHK_ACC_MAX_MRECORDS", "1")   # windows of 2^20 records: page regions of a few thousand
     monkeypatch.setenv("SHK_XCHG_LATE_SETTLE", str(late))
+    if one_call:
+        monkeypatch.setenv("SHK_DIST_ONE_CALL_SCATTER", "1")
     rng = np.random.default_rng(11)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     seqs = [b"ACAC" * 37 + b"AC" if i % 10 == 0 else lut[rng.integers(0, 4, size=150)].tobytes() for i in range(24_000)]
@@ -288,6 +292,25 @@ def test_exchange_with_a_hot_page_spills_at_the_absorb(orc, monkeypatch, late):
     offsets = np.arange(len(seqs) + 1, dtype=np.uint64) * 150
     res = _exchange_run(orc, bases, offsets, 19, 2, 5000, 2, hint=3_000_000)
     assert any(r[2] > 0 for r in res), "the hot page was meant to overflow its waiting region (n_spilled)"
+
+
+def test_scatter_in_two_calls_keeps_its_order():
+    """shk_xchg_scatter_end without a begin, and a second begin before the end: state errors, nothing launched."""
+    eng = sa.KmerEngine(21, 1, 100, capacity_hint=4_200_000, n_owners=1, owner_id=0)
+    bases, offsets = sa.synth_reads(sa.SynthSpec(genome_len=50_000), 0, 2_000)
+    d_b = torch.from_numpy(bases.copy()).cuda()
+    d_o = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    with pytest.raises(sa.ShkError, match="no exchange scatter is begun"):
+        eng.xchg_scatter_end()
+    rec, cur, lay = eng.xchg_scatter_begin_tensors(d_b.data_ptr(), d_o.data_ptr(), 2_000, len(bases))
+    with pytest.raises(sa.ShkError, match="begun and not ended"):
+        eng.xchg_scatter_begin_tensors(d_b.data_ptr(), d_o.data_ptr(), 2_000, len(bases))
+    assert eng.xchg_scatter_end() == 0
+    assert int(cur.sum().item()) == 2_000 * 130          # every k-mer is in a region of the one segment
+    eng.xchg_absorb_tensors(rec, cur, lay)
+    eng.finalize()
+    assert eng.counters()["n_kmers_ingested"] == 2_000 * 130
+    eng.close()
 
 
 @pytest.mark.parametrize("k", [19, 31])
