@@ -509,7 +509,17 @@ int grow_to(shk_ctx *c, uint32_t new_log_pages) {
   }
   fused_drop(c);
   TableRef nt{};
-  int rc = alloc_table(c, new_log_pages, &nt);
+  int rc = env_int("SHK_TEST_GROW_NOMEM", 0) && c->acc_buf.p ? SHK_ERR_NOMEM : alloc_table(c, new_log_pages, &nt);  // (test hook: the first try fails)
+  if (rc == SHK_ERR_NOMEM && c->acc_buf.p && !c->acc_active) {
+    // The waiting regions are empty here (settled above) and may hold most of the card (a window planned under a
+    // capacity hint that said the table would not grow takes the free memory but 48 GiB): give them back and try
+    // again; the next window plans them anew beside the larger table.
+    SHK_TRACEF("grow_to: no room for the %u-page table beside %.1f GiB of waiting regions -> regions given back\n", 1u << new_log_pages, c->acc_buf.cap / 1073741824.0);
+    c->acc_buf.release();
+    c->acc_budget_max = 0;
+    rc = alloc_table(c, new_log_pages, &nt);
+    if (rc == SHK_OK) c->err.clear();
+  }
   if (rc != SHK_OK) return rc;
   if (c->tb_stale) {
     c->tb_stale = false;  // (nothing to carry over: the new table is the cleared one)

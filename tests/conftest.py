@@ -28,7 +28,7 @@ _HOOKS = ("SHK_FLUSH_GROUP_PAGES", "SHK_DEFER_BUDGET", "SHK_LEVEL1_LOG", "SHK_TW
           "SHK_DIST_MAX_MESSAGE", "SHK_FASTQ_WINDOW_KB", "SHK_FASTQ_THREADS", "SHK_FASTQ_COPY_THREADS", "SHK_NO_AVX2",
           "SHK_RUN_ASCII", "SHK_GROUP_ROUND_KB", "SHK_TRACE", "SHK_FASTQ_DEBUG", "SHK_PGZ_MIN_KB", "SHK_PGZ_CHUNK_KB",
           "SHK_PGZ_THREADS", "SHK_WIDE_WINDOW", "SHK_BENCH_EXTRAS", "SHK_HOST_PACK", "SHK_ACC_MAX_MRECORDS", "SHK_SLICE_KB", "SHK_NO_MEM_CACHE",
-          "SHK_FUSED_HIST", "SHK_INSERT_PAGED", "SHK_INSERT_PAGED_MIN", "SHK_XL64", "SHK_XCHG_LATE_SETTLE", "SHK_DIST_ONE_CALL_SCATTER", "SHK_SCATTER64", "SHK_S64_INTERLEAVE", "SHK_CTL_OUT_KERNEL", "SHK_EXP_IGNORE_FINALIZE")
+          "SHK_FUSED_HIST", "SHK_INSERT_PAGED", "SHK_INSERT_PAGED_MIN", "SHK_XL64", "SHK_XCHG_LATE_SETTLE", "SHK_DIST_ONE_CALL_SCATTER", "SHK_TEST_GROW_NOMEM", "SHK_WINDOW_KEEP_GIB", "SHK_WINDOW_TABLES", "SHK_SCATTER64", "SHK_S64_INTERLEAVE", "SHK_CTL_OUT_KERNEL", "SHK_EXP_IGNORE_FINALIZE")
 
 
 @pytest.fixture(autouse=True)

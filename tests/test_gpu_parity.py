@@ -893,6 +893,24 @@ def test_deferred_page_passes_two_level(orc, monkeypatch, k, chunks, hint, budge
     _deferred_page_passes(orc, monkeypatch, k, chunks, hint, budget)
 
 
+@pytest.mark.parametrize("k,chunks", [(21, 1), (31, 2)])
+def test_growth_that_finds_no_room_beside_the_waiting_regions(orc, monkeypatch, k, chunks):
+    """A window planned under a capacity hint may hold most of the card; if the table has to grow all the same (the
+    hint was too low) and finds no room, the — by then empty — regions are given back and planned anew beside the larger
+    table (grow_to).  SHK_TEST_GROW_NOMEM makes every growth's first try fail while regions exist.  Exact all the same."""
+    monkeypatch.setenv("SHK_TEST_GROW_NOMEM", "1")
+    spec = sa.SynthSpec(genome_len=6_000_000, sub_per_64k=100, n_per_64k=30)
+    bases, offsets = sa.synth_reads(spec, 0, 45_000)
+    ref = orc.run_batch(bases, offsets, k, chunks, 100)
+    with sa.KmerEngine(k, chunks, 100, capacity_hint=1_100_000) as eng:
+        for a in range(0, 45_000, 1_500):
+            eng.ingest_reads(bases, offsets[a:a + 1_501])
+        eng.finalize()
+        assert np.array_equal(eng.histograms(), ref.histograms())
+        c = eng.counters()
+    assert c["n_grows"] >= 1 and c["n_unique_kmers"] == ref.stats["n_unique_kmers"]
+
+
 @pytest.mark.parametrize("k,chunks", [(21, 1), (21, 3), (31, 2)])
 def test_grouped_flush_with_a_hint_far_too_low(orc, monkeypatch, k, chunks):
     """A capacity hint is a promise the engine must survive: with one the deferred window never ends for the
