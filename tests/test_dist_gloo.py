@@ -404,6 +404,43 @@ class NumpyOwnerEngine:
     owned = None
 
 
+class NumpyOwnerEngineTwoCalls(NumpyOwnerEngine):
+    """The same stand-in with the scatter in two calls (include/shk.h: shk_xchg_scatter_begin / _end), behaving like the
+    device engine: begin hands out the segments and reports nothing; what the scatter found — an invalid byte, foreign
+    spills — comes out of end.  Keeps the order of the calls OwnerCounter makes."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.calls, self._held = [], None
+
+    def xchg_scatter_begin_tensors(self, bases, offsets, n_seqs, n_bases, layout_bases=0):
+        assert self._held is None, "begin before the last scatter was ended"
+        self.calls.append("begin")
+        try:
+            rec, cur, lay, nf = self.xchg_scatter_tensors(bases, offsets, n_seqs, n_bases, layout_bases)
+            self._held = (None, nf)
+        except RuntimeError as e:  # (the device finds the byte while the host has already gone on: reported by end)
+            rec, cur, lay, _ = self.xchg_scatter_tensors(0, 0, 0, 0, layout_bases)
+            self._held = (e, 0)
+        return rec, cur, lay
+
+    def xchg_scatter_end(self):
+        assert self._held is not None, "end without a begin"
+        self.calls.append("end")
+        (e, nf), self._held = self._held, None
+        if e is not None:
+            raise e
+        return nf
+
+    def xchg_absorb_tensors(self, rec_t, cur_t, lay):
+        self.calls.append("absorb")
+        super().xchg_absorb_tensors(rec_t, cur_t, lay)
+
+
+def _owner_engine(*a):
+    return (NumpyOwnerEngineTwoCalls if os.environ.get("SHK_TEST_TWO_CALL_ENGINE") else NumpyOwnerEngine)(*a)
+
+
 def _owner_worker(rank, world, port, k, chunks, histo_max, n_reads, log_p1, cap, poly, out_dir):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -414,7 +451,7 @@ def _owner_worker(rank, world, port, k, chunks, histo_max, n_reads, log_p1, cap,
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bases, offsets = _owner_input(sa, n_reads, poly)
-    eng = NumpyOwnerEngine(k, chunks, histo_max, world, rank, log_p1, cap)
+    eng = _owner_engine(k, chunks, histo_max, world, rank, log_p1, cap)
     oc = OwnerCounter(eng, dist, round_bases=1000 * 160)
     mine = shard_batches(n_reads, rank, world)
     for r in range(len(shard_batches(n_reads, 0, world))):
@@ -424,6 +461,8 @@ def _owner_worker(rank, world, port, k, chunks, histo_max, n_reads, log_p1, cap,
         else:
             oc.round(None)
     hist = oc.finalize_histograms()
+    if hasattr(eng, "calls"):
+        open(os.path.join(out_dir, f"calls_{rank}.txt"), "w").write(" ".join(eng.calls))
     np.save(os.path.join(out_dir, f"hist_{rank}.npy"), hist)
     np.save(os.path.join(out_dir, f"tot_{rank}.npy"),
             np.array([oc.totals[x] for x in ("n_reads_ingested", "n_bases_read", "n_bases_ingested",
@@ -503,7 +542,7 @@ def _owner_error_worker(rank, world, port, k, out_dir):
     bases, offsets = _owner_input(sa, n_reads, False)
     bases = bases.copy()
     bases[int(offsets[3100]) + 2] = ord("x")   # read 3100: rank 1's second batch (batches of 1000 go round robin)
-    eng = NumpyOwnerEngine(k, 2, 40, world, rank, 10 if k <= 21 else 10, 1024)
+    eng = _owner_engine(k, 2, 40, world, rank, 10 if k <= 21 else 10, 1024)
     oc = OwnerCounter(eng, dist, round_bases=1000 * 160)
     mine = shard_batches(n_reads, rank, world)
     outcome = "finished"
@@ -528,3 +567,37 @@ def test_a_failing_rank_takes_every_rank_out_of_the_pipelined_rounds(tmp_path, k
     o1 = (tmp_path / "outcome_1.txt").read_text()
     assert "Invalid character 'x' in sequence. Only ACGTN allowed." in o1, o1
     assert "a peer rank failed" in o0, o0
+
+
+
+@pytest.mark.parametrize("k,chunks,n_reads,log_p1,cap,poly", [(21, 10, 3300, 10, 1024, False), (15, 3, 2500, 4, 1024, True)])
+def test_two_rank_owner_rounds_with_the_scatter_in_two_calls(orc, tmp_path, monkeypatch, k, chunks, n_reads, log_p1, cap, poly):
+    """An engine that has shk_xchg_scatter_begin / _end (every device engine): OwnerCounter begins round r's scatter,
+    launches the absorbs of round r − 1's segments — W of them — and only then asks for the scatter's outcome; the last
+    round's segments are absorbed at finalize.  Same histograms, same totals, foreign spills (the skewed case) included."""
+    import sharkmer_amd as sa
+    monkeypatch.setenv("SHK_TEST_TWO_CALL_ENGINE", "1")
+    port = _free_port()
+    mp.spawn(_owner_worker, args=(2, port, k, chunks, 40, n_reads, log_p1, cap, poly, str(tmp_path)), nprocs=2, join=True)
+    bases, offsets = _owner_input(sa, n_reads, poly)
+    ref = orc.run_batch(bases, offsets, k, chunks, 40)
+    h0, h1 = np.load(tmp_path / "hist_0.npy"), np.load(tmp_path / "hist_1.npy")
+    assert np.array_equal(h0, h1) and np.array_equal(h0, ref.histograms())
+    t0 = np.load(tmp_path / "tot_0.npy")
+    assert list(t0[:5]) == [ref.stats[x] for x in ("n_reads_ingested", "n_bases_read", "n_bases_ingested", "n_kmers_ingested", "n_unique_kmers")]
+    if poly:
+        assert t0[5] > 0   # rounds with foreign spills
+    n_rounds = -(-n_reads // 2000)
+    for rank in (0, 1):
+        calls = (tmp_path / f"calls_{rank}.txt").read_text().split()
+        assert calls == ["begin", "end"] + ["begin", "absorb", "absorb", "end"] * (n_rounds - 1) + ["absorb", "absorb"], calls
+
+
+def test_a_byte_found_at_the_scatter_s_end_takes_every_rank_out(tmp_path, monkeypatch):
+    """The two-call scatter reports an invalid byte from its END, after the previous round's absorbs have been launched:
+    the failing rank raises the reference's text, its peer "a peer rank failed", nobody hangs."""
+    monkeypatch.setenv("SHK_TEST_TWO_CALL_ENGINE", "1")
+    port = _free_port()
+    mp.spawn(_owner_error_worker, args=(2, port, 21, str(tmp_path)), nprocs=2, join=True)
+    assert "Invalid character 'x' in sequence. Only ACGTN allowed." in (tmp_path / "outcome_1.txt").read_text()
+    assert "a peer rank failed" in (tmp_path / "outcome_0.txt").read_text()
