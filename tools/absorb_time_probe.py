@@ -1,4 +1,7 @@
 import os, sys, time, json
+# Per-round host times of the exchange scatter and absorb calls (what found the runtime's one-time stall).
+# The probe times the ONE-call scatter (xchg_scatter_tensors), so it asks OwnerCounter for that form.
+os.environ.setdefault("SHK_DIST_ONE_CALL_SCATTER", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 import sharkmer_amd as sa
